@@ -1,0 +1,81 @@
+"""Weight container (.kpbw) shared by the HIP path and the parity oracle.
+
+Layout (little endian): 16-byte header {magic "KPBWGT1\\0", u32 arch, u32 n}, n records of
+{char name[40]; u32 ndim; u32 dims[4]; u32 offset_in_floats}, then the fp32 payload.
+Tensors keep the reference's OIHW order; kernels repack at kpb_net_create time.
+
+``fold_alike`` turns a state_dict of models/ALike.py (ALNet) into the folded tensor set:
+eval-mode BatchNorm (model_interface.py:86) is folded into the preceding conv.
+"""
+import struct
+
+import numpy as np
+
+MAGIC = b"KPBWGT1\0"
+ARCH_ALIKE = 1
+_REC = struct.Struct("<40sI4II")
+
+
+def pack(tensors: dict, arch: int) -> bytes:
+    names = list(tensors)
+    recs, payload, off = [], [], 0
+    for n in names:
+        a = np.ascontiguousarray(np.asarray(tensors[n], dtype=np.float32))
+        dims = list(a.shape) + [1] * (4 - a.ndim)
+        recs.append(_REC.pack(n.encode(), a.ndim, *dims, off))
+        payload.append(a.tobytes())
+        off += a.size
+    return MAGIC + struct.pack("<II", arch, len(names)) + b"".join(recs) + b"".join(payload)
+
+
+def unpack(blob: bytes):
+    assert blob[:8] == MAGIC, "not a .kpbw blob"
+    arch, n = struct.unpack_from("<II", blob, 8)
+    base = 16 + n * _REC.size
+    out = {}
+    for i in range(n):
+        name, ndim, d0, d1, d2, d3, off = _REC.unpack_from(blob, 16 + i * _REC.size)
+        shape = (d0, d1, d2, d3)[:ndim]
+        cnt = int(np.prod(shape)) if ndim else 1
+        out[name.rstrip(b"\0").decode()] = np.frombuffer(blob, np.float32, cnt, base + 4 * off).reshape(shape).copy()
+    return arch, out
+
+
+def _np(v):
+    return v.detach().cpu().numpy().astype(np.float64) if hasattr(v, "detach") else np.asarray(v, np.float64)
+
+
+def _fold(sd, conv, bn, eps=1e-5):
+    w = _np(sd[conv + ".weight"])
+    g, b = _np(sd[bn + ".weight"]), _np(sd[bn + ".bias"])
+    mu, var = _np(sd[bn + ".running_mean"]), _np(sd[bn + ".running_var"])
+    s = g / np.sqrt(var + eps)
+    return (w * s[:, None, None, None]).astype(np.float32), (b - mu * s).astype(np.float32)
+
+
+def fold_alike(sd) -> dict:
+    """state_dict of ALNet (models/ALike.py:84-134) -> folded tensors named as csrc/alike.hip expects."""
+    t = {}
+    t["b1c1.w"], t["b1c1.b"] = _fold(sd, "block1.conv1", "block1.bn1")
+    t["b1c2.w"], t["b1c2.b"] = _fold(sd, "block1.conv2", "block1.bn2")
+    for i in (2, 3, 4):
+        p, q = "block%d" % i, "b%d" % i
+        t[q + "c1.w"], t[q + "c1.b"] = _fold(sd, p + ".conv1", p + ".bn1")
+        t[q + "c2.w"], t[q + "c2.b"] = _fold(sd, p + ".conv2", p + ".bn2")
+        w = _np(sd[p + ".downsample.weight"]).astype(np.float32)
+        t[q + "ds.w"] = w.reshape(w.shape[0], w.shape[1])
+        t[q + "ds.b"] = _np(sd[p + ".downsample.bias"]).astype(np.float32)
+    for i in (1, 2, 3, 4):
+        w = _np(sd["conv%d.weight" % i]).astype(np.float32)
+        t["agg%d.w" % i] = w.reshape(w.shape[0], w.shape[1])
+    w = _np(sd["convhead2.weight"]).astype(np.float32)
+    t["head.w"] = w.reshape(w.shape[0], w.shape[1])
+    return t
+
+
+def load_alike_t():
+    """The ALIKE-t tensors shipped with the package (folded from the reference's weights/alike-t.pth)."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights", "alike-t.kpbw")
+    with open(path, "rb") as f:
+        return unpack(f.read())[1]

@@ -1,0 +1,123 @@
+"""CPU parity oracle for the keypoint_bench hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package.  The product (``keypoint_bench_amd``) never does: it fails loudly when its HIP library is
+missing instead of falling back to anything here.
+
+Two layers:
+  * ``kpb_oracle.c``  -- plain-C restatement (fast enough for 480x640), loaded through ctypes.
+  * ``numpy_ref.py``  -- a literal numpy restatement used on small inputs to cross-check the C code.
+  * ``alike_ref.py``  -- torch-fp32 functional restatement of models/ALike.py:136-164.
+Each function cites the reference file:line it follows; pinning against the reference's own outputs
+is done by tests/test_oracle_golden.py with the fixtures under tests/golden/.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libkpb_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "kpb_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libkpb_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int)
+        dp = ctypes.POINTER(ctypes.c_double)
+        L.kpbo_fast_nms.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.kpbo_fast_nms.restype = ctypes.c_int
+        L.kpbo_detection.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_float, fp, ip, ctypes.c_int]
+        L.kpbo_detection.restype = ctypes.c_int
+        L.kpbo_sample.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, ctypes.c_long,
+                                  ctypes.c_long, fp, ctypes.c_int, ctypes.c_int, fp]
+        L.kpbo_sample.restype = None
+        L.kpbo_match.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                 ip, dp]
+        L.kpbo_match.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+DEFAULT_PARAMS = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=300, min_score=0.0)  # extracter.py:200-205
+
+
+def fast_nms(score_hw, nms_dist):
+    """utils/extracter.py:6-100 on one [H, W] map.  Returns (map, rounds)."""
+    s = _f32(score_hw)
+    out = np.empty_like(s)
+    rounds = lib().kpbo_fast_nms(_fp(s), _fp(out), s.shape[0], s.shape[1], int(nms_dist))
+    return out, rounds
+
+
+def detection(score_hw, params=None):
+    """utils/extracter.py:193-221 on one [H, W] map.  Returns (kps[N,3] float32, flat_idx[N] int32)."""
+    p = dict(DEFAULT_PARAMS) if params is None else params
+    s = _f32(score_hw)
+    H, W = s.shape
+    cap = H * W
+    kps = np.empty((cap, 3), np.float32)
+    idx = np.empty((cap,), np.int32)
+    n = lib().kpbo_detection(_fp(s), H, W, int(p["nms_dist"]), float(p["threshold"]), int(p["border_dist"]),
+                             int(p["top_k"]), float(p["min_score"]), _fp(kps),
+                             idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), cap)
+    return kps[:n].copy(), idx[:n].copy()
+
+
+def sample(desc_chw, pts):
+    """utils/matcher.py:221-226: desc [C, Hd, Wd] (any strides), pts [N, >=2] -> [N, C]."""
+    d = np.asarray(desc_chw, dtype=np.float32)
+    if not d.flags.c_contiguous:
+        d = np.ascontiguousarray(d)
+    C, Hd, Wd = d.shape
+    p = _f32(pts)
+    n = p.shape[0]
+    out = np.empty((n, C), np.float32)
+    if n:
+        lib().kpbo_sample(_fp(d), C, Hd, Wd, Hd * Wd, Wd, 1, _fp(p), n, p.shape[1], _fp(out))
+    return out
+
+
+def match(d0, d1, max_distance=np.inf, cross_check=True):
+    """skimage.feature.match_descriptors as called at utils/matcher.py:227-230 (restated, unpinned).
+    Returns (pairs[K,2] int64, dist[K] float64)."""
+    a, b = _f32(d0), _f32(d1)
+    n, m = a.shape[0], b.shape[0]
+    pairs = np.empty((max(min(n, m), n), 2), np.int32)
+    dist = np.empty((max(n, 1),), np.float64)
+    k = 0
+    if n and m:
+        k = lib().kpbo_match(_fp(a), n, _fp(b), m, a.shape[1], float(max_distance), int(bool(cross_check)),
+                             pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                             dist.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+    return pairs[:k].astype(np.int64), dist[:k].copy()
+
+
+def brute_force_matcher(pts0, pts1, desc0_chw, desc1_chw, params):
+    """utils/matcher.py:206-234 end to end on numpy arrays."""
+    assert params["metric"] == "euclidean"
+    d0 = sample(desc0_chw, pts0)
+    d1 = sample(desc1_chw, pts1)
+    pairs, _ = match(d0, d1, params["max_distance"], params["cross_check"])
+    return np.asarray(pts0)[pairs[:, 0]], np.asarray(pts1)[pairs[:, 1]]

@@ -1,0 +1,226 @@
+/*
+ * kpb_oracle.c -- CPU restatement of the keypoint_bench hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP path in keypoint_bench_amd/csrc.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product never does.
+ *
+ * Every function restates one piece of the reference (linyicheng1/keypoint_bench) and cites it:
+ *   kpbo_fast_nms      utils/extracter.py:6-100    (fast_nms, literal round-by-round semantics)
+ *   kpbo_detection     utils/extracter.py:193-221  (detection = A1 nms -> A2 border -> A3 compaction -> A4 top-k)
+ *   kpbo_sample        utils/matcher.py:221-226    (grid_sample bilinear, align_corners=True, zero padding)
+ *   kpbo_match         utils/matcher.py:227-230    (skimage.feature.match_descriptors; third-party, NOT vendored
+ *                                                   in the reference -> restated from its documented behaviour:
+ *                                                   float64 cdist euclidean, argmin axis 1, cross-check with
+ *                                                   argmin axis 0, strict < max_distance.  PARITY UNPINNED
+ *                                                   for this one function)
+ * Pinning: tests/test_oracle_golden.py checks these against the .npz fixtures in tests/golden, which were produced
+ * by importing the reference's own utils/extracter.py and models/ALike.py (tests/golden/make_golden.py).
+ *
+ * Plain C99, no dependencies.  Build: gcc -O2 -fPIC -shared -ffp-contract=off (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * A1  fast_nms (utils/extracter.py:6-100).
+ * One round (lines 54-96):
+ *   - unfold with zero padding nms_dist, window ks*ks in raster order (54-66)
+ *   - argmax over the window; torch.argmax returns the FIRST index of the maximum, so the centre
+ *     (index ks*ks/2) wins iff it is strictly greater than every earlier cell and >= every later
+ *     cell, where cells outside the image hold 0.0 (69-70)
+ *   - stop when the number of maxima did not change (73-78)
+ *   - otherwise every pixel that has a maximum somewhere in its window, the pixel itself excluded,
+ *     is set to 0.0 (81-96)
+ * Returns the number of rounds executed (number of unfold/argmax evaluations).
+ * ---------------------------------------------------------------------------------------------- */
+int kpbo_fast_nms(const float* in, float* out, int H, int W, int nms_dist)
+{
+    const size_t P = (size_t)H * W;
+    memcpy(out, in, P * sizeof(float));
+    if (nms_dist == 0) return 0; /* extracter.py:40-41 */
+    const int r = nms_dist;
+    unsigned char* ismax = (unsigned char*)malloc(P);
+    long count = -1;
+    int rounds = 0;
+    for (;;) {
+        long new_count = 0;
+        for (int y = 0; y < H; ++y) {
+            for (int x = 0; x < W; ++x) {
+                const float c = out[(size_t)y * W + x];
+                int is = 1;
+                for (int dy = -r; dy <= r && is; ++dy) {
+                    const int yy = y + dy;
+                    for (int dx = -r; dx <= r; ++dx) {
+                        if (dy == 0 && dx == 0) continue;
+                        const int xx = x + dx;
+                        const float v = (yy < 0 || yy >= H || xx < 0 || xx >= W) ? 0.0f : out[(size_t)yy * W + xx];
+                        const int earlier = (dy < 0) || (dy == 0 && dx < 0);
+                        if (earlier ? !(c > v) : !(c >= v)) { is = 0; break; }
+                    }
+                }
+                ismax[(size_t)y * W + x] = (unsigned char)is;
+                new_count += is;
+            }
+        }
+        ++rounds;
+        if (new_count == count) break;
+        count = new_count;
+        /* fold of the expanded mask with the centre channel zeroed, then masked_fill(fold>0, 0) */
+        for (int y = 0; y < H; ++y) {
+            for (int x = 0; x < W; ++x) {
+                if (!ismax[(size_t)y * W + x]) continue;
+                const int y0 = y - r < 0 ? 0 : y - r, y1 = y + r >= H ? H - 1 : y + r;
+                const int x0 = x - r < 0 ? 0 : x - r, x1 = x + r >= W ? W - 1 : x + r;
+                for (int yy = y0; yy <= y1; ++yy)
+                    for (int xx = x0; xx <= x1; ++xx)
+                        if (yy != y || xx != x) out[(size_t)yy * W + xx] = 0.0f;
+            }
+        }
+    }
+    free(ismax);
+    return rounds;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A2  remove_border_points (utils/extracter.py:164-190): zero a border_dist frame, AFTER nms.
+ * Python slice semantics: [:b] and [-b:] clamp to the extent.
+ * ---------------------------------------------------------------------------------------------- */
+void kpbo_remove_border(float* map, int H, int W, int border)
+{
+    if (border <= 0) return;
+    const int bx = border > W ? W : border, by = border > H ? H : border;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if (x < bx || x >= W - bx || y < by || y >= H - by) map[(size_t)y * W + x] = 0.0f;
+}
+
+typedef struct { float s; int idx; } kpbo_cand;
+
+static int cand_cmp_desc(const void* a, const void* b)
+{
+    const kpbo_cand* p = (const kpbo_cand*)a;
+    const kpbo_cand* q = (const kpbo_cand*)b;
+    if (p->s > q->s) return -1;
+    if (p->s < q->s) return 1;
+    return (p->idx > q->idx) - (p->idx < q->idx); /* ties: ascending raster index (tie rule) */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * A5  detection (utils/extracter.py:193-221) = A1 -> A2 -> A3 -> A4.
+ * A3 prob_map_to_positions_with_prob (129-161): raster-order compaction of map > threshold;
+ *    x = (col + 0.5) / W, y = (row + 0.5) / H in float32 (nonzero().float() + 0.5 divided by an
+ *    int64 [H, W] tensor promotes to float32); columns returned as (x, y, score) (161).
+ * A4 (217-220): if N > top_k keep the top_k highest scores, in descending-score order
+ *    (torch.argsort(descending=True); ties are unordered in the reference, here ascending raster
+ *    index); then, if min_score > 0, keep score > min_score.
+ * Returns n; fills out_kps[n*3] and out_idx[n] (flat raster index row*W+col).  cap = capacity.
+ * ---------------------------------------------------------------------------------------------- */
+int kpbo_detection(const float* score, int H, int W, int nms_dist, float threshold, int border,
+                   int top_k, float min_score, float* out_kps, int* out_idx, int cap)
+{
+    const size_t P = (size_t)H * W;
+    float* m = (float*)malloc(P * sizeof(float));
+    kpbo_fast_nms(score, m, H, W, nms_dist);
+    kpbo_remove_border(m, H, W, border);
+    kpbo_cand* c = (kpbo_cand*)malloc(P * sizeof(kpbo_cand));
+    int n = 0;
+    for (size_t i = 0; i < P; ++i)
+        if (m[i] > threshold) { c[n].s = m[i]; c[n].idx = (int)i; ++n; }
+    if (n > top_k) {
+        qsort(c, (size_t)n, sizeof(kpbo_cand), cand_cmp_desc);
+        n = top_k;
+    }
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        if (min_score > 0.0f && !(c[i].s > min_score)) continue;
+        if (k >= cap) break;
+        const int row = c[i].idx / W, col = c[i].idx % W;
+        out_kps[3 * k + 0] = ((float)col + 0.5f) / (float)W;
+        out_kps[3 * k + 1] = ((float)row + 0.5f) / (float)H;
+        out_kps[3 * k + 2] = c[i].s;
+        out_idx[k] = c[i].idx;
+        ++k;
+    }
+    free(c);
+    free(m);
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * M1  descriptor sampling (utils/matcher.py:221-226).
+ *   grid = (xy - 0.5) * 2 ; F.grid_sample(desc_map, grid, align_corners=True)  (bilinear, zeros)
+ * ATen's CPU kernel un-normalises with (g + 1) * ((size - 1) / 2), takes w = x - floor(x),
+ * e = 1 - w (same for y) and sums nw*s*e + ne*s*w + sw*n*e + se*n*w with out-of-range taps = 0.
+ * desc is addressed with explicit element strides (sc, sh, sw) so NCHW and channels-last both work.
+ * pts has row stride pstride floats, columns 0,1 = (x, y) normalised.
+ * ---------------------------------------------------------------------------------------------- */
+void kpbo_sample(const float* desc, int C, int Hd, int Wd, long sc, long sh, long sw_,
+                 const float* pts, int n, int pstride, float* out)
+{
+    const float fx = (float)(Wd - 1) / 2.0f, fy = (float)(Hd - 1) / 2.0f;
+    for (int i = 0; i < n; ++i) {
+        const float gx = (pts[(size_t)i * pstride + 0] - 0.5f) * 2.0f;
+        const float gy = (pts[(size_t)i * pstride + 1] - 0.5f) * 2.0f;
+        const float x = (gx + 1.0f) * fx, y = (gy + 1.0f) * fy;
+        const float xw = floorf(x), yn = floorf(y);
+        const float w = x - xw, e = 1.0f - w, nn = y - yn, s = 1.0f - nn;
+        const float c_nw = s * e, c_ne = s * w, c_sw = nn * e, c_se = nn * w;
+        const long x0 = (long)xw, y0 = (long)yn, x1 = x0 + 1, y1 = y0 + 1;
+        const int vx0 = x0 >= 0 && x0 < Wd, vx1 = x1 >= 0 && x1 < Wd;
+        const int vy0 = y0 >= 0 && y0 < Hd, vy1 = y1 >= 0 && y1 < Hd;
+        for (int ch = 0; ch < C; ++ch) {
+            const float* p = desc + (size_t)ch * sc;
+            const float nw = (vx0 && vy0) ? p[y0 * sh + x0 * sw_] : 0.0f;
+            const float ne = (vx1 && vy0) ? p[y0 * sh + x1 * sw_] : 0.0f;
+            const float sw = (vx0 && vy1) ? p[y1 * sh + x0 * sw_] : 0.0f;
+            const float se = (vx1 && vy1) ? p[y1 * sh + x1 * sw_] : 0.0f;
+            out[(size_t)i * C + ch] = nw * c_nw + ne * c_ne + sw * c_sw + se * c_se;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * M2  skimage.feature.match_descriptors(d0, d1, metric='euclidean', max_distance, cross_check)
+ * as called at utils/matcher.py:227-230 (restated; see file header).
+ *   distances = scipy cdist(float64): sqrt(sum_k (a_k - b_k)^2), k ascending, no FMA
+ *   indices2 = argmin(distances, axis=1) (first index on ties)
+ *   cross_check: keep i where argmin(distances, axis=0)[indices2[i]] == i
+ *   keep distances[i, indices2[i]] < max_distance (strict)
+ * out_pairs[k*2] = (i, j) ascending i; out_dist[k] = distance.  Returns K.
+ * ---------------------------------------------------------------------------------------------- */
+int kpbo_match(const float* d0, int n, const float* d1, int m, int C, double max_distance,
+               int cross_check, int* out_pairs, double* out_dist)
+{
+    if (n == 0 || m == 0) return 0;
+    double* rowmin = (double*)malloc((size_t)n * sizeof(double));
+    int* rowarg = (int*)malloc((size_t)n * sizeof(int));
+    double* colmin = (double*)malloc((size_t)m * sizeof(double));
+    int* colarg = (int*)malloc((size_t)m * sizeof(int));
+    for (int j = 0; j < m; ++j) { colmin[j] = INFINITY; colarg[j] = 0; }
+    for (int i = 0; i < n; ++i) {
+        double best = INFINITY; int arg = 0;
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < C; ++k) {
+                const double d = (double)d0[(size_t)i * C + k] - (double)d1[(size_t)j * C + k];
+                s += d * d;
+            }
+            const double dist = sqrt(s);
+            if (dist < best) { best = dist; arg = j; }
+            if (dist < colmin[j]) { colmin[j] = dist; colarg[j] = i; }
+        }
+        rowmin[i] = best; rowarg[i] = arg;
+    }
+    int K = 0;
+    for (int i = 0; i < n; ++i) {
+        const int j = rowarg[i];
+        if (cross_check && colarg[j] != i) continue;
+        if (!(rowmin[i] < max_distance)) continue;
+        out_pairs[2 * K] = i; out_pairs[2 * K + 1] = j; out_dist[K] = rowmin[i];
+        ++K;
+    }
+    free(rowmin); free(rowarg); free(colmin); free(colarg);
+    return K;
+}
