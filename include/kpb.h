@@ -1,0 +1,136 @@
+/*
+ * kpb.h -- C ABI of libkpb.so: the MI355X (gfx950) keypoint extract -> NMS/top-K -> brute-force
+ * match hot path of linyicheng1/keypoint_bench.
+ *
+ * The reference has no FFI layer of its own: its seams are three Python call signatures
+ * (SURVEY.md section 8b).  Each entry point below names the reference code it replaces; the ctypes
+ * binding a maintainer would add on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer (e.g. torch.Tensor.data_ptr()); the caller owns
+ *     all input and output buffers; nothing is allocated per call once a shape has been seen.
+ *   - all work is enqueued on the context's HIP stream and is asynchronous unless stated.
+ *   - return value: 0 = OK, < 0 = error (KPB_E_*); kpb_last_error() gives the text.
+ *   - one context per process/GPU, single caller thread (the reference runs batch_size 1 from one
+ *     Python thread, config/config_MHA.yaml:10).  ctypes releases the GIL during calls.
+ *   - "batch" lets the runner push many independent images/pairs through one launch wave; the
+ *     reference semantics are those of batch element 0 repeated (utils/extracter.py:161).
+ */
+#ifndef KPB_H
+#define KPB_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPB_VERSION 1
+
+#define KPB_OK 0
+#define KPB_E_INVALID (-1)      /* bad argument / unsupported size */
+#define KPB_E_HIP (-2)          /* a HIP runtime call failed */
+#define KPB_E_NOMEM (-3)        /* workspace allocation failed */
+#define KPB_E_NEGATIVE (-4)     /* score map holds negative values: outside this path's contract */
+#define KPB_E_NOT_CONVERGED (-5)/* NMS sweeps exhausted (only from the *_nosync pipeline paths) */
+#define KPB_E_WEIGHTS (-6)      /* malformed weight blob */
+
+#define KPB_MAX_NMS_DIST 16
+#define KPB_MAX_TOPK 8192       /* bound of the on-chip sort, applies only when top_k < H*W */
+
+typedef struct kpb_ctx kpb_ctx;
+typedef struct kpb_net kpb_net;
+
+/* extractor_params of config/config_MHA.yaml:68-73, read at utils/extracter.py:207-211 */
+typedef struct kpb_detect_params {
+    int32_t nms_dist;
+    float threshold;
+    int32_t border_dist;
+    int32_t top_k;
+    float min_score;
+} kpb_detect_params;
+
+/* brute_force_params of config/config_MHA.yaml:82-85 (metric is always euclidean here) */
+typedef struct kpb_match_params {
+    double max_distance;
+    int32_t cross_check;
+} kpb_match_params;
+
+int kpb_version(void);
+/* ctx may be NULL: returns the message of the last failed call that had no context. */
+const char* kpb_last_error(const kpb_ctx* ctx);
+
+/* device = HIP device ordinal; stream = hipStream_t to enqueue on (NULL = the default stream).
+ * Pass torch.cuda.current_stream().cuda_stream to order against torch work. */
+int kpb_ctx_create(int device, void* stream, kpb_ctx** out);
+void kpb_ctx_destroy(kpb_ctx* ctx);
+int kpb_sync(kpb_ctx* ctx);
+
+/* ---- A1: utils/extracter.py:6-100 fast_nms --------------------------------------------------
+ * score_dev [batch][H][W] fp32, non-negative; out_map_dev same shape (may not alias score_dev).
+ * Synchronous: iterates sweeps until every image reached the fixed point. */
+int kpb_fast_nms(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W, int nms_dist,
+                 float* out_map_dev);
+
+/* ---- A5: utils/extracter.py:193-221 detection (A1 nms, A2 border, A3 compaction, A4 top-k) ---
+ * score_dev [batch][H][W] fp32 (the reference's [1,1,H,W]); not modified.
+ * cap = min(top_k, H*W) rows are reserved per image:
+ * out_kps_dev [batch][cap][3] = (x, y, score), x = (col+0.5)/W, y = (row+0.5)/H;
+ * out_idx_dev [batch][cap] flat raster index row*W+col (may be NULL);
+ * out_n_dev   [batch] number of valid rows (<= cap).
+ * Row order: raster when N <= top_k, descending score (ties: ascending raster index) otherwise.
+ * sync != 0: blocks until done, re-running sweeps for images that had not converged, and
+ * returns KPB_E_NEGATIVE if any map held a negative score.  sync == 0: enqueue only; call
+ * kpb_detect_check() later. */
+int kpb_detect(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W,
+               const kpb_detect_params* params, float* out_kps_dev, int32_t* out_idx_dev,
+               int32_t* out_n_dev, int sync);
+/* After kpb_sync(): status of the last kpb_detect(sync=0): KPB_OK, KPB_E_NOT_CONVERGED or KPB_E_NEGATIVE. */
+int kpb_detect_check(kpb_ctx* ctx);
+
+/* ---- M1: utils/matcher.py:221-226 descriptor sampling (grid_sample, align_corners=True) -----
+ * desc_dev: [batch] maps of C channels, Hd x Wd, element strides (sb, sc, sh, sw) so both NCHW and
+ * channels-last tensors work.  pts_dev [batch][max_n][pts_cols] (cols 0,1 = x,y normalised).
+ * n_dev [batch] valid rows per item, or NULL = max_n everywhere.  out_dev [batch][max_n][C]. */
+int kpb_sample(kpb_ctx* ctx, const float* desc_dev, int batch, int C, int Hd, int Wd, int64_t sb,
+               int64_t sc, int64_t sh, int64_t sw, const float* pts_dev, int pts_cols, int max_n,
+               const int32_t* n_dev, float* out_dev);
+
+/* ---- M2: skimage.feature.match_descriptors as called at utils/matcher.py:227-230 -------------
+ * d0_dev [batch][max_n][C], d1_dev [batch][max_m][C] fp32; n_dev/m_dev [batch] or NULL.
+ * float64 euclidean distances, argmin with first-index ties, optional cross-check, strict
+ * < max_distance.  out_pairs_dev [batch][max_n][2] int32 (i, j) ascending i;
+ * out_dist_dev [batch][max_n] float64 (may be NULL); out_k_dev [batch]. */
+int kpb_match(kpb_ctx* ctx, const float* d0_dev, const float* d1_dev, int batch, int C, int max_n,
+              int max_m, const int32_t* n_dev, const int32_t* m_dev, const kpb_match_params* params,
+              int32_t* out_pairs_dev, double* out_dist_dev, int32_t* out_k_dev);
+
+/* ---- M3: utils/matcher.py:231-233 row gather ---------------------------------------------------
+ * out[b][i][:] = src[b][idx[b][i*idx_stride + idx_col]][:] for i < k[b].  cols floats per row. */
+int kpb_gather_rows(kpb_ctx* ctx, const float* src_dev, int batch, int src_rows, int cols,
+                    const int32_t* idx_dev, int idx_rows, int idx_stride, int idx_col,
+                    const int32_t* k_dev, float* out_dev);
+
+/* ---- N1..: extractor networks (models/ALike.py:136-164 ALNet.forward, ...) ---------------------
+ * arch: KPB_ARCH_*.  blob: a .kpbw container (keypoint_bench_amd/weights.py) holding the folded
+ * tensors; copied, the caller may free it. */
+#define KPB_ARCH_ALIKE 1
+int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len, kpb_net** out);
+void kpb_net_destroy(kpb_net* net);
+int kpb_net_desc_dim(const kpb_net* net);
+/* img_dev [batch][3][H][W] fp32 RGB in [0,1], H and W multiples of 32 (model_interface.py:192-204).
+ * score_out_dev [batch][H][W]; desc_out_dev [batch][H][W][C] (channels-last storage of the
+ * reference's [B,C,H,W] tensor) or NULL to skip the dense descriptor map (the features needed by
+ * kpb_net_desc_at stay resident in the context until the next forward). */
+int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H, int W,
+                    float* score_out_dev, float* desc_out_dev);
+/* Descriptors of the last forward at keypoints, equal to sampling the dense map with kpb_sample
+ * (the head and bilinear sampling are both linear): pts/n/out as in kpb_sample. */
+int kpb_net_desc_at(kpb_net* net, const float* pts_dev, int pts_cols, int max_n,
+                    const int32_t* n_dev, float* out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPB_H */

@@ -1,0 +1,108 @@
+"""ctypes binding of libkpb.so (include/kpb.h).  There is no CPU fallback: if the HIP library is
+missing or no gfx950 device is visible, every entry point raises."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libkpb.so")
+
+c_int, c_float, c_double, c_void_p, c_int64, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
+                                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t)
+
+
+class DetectParams(ctypes.Structure):
+    _fields_ = [("nms_dist", ctypes.c_int32), ("threshold", c_float), ("border_dist", ctypes.c_int32),
+                ("top_k", ctypes.c_int32), ("min_score", c_float)]
+
+
+class MatchParams(ctypes.Structure):
+    _fields_ = [("max_distance", c_double), ("cross_check", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/kpb.h one to one (tests check the export list)
+SIGNATURES = {
+    "kpb_version": (c_int, []),
+    "kpb_last_error": (ctypes.c_char_p, [c_void_p]),
+    "kpb_ctx_create": (c_int, [c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "kpb_ctx_destroy": (None, [c_void_p]),
+    "kpb_sync": (c_int, [c_void_p]),
+    "kpb_fast_nms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "kpb_detect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(DetectParams), c_void_p, c_void_p,
+                           c_void_p, c_int]),
+    "kpb_detect_check": (c_int, [c_void_p]),
+    "kpb_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
+                           c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "kpb_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                          ctypes.POINTER(MatchParams), c_void_p, c_void_p, c_void_p]),
+    "kpb_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                                c_void_p]),
+    "kpb_net_create": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
+    "kpb_net_destroy": (None, [c_void_p]),
+    "kpb_net_desc_dim": (c_int, [c_void_p]),
+    "kpb_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "kpb_net_desc_at": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+class KpbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libkpb error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libkpb.so and declare every prototype.  Raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError("%s is missing: run `python -m keypoint_bench_amd.build` (hipcc, gfx950). "
+                               "keypoint_bench_amd has no CPU fallback." % SO_PATH)
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class Context:
+    """One per process / GPU (kpb_ctx).  Enqueues on torch's current stream of `device`."""
+    _instances = {}
+
+    def __init__(self, device_index: int):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("keypoint_bench_amd needs an MI355X (gfx950) GPU; none is visible and there is no "
+                               "CPU fallback")
+        self.lib = load()
+        self.device_index = device_index
+        stream = torch.cuda.current_stream(device_index).cuda_stream
+        h = c_void_p()
+        rc = self.lib.kpb_ctx_create(device_index, c_void_p(stream), ctypes.byref(h))
+        if rc != 0:
+            raise KpbError(rc, self.lib.kpb_last_error(None).decode())
+        self.handle = h
+
+    @classmethod
+    def get(cls, device):
+        import torch
+        idx = device.index if isinstance(device, torch.device) else int(device)
+        if idx is None:
+            idx = torch.cuda.current_device()
+        if idx not in cls._instances:
+            cls._instances[idx] = cls(idx)
+        return cls._instances[idx]
+
+    def check(self, rc):
+        if rc != 0:
+            raise KpbError(rc, self.lib.kpb_last_error(self.handle).decode())
+
+    def sync(self):
+        self.check(self.lib.kpb_sync(self.handle))
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

@@ -1,0 +1,48 @@
+// api.hip -- context lifetime and error reporting of libkpb.so (include/kpb.h).
+#include "kpb_common.h"
+
+char g_kpb_err[512] = {0};
+
+extern "C" __attribute__((visibility("default"))) int kpb_version(void) { return KPB_VERSION; }
+
+extern "C" __attribute__((visibility("default"))) const char* kpb_last_error(const kpb_ctx* ctx) { return ctx ? ctx->err : g_kpb_err; }
+
+extern "C" __attribute__((visibility("default"))) int kpb_ctx_create(int device, void* stream, kpb_ctx** out)
+{
+    if (!out) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_ctx_create: null out pointer");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return kpb_fail(nullptr, KPB_E_HIP, "kpb_ctx_create: no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= count)
+        return kpb_fail(nullptr, KPB_E_INVALID, "kpb_ctx_create: device %d out of range (0..%d)", device, count - 1);
+    hipDeviceProp_t prop;
+    KPB_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return kpb_fail(nullptr, KPB_E_HIP, "kpb_ctx_create: device %d is %s; libkpb.so is built for gfx950 only", device,
+                        prop.gcnArchName);
+    KPB_HIP(nullptr, hipSetDevice(device));
+    kpb_ctx* c = new kpb_ctx();
+    c->device = device;
+    c->stream = static_cast<hipStream_t>(stream);   // NULL = the device's default stream
+    *out = c;
+    return KPB_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) void kpb_ctx_destroy(kpb_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (kpb_buf* b : {&ctx->ws_nms_state, &ctx->ws_nms_map, &ctx->ws_cand, &ctx->ws_match, &ctx->ws_misc})
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_sync(kpb_ctx* ctx)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_sync: null context");
+    KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return KPB_OK;
+}

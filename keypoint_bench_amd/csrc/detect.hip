@@ -1,0 +1,548 @@
+// detect.hip -- A1..A5 of the hot path: radius-NMS to its fixed point, border mask, raster compaction,
+// top-K.  Replaces utils/extracter.py:6-100 (fast_nms), 164-190, 129-161 and 193-221 of the reference.
+//
+// NMS formulation (DESIGN.md "NMS fixed point"): for a non-negative map the reference's
+// unfold/argmax/fold loop converges to the unique fixed point in which a pixel survives iff it is
+// the (value desc, raster index asc) maximum of its (2r+1)^2 window among survivors.  The two
+// inference rules -- "p is a maximum once every pixel ahead of it in its window is dead" and "q is
+// dead once a maximum lies within r of it" -- are monotone, so they may be applied in any order and
+// on stale neighbour state; every schedule ends in the same map.  nms_sweep therefore iterates whole
+// rounds inside LDS on a 32x64 tile with a 2r halo (no 207 MB unfold buffers, the 1.2 MB map stays in
+// L2), updates the map in place, and is re-launched until no tile changed.
+#include "kpb_common.h"
+
+namespace {
+
+constexpr int TH = 32, TW = 64, NMS_THREADS = 256, MAXLIST = 1024;
+
+struct NmsArgs {
+    const float* src;   // [B][P] input maps (read by sweep 0)
+    float* cur;         // [B][P] working maps (written by sweep 0, updated in place afterwards)
+    int* tchg_prev;     // [B][ntiles] tile-changed flags of the previous sweep (unused in sweep 0)
+    int* tchg_cur;      // [B][ntiles] flags written by this sweep
+    int* lastchg;       // [B] 1 + index of the last sweep that changed anything
+    int* negflag;       // [B] set when a negative score is seen
+    int H, W, r, tiles_y, tiles_x, sweep, max_local;
+};
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_sweep(NmsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int r = a.r, LH = TH + 4 * r, LW = TW + 4 * r;
+    float* t = reinterpret_cast<float*>(smem);      // tile values: >0 alive, 0 dead, <0 confirmed maximum
+    float* e = t + LH * LW;                         // row maxima over [x-r, x+r]
+    int* maxlist = reinterpret_cast<int*>(e + LH * LW);
+    int* s_cnt = maxlist + MAXLIST;                 // [0] new maxima, [1] any kill, [2] owned kill, [3] overflow
+
+    const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    int* tcur = a.tchg_cur + (size_t)img * ntiles;
+
+    if (a.sweep > 0) {  // skip tiles whose 3x3 neighbourhood was quiet last sweep (uniform branch)
+        const int* tprev = a.tchg_prev + (size_t)img * ntiles;
+        int need = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = ty + dy, xx = tx + dx;
+                if (yy >= 0 && yy < a.tiles_y && xx >= 0 && xx < a.tiles_x) need |= tprev[yy * a.tiles_x + xx];
+            }
+        if (!need) {
+            if (tid == 0) tcur[tile] = 0;
+            return;
+        }
+    }
+
+    const size_t P = (size_t)a.H * a.W;
+    const float* in = (a.sweep == 0 ? a.src : a.cur) + (size_t)img * P;
+    float* out = a.cur + (size_t)img * P;
+    const int gy0 = ty * TH - 2 * r, gx0 = tx * TW - 2 * r;
+
+    int neg = 0;
+    for (int i = tid; i < LH * LW; i += NMS_THREADS) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = gy0 + ly, gx = gx0 + lx;
+        float v = 0.0f;  // F.unfold's zero padding (extracter.py:54-60)
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)gy * a.W + gx];
+        neg |= (v < 0.0f);
+        t[i] = v;
+    }
+    if (tid < 4) s_cnt[tid] = 0;
+    __syncthreads();
+    if (neg) a.negflag[img] = 1;
+
+    // the 8 owned pixels this thread writes back
+    float orig[TH * TW / NMS_THREADS];
+#pragma unroll
+    for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
+        const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
+        orig[k] = t[(oy + 2 * r) * LW + ox + 2 * r];
+    }
+
+    const int ks = 2 * r + 1, ks2 = ks * ks, IW = LW - 2 * r, IH = LH - 2 * r;
+    int unconverged = 1;
+    for (int iter = 0; iter < a.max_local; ++iter) {
+        // pass 1: e[y][x] = max t[y][x-r..x+r], all rows, columns [r, LW-r)
+        for (int i = tid; i < LH * IW; i += NMS_THREADS) {
+            const int y = i / IW, x = i - y * IW + r;
+            const float* row = t + y * LW + x;
+            float m = row[-r];
+            for (int d = -r + 1; d <= r; ++d) m = fmaxf(m, row[d]);
+            e[y * LW + x] = m;
+        }
+        __syncthreads();
+        // pass 2: maxima among alive pixels of the inset region (their whole window is in LDS).
+        // argmax returns the first index of the maximum (extracter.py:69-70): the centre must be
+        // strictly greater than the rows above and the cells to its left, >= the rest.
+        for (int i = tid; i < IH * IW; i += NMS_THREADS) {
+            const int y = i / IW + r, x = i - (y - r) * IW + r;
+            const float v = t[y * LW + x];
+            if (v > 0.0f && v == e[y * LW + x]) {
+                bool ok = true;
+                for (int d = 1; d <= r && ok; ++d) ok = v > t[y * LW + x - d];
+                for (int d = 1; d <= r && ok; ++d) ok = (v > e[(y - d) * LW + x]) && (v >= e[(y + d) * LW + x]);
+                if (ok) {
+                    const int slot = atomicAdd(&s_cnt[0], 1);
+                    if (slot < MAXLIST) maxlist[slot] = y * LW + x;
+                    else s_cnt[3] = 1;
+                }
+            }
+        }
+        __syncthreads();
+        const int nmax = min(s_cnt[0], MAXLIST);
+        // kill pass: zero the window of every new maximum (extracter.py:81-96), mark the maximum itself
+        for (int i = tid; i < nmax * ks2; i += NMS_THREADS) {
+            const int m = i / ks2, c = i - m * ks2;
+            const int dy = c / ks - r, dx = c - (dy + r) * ks - r;
+            const int pos = maxlist[m] + dy * LW + dx;
+            if (dy == 0 && dx == 0) {
+                t[pos] = -t[pos];
+            } else if (t[pos] != 0.0f) {
+                t[pos] = 0.0f;
+                s_cnt[1] = 1;
+                const int py = pos / LW - 2 * r, px = pos - (py + 2 * r) * LW - 2 * r;
+                if (py >= 0 && py < TH && px >= 0 && px < TW) s_cnt[2] = 1;
+            }
+        }
+        __syncthreads();
+        const int any_kill = s_cnt[1], overflow = s_cnt[3];
+        __syncthreads();
+        if (tid == 0) { s_cnt[0] = 0; s_cnt[1] = 0; s_cnt[3] = 0; }
+        __syncthreads();
+        if (!any_kill && !overflow) { unconverged = 0; break; }
+    }
+
+    // write back owned pixels that changed (sweep 0 writes everything: it materialises cur)
+    const int by = ty * TH, bx = tx * TW;
+#pragma unroll
+    for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
+        const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
+        const int gy = by + oy, gx = bx + ox;
+        if (gy < a.H && gx < a.W) {
+            const float v = fabsf(t[(oy + 2 * r) * LW + ox + 2 * r]);
+            if (a.sweep == 0 || v != orig[k]) out[(size_t)gy * a.W + gx] = v;
+        }
+    }
+    if (tid == 0) {
+        const int flag = (s_cnt[2] || unconverged) ? 1 : 0;
+        tcur[tile] = flag;
+        if (flag) atomicMax(&a.lastchg[img], a.sweep + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2 + A3 + A4: one 1024-thread workgroup per image.
+__device__ __forceinline__ unsigned f2key(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+constexpr int SEL_THREADS = 1024, SEL_WAVES = SEL_THREADS / 64;
+
+// exclusive block scan of a pair of counters packed in 64 bits; returns exclusive value, total via ref
+__device__ __forceinline__ unsigned long long block_scan(unsigned long long v, unsigned long long* wsum,
+                                                         unsigned long long& total)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    unsigned long long base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_WAVES; ++w) {
+        const unsigned long long s = wsum[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+struct SelArgs {
+    const float* map;            // [B][P] map after NMS (or the input map when nms_dist == 0)
+    unsigned long long* cand;    // [B][P] scratch: (key << 32) | ~idx in raster order
+    float* out_kps;              // [B][top_k][3]
+    int* out_idx;                // [B][top_k] or null
+    int* out_n;                  // [B]
+    int H, W, border, top_k, kpad;
+    float threshold, min_score;
+};
+
+__device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned long long* src, int n,
+                                     unsigned long long* wsum)
+{
+    // ordered compaction with the min_score predicate (extracter.py:219-220), then (x, y, score) rows
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += SEL_THREADS) {
+        const int i = c0 + threadIdx.x;
+        unsigned long long ent = 0;
+        bool keep = false;
+        float s = 0.0f;
+        if (i < n) {
+            ent = src[i];
+            s = key2f((unsigned)(ent >> 32));
+            keep = !(a.min_score > 0.0f) || (s > a.min_score);
+        }
+        unsigned long long tot;
+        const unsigned long long ex = block_scan(keep ? 1ull : 0ull, wsum, tot);
+        if (keep) {
+            const int pos = base + (int)ex;
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(ent & 0xFFFFFFFFull);
+            const int row = idx / a.W, col = idx - row * a.W;
+            float* o = a.out_kps + ((size_t)img * a.top_k + pos) * 3;
+            o[0] = __fdiv_rn((float)col + 0.5f, (float)a.W);   // extracter.py:149,158
+            o[1] = __fdiv_rn((float)row + 0.5f, (float)a.H);
+            o[2] = s;
+            if (a.out_idx) a.out_idx[(size_t)img * a.top_k + pos] = (int)idx;
+        }
+        base += (int)tot;
+    }
+    if (threadIdx.x == 0) a.out_n[img] = base;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem);   // [kpad]
+    __shared__ unsigned long long wsum[SEL_WAVES];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_krem;
+
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int P = a.H * a.W;
+    const float* map = a.map + (size_t)img * P;
+    unsigned long long* cand = a.cand + (size_t)img * P;
+    const int bx = min(max(a.border, 0), a.W), by = min(max(a.border, 0), a.H);
+
+    // A2 + A3: border mask and raster-order compaction of map > threshold
+    int n = 0;
+    const bool vec = ((P & 3) == 0) && ((reinterpret_cast<uintptr_t>(map) & 15) == 0);
+    for (int c0 = 0; c0 < P; c0 += SEL_THREADS * 4) {
+        const int i0 = c0 + tid * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vec && i0 + 3 < P) {
+            const float4 q = *reinterpret_cast<const float4*>(map + i0);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (i0 + j < P) v[j] = map[i0 + j];
+        }
+        bool pred[4];
+        int cnt = 0;
+        int row = i0 / a.W, col = i0 - row * a.W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool inside = (i0 + j < P) && col >= bx && col < a.W - bx && row >= by && row < a.H - by;
+            pred[j] = inside && (v[j] > a.threshold);
+            cnt += pred[j];
+            if (++col == a.W) { col = 0; ++row; }
+        }
+        unsigned long long tot;
+        int pos = n + (int)block_scan((unsigned long long)cnt, wsum, tot);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (pred[j]) cand[pos++] = ((unsigned long long)f2key(v[j]) << 32) | (0xFFFFFFFFu - (unsigned)(i0 + j));
+        n += (int)tot;
+    }
+    __syncthreads();
+
+    if (n <= a.top_k) {  // raster order kept (extracter.py:217)
+        emit(a, img, cand, n, wsum);
+        return;
+    }
+
+    // A4: radix select of the top_k-th largest key, 8 bits per pass
+    if (tid == 0) { s_prefix = 0; s_krem = (unsigned)a.top_k; }
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < n; i += SEL_THREADS) {
+            const unsigned k = (unsigned)(cand[i] >> 32);
+            if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned krem = s_krem, cum = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (cum + hist[d] >= krem) break;
+                cum += hist[d];
+            }
+            s_krem = krem - cum;
+            s_prefix = prefix | ((unsigned)d << shift);
+        }
+        __syncthreads();
+    }
+    const unsigned T = s_prefix, krem = s_krem;   // take every key > T and the first krem keys == T
+
+    for (int i = tid; i < a.kpad; i += SEL_THREADS) sel[i] = 0ull;
+    __syncthreads();
+    unsigned gt_base = 0, eq_base = 0;
+    for (int c0 = 0; c0 < n; c0 += SEL_THREADS) {
+        const int i = c0 + tid;
+        unsigned long long ent = 0;
+        bool gt = false, eq = false;
+        if (i < n) {
+            ent = cand[i];
+            const unsigned k = (unsigned)(ent >> 32);
+            gt = k > T;
+            eq = k == T;
+        }
+        unsigned long long tot;
+        const unsigned long long ex = block_scan((gt ? 1ull : 0ull) | (eq ? (1ull << 32) : 0ull), wsum, tot);
+        const unsigned gtb = gt_base + (unsigned)(ex & 0xFFFFFFFFull), eqb = eq_base + (unsigned)(ex >> 32);
+        if (gt || (eq && eqb < krem)) sel[gtb + min(eqb, krem)] = ent;
+        gt_base += (unsigned)(tot & 0xFFFFFFFFull);
+        eq_base += (unsigned)(tot >> 32);
+    }
+    __syncthreads();
+
+    // bitonic sort, descending on (key, ~idx): score descending, ties ascending raster index
+    for (int k = 2; k <= a.kpad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < a.kpad; i += SEL_THREADS) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = sel[i], y = sel[l];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { sel[i] = y; sel[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    emit(a, img, sel, a.top_k, wsum);
+}
+
+int next_pow2(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int env_int(const char* name, int dflt)
+{
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+struct NmsPlan {
+    int tiles_x, tiles_y, ntiles;
+    size_t lds;
+    int* tchg[2];
+    int* lastchg;
+    int* negflag;
+};
+
+int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p)
+{
+    p.tiles_x = cdiv(W, TW);
+    p.tiles_y = cdiv(H, TH);
+    p.ntiles = p.tiles_x * p.tiles_y;
+    const int LH = TH + 4 * r, LW = TW + 4 * r;
+    p.lds = (size_t)2 * LH * LW * sizeof(float) + (MAXLIST + 4) * sizeof(int);
+    const size_t nflag = (size_t)batch * p.ntiles;
+    const size_t bytes = (2 * nflag + 2 * (size_t)batch) * sizeof(int);
+    if (int rc = kpb_reserve(ctx, ctx->ws_nms_state, bytes)) return rc;
+    int* base = static_cast<int*>(ctx->ws_nms_state.p);
+    p.lastchg = base;
+    p.negflag = base + batch;
+    p.tchg[0] = base + 2 * batch;
+    p.tchg[1] = p.tchg[0] + nflag;
+    static bool attr_set = false;
+    if (!attr_set) {
+        KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    return KPB_OK;
+}
+
+int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int batch, int H, int W, int r,
+               int first_sweep, int nsweeps)
+{
+    for (int s = first_sweep; s < first_sweep + nsweeps; ++s) {
+        NmsArgs a;
+        a.src = src; a.cur = cur;
+        a.tchg_prev = p.tchg[(s + 1) & 1];
+        a.tchg_cur = p.tchg[s & 1];
+        a.lastchg = p.lastchg; a.negflag = p.negflag;
+        a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
+        a.sweep = s; a.max_local = 64;
+        hipLaunchKernelGGL(nms_sweep, dim3(p.ntiles, batch), dim3(NMS_THREADS), p.lds, ctx->stream, a);
+    }
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+// reads lastchg/negflag back; returns number of images that changed in sweep (sweeps_run - 1), sets neg
+int nms_status(kpb_ctx* ctx, const NmsPlan& p, int batch, int sweeps_run, int& pending, int& neg)
+{
+    std::vector<int> h(2 * (size_t)batch);
+    KPB_HIP(ctx, hipMemcpyAsync(h.data(), p.lastchg, h.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pending = 0; neg = 0;
+    for (int b = 0; b < batch; ++b) {
+        pending += (h[b] >= sweeps_run);
+        neg |= h[batch + b];
+    }
+    return KPB_OK;
+}
+
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W, int nms_dist,
+                            float* out_map_dev)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_fast_nms: null context");
+    if (!score_dev || !out_map_dev || batch <= 0 || H <= 0 || W <= 0 || nms_dist < 0 || nms_dist > KPB_MAX_NMS_DIST)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_fast_nms: bad argument (nms_dist must be 0..%d)", KPB_MAX_NMS_DIST);
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)batch * H * W * sizeof(float);
+    if (nms_dist == 0) {  // extracter.py:40-41
+        KPB_HIP(ctx, hipMemcpyAsync(out_map_dev, score_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return KPB_OK;
+    }
+    NmsPlan p;
+    if (int rc = nms_plan(ctx, batch, H, W, nms_dist, p)) return rc;
+    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
+    const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+    int run = 0, pending = 1, neg = 0;
+    while (pending) {
+        if (int rc = nms_launch(ctx, p, score_dev, out_map_dev, batch, H, W, nms_dist, run, chunk)) return rc;
+        run += chunk;
+        if (int rc = nms_status(ctx, p, batch, run, pending, neg)) return rc;
+        if (neg) return kpb_fail(ctx, KPB_E_NEGATIVE, "kpb_fast_nms: negative scores are outside this path's contract");
+        if (run > 100000) return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_fast_nms: no fixed point after %d sweeps", run);
+    }
+    return KPB_OK;
+}
+
+namespace {
+struct DetState {
+    NmsPlan plan;
+    const float* score; float* cur; unsigned long long* cand;
+    int batch, H, W; kpb_detect_params prm;
+    float* out_kps; int* out_idx; int* out_n;
+    int sweeps_run;
+} g_det;
+
+int det_select(kpb_ctx* ctx, const DetState& d)
+{
+    SelArgs s;
+    s.map = d.prm.nms_dist == 0 ? d.score : d.cur;
+    s.cand = d.cand;
+    s.out_kps = d.out_kps; s.out_idx = d.out_idx; s.out_n = d.out_n;
+    s.H = d.H; s.W = d.W; s.border = d.prm.border_dist; s.top_k = d.prm.top_k;
+    s.kpad = d.prm.top_k >= d.H * d.W ? 0 : next_pow2(d.prm.top_k);
+    s.threshold = d.prm.threshold; s.min_score = d.prm.min_score;
+    hipLaunchKernelGGL(select_topk, dim3(d.batch), dim3(SEL_THREADS), (size_t)s.kpad * sizeof(unsigned long long),
+                       ctx->stream, s);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W,
+                          const kpb_detect_params* prm, float* out_kps_dev, int32_t* out_idx_dev,
+                          int32_t* out_n_dev, int sync)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_detect: null context");
+    if (!score_dev || !prm || !out_kps_dev || !out_n_dev || batch <= 0 || H <= 0 || W <= 0)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: bad argument");
+    if (prm->nms_dist < 0 || prm->nms_dist > KPB_MAX_NMS_DIST)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: nms_dist %d outside 0..%d", prm->nms_dist, KPB_MAX_NMS_DIST);
+    if ((size_t)H * W >= (1u << 31)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: map too large");
+    if (prm->top_k <= 0 || (prm->top_k > KPB_MAX_TOPK && prm->top_k < H * W))
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: top_k %d outside 1..%d (or >= H*W)", prm->top_k, KPB_MAX_TOPK);
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)H * W;
+    DetState& d = g_det;
+    d.score = score_dev; d.batch = batch; d.H = H; d.W = W; d.prm = *prm;
+    if (d.prm.top_k > H * W) d.prm.top_k = H * W;   // N can never exceed H*W: same rows, smaller buffers
+    d.out_kps = out_kps_dev; d.out_idx = out_idx_dev; d.out_n = out_n_dev;
+    if (int rc = kpb_reserve(ctx, ctx->ws_cand, (size_t)batch * P * sizeof(unsigned long long))) return rc;
+    d.cand = static_cast<unsigned long long*>(ctx->ws_cand.p);
+    if (int rc = nms_plan(ctx, batch, H, W, prm->nms_dist, d.plan)) return rc;
+    d.sweeps_run = 0;
+    d.cur = nullptr;
+    if (prm->nms_dist > 0) {
+        if (int rc = kpb_reserve(ctx, ctx->ws_nms_map, (size_t)batch * P * sizeof(float))) return rc;
+        d.cur = static_cast<float*>(ctx->ws_nms_map.p);
+        KPB_HIP(ctx, hipMemsetAsync(d.plan.lastchg, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
+        const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+        if (int rc = nms_launch(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, 0, chunk)) return rc;
+        d.sweeps_run = chunk;
+    }
+    if (int rc = det_select(ctx, d)) return rc;
+    ctx->det_pending = 1;
+    if (!sync) return KPB_OK;
+    return kpb_detect_check(ctx);
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* ctx)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_detect_check: null context");
+    if (!ctx->det_pending) return KPB_OK;
+    DetState& d = g_det;
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    if (d.prm.nms_dist == 0) {
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->det_pending = 0;
+        return KPB_OK;
+    }
+    const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+    for (;;) {
+        int pending = 0, neg = 0;
+        if (int rc = nms_status(ctx, d.plan, d.batch, d.sweeps_run, pending, neg)) return rc;
+        if (neg) {
+            ctx->det_pending = 0;
+            return kpb_fail(ctx, KPB_E_NEGATIVE, "kpb_detect: negative scores are outside this path's contract "
+                                                 "(the reference's zero padding makes them data dependent)");
+        }
+        if (!pending) break;
+        if (d.sweeps_run > 100000) return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_detect: NMS did not converge");
+        if (int rc = nms_launch(ctx, d.plan, d.score, d.cur, d.batch, d.H, d.W, d.prm.nms_dist, d.sweeps_run, chunk)) return rc;
+        d.sweeps_run += chunk;
+        if (int rc = det_select(ctx, d)) return rc;
+    }
+    ctx->det_pending = 0;
+    return KPB_OK;
+}

@@ -1,0 +1,74 @@
+// kpb_common.h -- context, error handling and workspace arena shared by the libkpb.so translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/kpb.h"
+
+struct kpb_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct kpb_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+    // named workspaces, grown on demand (first call of a shape = warm-up), never freed before destroy
+    kpb_buf ws_nms_state;   // per-image / per-tile sweep flags
+    kpb_buf ws_nms_map;     // [batch][H*W] working map
+    kpb_buf ws_cand;        // [batch][H*W] uint64 candidate list (key<<32 | ~idx)
+    kpb_buf ws_match;       // per-tile row/column minima
+    kpb_buf ws_misc;
+    int* host_flags = nullptr;  // pinned, for status read-back
+    // state of the last kpb_detect(sync=0)
+    int det_batch = 0, det_sweeps = 0;
+    int det_pending = 0;
+};
+
+extern char g_kpb_err[512];
+
+inline int kpb_fail(kpb_ctx* ctx, int code, const char* fmt, ...)
+{
+    char* dst = ctx ? ctx->err : g_kpb_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define KPB_HIP(ctx, call)                                                                             \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return kpb_fail(ctx, KPB_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                            __FILE__, __LINE__);                                                       \
+    } while (0)
+
+inline int kpb_reserve(kpb_ctx* ctx, kpb_buf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return KPB_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        b.p = nullptr;
+        return kpb_fail(ctx, KPB_E_NOMEM, "workspace allocation of %zu bytes failed", want);
+    }
+    b.cap = want;
+    return KPB_OK;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,127 @@
+"""GPU parity of A1..A5 (csrc/detect.hip through the C ABI) against the oracle and the reference goldens."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, params_from, assert_kps_equal
+from keypoint_bench_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def test_library_loaded_and_version():
+    from keypoint_bench_amd import _lib
+    assert _lib.load().kpb_version() == 1
+
+
+def test_detection_golden_small():
+    from keypoint_bench_amd.utils.extracter import detection
+    g = load_golden("det_small.npz")
+    for name in g["cases"]:
+        p = params_from(g[name + ".params"])
+        s = torch.from_numpy(g[name + ".score"])[None, None].to(_dev())
+        before = s.clone()
+        kps = detection(s, p).cpu().numpy()
+        assert torch.equal(s, before), "detection must not mutate its input"
+        assert_kps_equal(kps, g[name + ".kps"], p["top_k"], name)
+        okps, _ = oracle.detection(g[name + ".score"], p)
+        np.testing.assert_array_equal(kps.view(np.uint32), okps.view(np.uint32), err_msg=name)  # same tie rule
+
+
+def test_fast_nms_maps_golden():
+    from keypoint_bench_amd.utils.extracter import fast_nms
+    g = load_golden("det_small.npz")
+    for name in g["cases"]:
+        if name + ".nms" not in g.files:
+            continue
+        p = params_from(g[name + ".params"])
+        s = torch.from_numpy(g[name + ".score"])[None, None].to(_dev())
+        out = fast_nms(s, nms_dist=p["nms_dist"])[0, 0].cpu().numpy()
+        np.testing.assert_array_equal(out.view(np.uint32), g[name + ".nms"].view(np.uint32), err_msg=name)
+
+
+def test_detection_default_params_none():
+    from keypoint_bench_amd.utils.extracter import detection
+    g = load_golden("det_small.npz")
+    s = torch.from_numpy(g["defaults_none.score"])[None, None].to(_dev())
+    kps = detection(s, None).cpu().numpy()
+    assert_kps_equal(kps, g["defaults_none.kps"], 300, "defaults")
+
+
+def test_detection_full_size_golden_and_batched():
+    from keypoint_bench_amd.utils.extracter import detection, detection_batch
+    g = load_golden("det_full.npz")
+    gens = dict(uniform=synthetic.score_uniform, smooth=synthetic.score_smooth)
+    maps, wants = [], []
+    for name in g["cases"]:
+        fam, seed = g[name + ".gen"]
+        smap = gens[str(fam)](int(seed), 480, 640)
+        p = params_from(g[name + ".params"])
+        kps = detection(torch.from_numpy(smap)[None, None].to(_dev()), p).cpu().numpy()
+        assert_kps_equal(kps, g[name + ".kps"], p["top_k"], name)
+        if p["nms_dist"] == 6:
+            maps.append(smap)
+            wants.append(g[name + ".kps"])
+    # the batch entry point must give the same rows per image
+    p = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
+    kps, idx, n = detection_batch(torch.from_numpy(np.stack(maps))[:, None].to(_dev()), p)
+    for b, want in enumerate(wants):
+        nb = int(n[b])
+        assert_kps_equal(kps[b, :nb].cpu().numpy(), want, 1000, "batch %d" % b)
+        ii = idx[b, :nb].cpu().numpy()
+        np.testing.assert_array_equal(kps[b, :nb, 2].cpu().numpy(), maps[b].ravel()[ii])
+
+
+def test_detection_on_reference_alike_score_maps():
+    from keypoint_bench_amd.utils.extracter import detection
+    g = load_golden("alike_t.npz")
+    p = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
+    for s, k in (("full.score0", "full.kps0"), ("full.score1", "full.kps1")):
+        kps = detection(torch.from_numpy(g[s])[None, None].to(_dev()), p).cpu().numpy()
+        assert_kps_equal(kps, g[k], 1000, s)
+
+
+@pytest.mark.parametrize("nms", [1, 3, 6, 11, 16])
+def test_detection_random_vs_oracle(nms):
+    from keypoint_bench_amd.utils.extracter import detection
+    rng = np.random.default_rng(1000 + nms)
+    for (H, W, topk, border, thr, ms) in ((70, 130, 64, 5, 0.0, 0.0), (33, 65, 500, 0, 0.3, 0.0), (128, 96, 17, 9, 0.0, 0.5)):
+        for quant in (0, 16):
+            s = rng.random((H, W), dtype=np.float32)
+            if quant:
+                s = np.floor(s * quant).astype(np.float32) / quant
+            p = dict(nms_dist=nms, threshold=thr, border_dist=border, top_k=topk, min_score=ms)
+            want, _ = oracle.detection(s, p)
+            got = detection(torch.from_numpy(s)[None, None].to(_dev()), p).cpu().numpy()
+            np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32),
+                                          err_msg="nms=%d %dx%d quant=%d" % (nms, H, W, quant))
+
+
+def test_negative_scores_fail_loudly():
+    from keypoint_bench_amd.utils.extracter import detection
+    from keypoint_bench_amd._lib import KpbError
+    s = torch.rand(1, 1, 64, 64, device=_dev()) - 0.5
+    with pytest.raises(KpbError):
+        detection(s, dict(nms_dist=4, threshold=0.0, border_dist=4, top_k=100, min_score=0.0))
+
+
+def test_full_size_properties():
+    """Size-independent properties at the BASELINE size: survivors are >= nms_dist+1 apart, every
+    survivor is a local maximum of the input, and detection is idempotent on its own NMS map."""
+    from keypoint_bench_amd.utils.extracter import detection_batch, fast_nms
+    s = torch.from_numpy(np.stack([synthetic.score_uniform(77, 480, 640), synthetic.score_smooth(78, 480, 640)]))[:, None].to(_dev())
+    m = fast_nms(s, nms_dist=6)
+    m2 = fast_nms(m, nms_dist=6)
+    assert torch.equal(m, m2)
+    alive = (m > 0)
+    pooled = torch.nn.functional.max_pool2d(alive.float(), 13, 1, 6) * 0 + torch.nn.functional.avg_pool2d(alive.float(), 13, 1, 6, divisor_override=1)
+    assert float((pooled * alive).max()) == 1.0          # exactly one survivor in each survivor's window
+    wmax = torch.nn.functional.max_pool2d(s, 13, 1, 6)
+    assert bool(((m == s) | (m == 0)).all())
+    kept_vals = m[alive]
+    assert bool((kept_vals <= wmax[alive]).all())
