@@ -1,8 +1,652 @@
-// alike.hip -- placeholder entry points (replaced by the ALIKE forward kernels)
+// alike.hip -- N1: ALIKE forward (models/ALike.py:136-164 ALNet.forward, ConvBlock 25-28, ResBlock 65-81)
+// as hand-written gfx950 kernels.  fp32 throughout (the reference's CPU path is fp32 and the parity
+// contract is 1e-4 on descriptors / bit-stable keypoints, so no bf16 shortcuts).
+//
+// Data layout in HBM: every activation is NHWC fp32 ([B][H][W][C], channel minor) so that one
+// pixel's channels are one contiguous 32..256-byte segment: float4 loads in the conv kernels, whole
+// 128-byte lines in the head's MFMA epilogue, and a channels-last [B,C,H,W] torch view for the dense
+// descriptor map.  The input image stays in the reference's planar [B,3,H,W].
+//
+//   alike_block1   3->8->8 3x3 (+folded BN, ReLU) fused through LDS; VALU fp32 (K=27/72, N=8 is
+//                  too thin for a 32x32 MFMA tile; fp32 MFMA peak equals the VALU peak on gfx950)
+//   conv3x3_k      generic pooled-input 3x3 conv (+bias, +1x1 residual branch, ReLU): block2..4
+//   conv1x1_relu   the four aggregation 1x1 convs
+//   alike_head     per pixel: [relu(agg1 x1) | up2 a2 | up8 a3 | up32 a4] (align_corners bilinear),
+//                  score = sigmoid(w64 . f); dense mode adds the 64->64 descriptor GEMM on
+//                  v_mfma_f32_32x32x2_f32 with the A operand taken straight from the registers that
+//                  built f (K permuted so lane (p,h) owns channels 32h..32h+31) and B resident in VGPRs
+//   alike_desc_at  descriptors at keypoints only: bilinear taps on f, then one 64x64 mat-vec
 #include "kpb_common.h"
-struct kpb_net { kpb_ctx* ctx; };
-extern "C" __attribute__((visibility("default"))) int kpb_net_create(kpb_ctx* ctx, int, const void*, size_t, kpb_net**) { return kpb_fail(ctx, KPB_E_INVALID, "not built"); }
-extern "C" __attribute__((visibility("default"))) void kpb_net_destroy(kpb_net*) {}
-extern "C" __attribute__((visibility("default"))) int kpb_net_desc_dim(const kpb_net*) { return 0; }
-extern "C" __attribute__((visibility("default"))) int kpb_net_forward(kpb_net* n, const float*, int, int, int, float*, float*) { return kpb_fail(n ? n->ctx : nullptr, KPB_E_INVALID, "not built"); }
-extern "C" __attribute__((visibility("default"))) int kpb_net_desc_at(kpb_net* n, const float*, int, int, const int32_t*, float*) { return kpb_fail(n ? n->ctx : nullptr, KPB_E_INVALID, "not built"); }
+
+#include <map>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float relu(float v) { return fmaxf(v, 0.0f); }
+
+// ------------------------------------------------------------------------------------------------ block1
+constexpr int B1_TH = 16, B1_TW = 32;
+
+struct Block1Args {
+    const float* img;   // [B][3][H][W]
+    float* x1;          // [B][H][W][8]
+    const float* w1;    // [27][8]  (cin, ky, kx) major, cout minor
+    const float* b1;    // [8]
+    const float* w2;    // [9][8][8] (tap, cin, cout)
+    const float* b2;    // [8]
+    int H, W;
+};
+
+__global__ __launch_bounds__(256) void alike_block1(Block1Args a)
+{
+    __shared__ float in[3][B1_TH + 4][B1_TW + 4];
+    __shared__ __attribute__((aligned(16))) float mid[B1_TH + 2][B1_TW + 2][8];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int ty0 = blockIdx.y * B1_TH, tx0 = blockIdx.x * B1_TW;
+    const size_t P = (size_t)a.H * a.W;
+    const float* img = a.img + (size_t)b * 3 * P;
+    for (int i = tid; i < 3 * (B1_TH + 4) * (B1_TW + 4); i += 256) {
+        const int c = i / ((B1_TH + 4) * (B1_TW + 4)), rem = i - c * (B1_TH + 4) * (B1_TW + 4);
+        const int y = rem / (B1_TW + 4), x = rem - y * (B1_TW + 4);
+        const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
+        float v = 0.0f;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = img[c * P + (size_t)gy * a.W + gx];
+        in[c][y][x] = v;
+    }
+    __syncthreads();
+    for (int pos = tid; pos < (B1_TH + 2) * (B1_TW + 2); pos += 256) {
+        const int my = pos / (B1_TW + 2), mx = pos - my * (B1_TW + 2);
+        const int gy = ty0 - 1 + my, gx = tx0 - 1 + mx;
+        float acc[8];
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = a.b1[j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float v = in[c][my + ky][mx + kx];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, a.w1[((c * 3 + ky) * 3 + kx) * 8 + j], acc[j]);
+                    }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = relu(acc[j]);
+        } else {   // conv2 pads its INPUT (the ReLU'd map) with zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        }
+        *reinterpret_cast<float4*>(&mid[my][mx][0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(&mid[my][mx][4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    __syncthreads();
+    for (int px = tid; px < B1_TH * B1_TW; px += 256) {
+        const int oy = px / B1_TW, ox = px - oy * B1_TW;
+        const int gy = ty0 + oy, gx = tx0 + ox;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = a.b2[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 lo = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx][0]);
+                const float4 hi = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx][4]);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(v[c], a.w2[((ky * 3 + kx) * 8 + c) * 8 + j], acc[j]);
+            }
+        if (gy < a.H && gx < a.W) {
+            float* o = a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
+            *reinterpret_cast<float4*>(o + 4) = make_float4(relu(acc[4]), relu(acc[5]), relu(acc[6]), relu(acc[7]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv3x3
+struct ConvArgs {
+    const float* in;     // [B][H*POOL][W*POOL][CIN]
+    float* out;          // [B][H][W][COUT]
+    const float* w;      // [9][CIN][COUT]
+    const float* bias;   // [COUT]
+    const float* res_in; // RES: [B][H*RPOOL][W*RPOOL][CDS]
+    const float* ds_w;   // [CDS][COUT]
+    const float* ds_b;   // [COUT]
+    int H, W;            // output size
+};
+
+// Each thread: one pixel x 16 output channels.  Waves split into COUT/16 channel groups and
+// 4/(COUT/16) pixel groups of 4x16 pixels; weights are wave-uniform -> scalar loads.
+template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool RELU>
+__global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
+{
+    constexpr int G = COUT / 16, PG = 4 / G, TH = 4 * PG, TW = 16, C4 = CIN / 4;
+    static_assert(COUT % 16 == 0 && (G == 1 || G == 2 || G == 4) && CIN % 4 == 0, "channel config");
+    __shared__ __attribute__((aligned(16))) float tile[(TH + 2) * (TW + 2) * CIN];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int cg = wv % G, pg = wv / G;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const int Hi = a.H * POOL, Wi = a.W * POOL;
+    const float* in = a.in + (size_t)b * Hi * Wi * CIN;
+
+    for (int i = tid; i < (TH + 2) * (TW + 2) * C4; i += 256) {
+        const int pos = i / C4, c4 = i - pos * C4;
+        const int y = pos / (TW + 2), x = pos - y * (TW + 2);
+        const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+            const float* p = in + ((size_t)(gy * POOL) * Wi + (size_t)gx * POOL) * CIN + c4 * 4;
+            v = *reinterpret_cast<const float4*>(p);
+#pragma unroll
+            for (int dy = 0; dy < POOL; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < POOL; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const float4 q = *reinterpret_cast<const float4*>(p + ((size_t)dy * Wi + dx) * CIN);
+                    v.x = fmaxf(v.x, q.x); v.y = fmaxf(v.y, q.y); v.z = fmaxf(v.z, q.z); v.w = fmaxf(v.w, q.w);
+                }
+        }
+        *reinterpret_cast<float4*>(&tile[pos * CIN + c4 * 4]) = v;
+    }
+    __syncthreads();
+
+    const int row = pg * 4 + (lane >> 4), col = lane & 15;
+    const int gy = ty0 + row, gx = tx0 + col;
+    float acc[16];
+    const float* bias = a.bias + cg * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* t = &tile[((row + ky) * (TW + 2) + col + kx) * CIN];
+            const float* w = a.w + (size_t)((ky * 3 + kx) * CIN) * COUT + cg * 16;
+#pragma unroll 2
+            for (int c4 = 0; c4 < C4; ++c4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(t + c4 * 4);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[c], w[(c4 * 4 + c) * COUT + j], acc[j]);
+            }
+        }
+    if (gy >= a.H || gx >= a.W) return;
+    if (RES) {   // identity = downsample(x): 1x1 conv (with bias) on the block input (ALike.py:76-77)
+        constexpr int D4 = CDS / 4;
+        const int Hr = a.H * RPOOL, Wr = a.W * RPOOL;
+        const float* p = a.res_in + ((size_t)b * Hr * Wr + (size_t)(gy * RPOOL) * Wr + (size_t)gx * RPOOL) * CDS;
+        const float* dw = a.ds_w + cg * 16;
+        const float* db = a.ds_b + cg * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] += db[j];
+        for (int c4 = 0; c4 < D4; ++c4) {
+            float4 v4 = *reinterpret_cast<const float4*>(p + c4 * 4);
+#pragma unroll
+            for (int dy = 0; dy < RPOOL; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < RPOOL; ++dx) {
+                    if (dy == 0 && dx == 0) continue;
+                    const float4 q = *reinterpret_cast<const float4*>(p + ((size_t)dy * Wr + dx) * CDS + c4 * 4);
+                    v4.x = fmaxf(v4.x, q.x); v4.y = fmaxf(v4.y, q.y); v4.z = fmaxf(v4.z, q.z); v4.w = fmaxf(v4.w, q.w);
+                }
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[c], dw[(c4 * 4 + c) * COUT + j], acc[j]);
+        }
+    }
+    float* o = a.out + ((size_t)b * a.H * a.W + (size_t)gy * a.W + gx) * COUT + cg * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 v = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        if (RELU) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
+        *reinterpret_cast<float4*>(o + 4 * q) = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 1x1 + ReLU
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out, const float* w /*[CIN][16]*/, size_t npix)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    const float* x = in + p * CIN;
+#pragma unroll 2
+    for (int c4 = 0; c4 < CIN / 4; ++c4) {
+        const float4 v4 = *reinterpret_cast<const float4*>(x + c4 * 4);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[c], w[(c4 * 4 + c) * 16 + j], acc[j]);
+    }
+    float* o = out + p * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(o + 4 * q) = make_float4(relu(acc[4 * q]), relu(acc[4 * q + 1]), relu(acc[4 * q + 2]), relu(acc[4 * q + 3]));
+}
+
+// ------------------------------------------------------------------------------------------------ head
+struct HeadArgs {
+    const float* x1;   // [B][H][W][8]
+    const float* a2;   // [B][H/2][W/2][16]
+    const float* a3;   // [B][H/8][W/8][16]
+    const float* a4;   // [B][H/32][W/32][16]
+    const float* agg1; // [8][16]
+    const float* whT;  // [64][64]  whT[c][o] = head.w[o][c], o < 64
+    const float* wsc;  // [64]      head.w[64][c]
+    float* score;      // [B][H][W]
+    float* desc;       // [B][H][W][64] or null
+    int H, W;
+};
+
+// 16 channels of an align_corners=True bilinear upsample (nn.Upsample, ALike.py:126-129) at (y, x)
+__device__ __forceinline__ void up16(const float* m, int Hs, int Ws, float sy, float sx, int y, int x, float* f)
+{
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float* p00 = m + ((size_t)y0 * Ws + x0) * 16;
+    const float* p01 = m + ((size_t)y0 * Ws + x1) * 16;
+    const float* p10 = m + ((size_t)y1 * Ws + x0) * 16;
+    const float* p11 = m + ((size_t)y1 * Ws + x1) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(p00 + 4 * q), b = *reinterpret_cast<const float4*>(p01 + 4 * q);
+        const float4 c = *reinterpret_cast<const float4*>(p10 + 4 * q), d = *reinterpret_cast<const float4*>(p11 + 4 * q);
+        f[4 * q + 0] = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+        f[4 * q + 1] = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+        f[4 * q + 2] = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+        f[4 * q + 3] = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+    }
+}
+
+// channels [32h, 32h+32) of the concatenated feature x1234 (ALike.py:147-154) at pixel (y, x)
+__device__ __forceinline__ void features32(const HeadArgs& a, int b, int y, int x, int h, float* f)
+{
+    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
+    if (h == 0) {
+        const float* px = a.x1 + ((size_t)b * a.H * a.W + (size_t)y * a.W + x) * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(px), hi = *reinterpret_cast<const float4*>(px + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) f[j] = fmaf(v[c], a.agg1[c * 16 + j], f[j]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = relu(f[j]);
+        up16(a.a2 + (size_t)b * H2 * W2 * 16, H2, W2, (float)(H2 - 1) / (float)(a.H - 1), (float)(W2 - 1) / (float)(a.W - 1), y, x, f + 16);
+    } else {
+        up16(a.a3 + (size_t)b * H8 * W8 * 16, H8, W8, (float)(H8 - 1) / (float)(a.H - 1), (float)(W8 - 1) / (float)(a.W - 1), y, x, f);
+        up16(a.a4 + (size_t)b * H32 * W32 * 16, H32, W32, (float)(H32 - 1) / (float)(a.H - 1), (float)(W32 - 1) / (float)(a.W - 1), y, x, f + 16);
+    }
+}
+
+constexpr int HEAD_TILES = 4;   // 32-pixel tiles per wave (amortises the B-fragment load)
+
+template <bool DENSE>
+__global__ __launch_bounds__(256) void alike_head(HeadArgs a)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int xbase = (blockIdx.x * 4 + wv) * 32 * HEAD_TILES;
+    if (xbase >= a.W) return;
+
+    float bw0[32], bw1[32], ws[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+        ws[s] = a.wsc[32 * h + s];
+        if (DENSE) {   // B[k = h][j = p] of step s: head weight of output p (+32) for input channel 32h+s
+            bw0[s] = a.whT[(32 * h + s) * 64 + p];
+            bw1[s] = a.whT[(32 * h + s) * 64 + 32 + p];
+        }
+    }
+    for (int t = 0; t < HEAD_TILES; ++t) {
+        const int x0 = xbase + 32 * t;
+        if (x0 >= a.W) break;
+        const int x = x0 + p;   // W is a multiple of 32: the tile is whole
+        float f[32];
+        features32(a, b, y, x, h, f);
+        float sc = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) sc = fmaf(f[s], ws[s], sc);
+        sc += __shfl_xor(sc, 32, 64);
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+        if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
+        if (DENSE) {
+            f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+            for (int s = 0; s < 32; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], bw0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], bw1[s], acc1, 0, 0, 0);
+            }
+            // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
+            float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
+                d[(size_t)rowp * 64 + p] = acc0[r];
+                d[(size_t)rowp * 64 + 32 + p] = acc1[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ desc_at
+struct DescAtArgs {
+    HeadArgs h;
+    const float* pts; const int* n; float* out;
+    int pts_cols, max_n;
+};
+
+// one wave per keypoint; lane = feature channel while sampling, = output channel for the mat-vec.
+// Equals kpb_sample() on the dense map because the 1x1 head and the bilinear taps are both linear.
+__global__ __launch_bounds__(256) void alike_desc_at(DescAtArgs a)
+{
+    __shared__ float fs[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wv;
+    const int n = a.n ? min(a.n[b], a.max_n) : a.max_n;
+    if (i >= n) return;
+    const float* pt = a.pts + ((size_t)b * a.max_n + i) * a.pts_cols;
+    const int H = a.h.H, W = a.h.W;
+    const float gx = (pt[0] - 0.5f) * 2.0f, gy = (pt[1] - 0.5f) * 2.0f;   // matcher.py:221-222
+    const float x = (gx + 1.0f) * ((float)(W - 1) / 2.0f), y = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, nn = y - yn, s = 1.0f - nn;
+    const float cw[4] = {s * e, s * w, nn * e, nn * w};
+    const int x0 = (int)xw, y0 = (int)yn;
+    // this lane's feature channel c = lane: group g = c / 16 decides the formula
+    const int g = lane >> 4, j = lane & 15;
+    float acc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tx = x0 + (t & 1), ty = y0 + (t >> 1);
+        if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;   // grid_sample zero padding
+        float v;
+        if (g == 0) {
+            const float* px = a.h.x1 + ((size_t)b * H * W + (size_t)ty * W + tx) * 8;
+            v = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v = fmaf(px[c], a.h.agg1[c * 16 + j], v);
+            v = relu(v);
+        } else {
+            const int sh = g == 1 ? 2 : (g == 2 ? 8 : 32);
+            const int Hs = H / sh, Ws = W / sh;
+            const float* m = (g == 1 ? a.h.a2 : (g == 2 ? a.h.a3 : a.h.a4)) + (size_t)b * Hs * Ws * 16;
+            const float fy = ((float)(Hs - 1) / (float)(H - 1)) * (float)ty, fx = ((float)(Ws - 1) / (float)(W - 1)) * (float)tx;
+            const int sy0 = (int)fy, sx0 = (int)fx;
+            const int sy1 = sy0 + (sy0 < Hs - 1 ? 1 : 0), sx1 = sx0 + (sx0 < Ws - 1 ? 1 : 0);
+            const float ly = fy - (float)sy0, lx = fx - (float)sx0, hy = 1.0f - ly, hx = 1.0f - lx;
+            v = hy * (hx * m[((size_t)sy0 * Ws + sx0) * 16 + j] + lx * m[((size_t)sy0 * Ws + sx1) * 16 + j]) +
+                ly * (hx * m[((size_t)sy1 * Ws + sx0) * 16 + j] + lx * m[((size_t)sy1 * Ws + sx1) * 16 + j]);
+        }
+        acc = fmaf(cw[t], v, acc);
+    }
+    fs[wv][lane] = acc;
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < 64; ++c) o = fmaf(fs[wv][c], a.h.whT[c * 64 + lane], o);
+    a.out[((size_t)b * a.max_n + i) * 64 + lane] = o;
+}
+
+}  // namespace
+
+// ================================================================================================ host side
+struct kpb_net {
+    kpb_ctx* ctx = nullptr;
+    int arch = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, dim = 0;
+    float* wdev = nullptr;                 // all repacked weights
+    std::map<std::string, size_t> off;     // name -> float offset in wdev
+    kpb_buf act;                           // activations of the last forward
+    int B = 0, H = 0, W = 0;
+    float *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
+          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr;
+};
+
+namespace {
+
+struct Rec { char name[40]; uint32_t ndim; uint32_t dims[4]; uint32_t off; };
+
+struct Blob {
+    std::map<std::string, std::pair<const float*, std::vector<uint32_t>>> t;
+    uint32_t arch = 0;
+    bool parse(const void* blob, size_t len)
+    {
+        const unsigned char* p = static_cast<const unsigned char*>(blob);
+        if (len < 16 || memcmp(p, "KPBWGT1\0", 8) != 0) return false;
+        uint32_t n;
+        memcpy(&arch, p + 8, 4);
+        memcpy(&n, p + 12, 4);
+        const size_t base = 16 + (size_t)n * sizeof(Rec);
+        if (base > len) return false;
+        for (uint32_t i = 0; i < n; ++i) {
+            Rec r;
+            memcpy(&r, p + 16 + (size_t)i * sizeof(Rec), sizeof(Rec));
+            if (r.ndim > 4) return false;
+            size_t cnt = 1;
+            std::vector<uint32_t> d(r.dims, r.dims + r.ndim);
+            for (uint32_t v : d) cnt *= v;
+            if (base + 4 * ((size_t)r.off + cnt) > len) return false;
+            r.name[39] = 0;
+            t[r.name] = {reinterpret_cast<const float*>(p + base + 4 * (size_t)r.off), d};
+        }
+        return true;
+    }
+    const float* get(const char* name, std::vector<uint32_t> dims) const
+    {
+        auto it = t.find(name);
+        if (it == t.end() || it->second.second != dims) return nullptr;
+        return it->second.first;
+    }
+};
+
+// OIHW [co][ci][3][3] -> [tap][ci][co]
+void repack3x3(const float* w, int co, int ci, std::vector<float>& out)
+{
+    out.resize((size_t)9 * ci * co);
+    for (int o = 0; o < co; ++o)
+        for (int c = 0; c < ci; ++c)
+            for (int k = 0; k < 9; ++k) out[((size_t)k * ci + c) * co + o] = w[((size_t)o * ci + c) * 9 + k];
+}
+// [co][ci] -> [ci][co]
+void transpose(const float* w, int co, int ci, std::vector<float>& out)
+{
+    out.resize((size_t)ci * co);
+    for (int o = 0; o < co; ++o)
+        for (int c = 0; c < ci; ++c) out[(size_t)c * co + o] = w[(size_t)o * ci + c];
+}
+
+template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL>
+void launch_conv(hipStream_t st, const ConvArgs& a, int B)
+{
+    constexpr int G = COUT / 16, TH = 4 * (4 / G), TW = 16;
+    hipLaunchKernelGGL((conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
+}
+
+}  // namespace
+
+#define KPB_API extern "C" __attribute__((visibility("default")))
+
+KPB_API int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len, kpb_net** out)
+{
+    if (!ctx || !out || !blob) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: null argument");
+    *out = nullptr;
+    if (arch != KPB_ARCH_ALIKE) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: unknown arch %d", arch);
+    Blob bl;
+    if (!bl.parse(blob, len) || (int)bl.arch != arch) return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: malformed .kpbw blob");
+    // this build carries the ALIKE-t channel plan (c1..c4 = 8,16,32,64, dim 64: config/config_MHA.yaml Alike_params)
+    const uint32_t c1 = 8, c2 = 16, c3 = 32, c4 = 64, dim = 64;
+    struct { const char* n; std::vector<uint32_t> d; } need[] = {
+        {"b1c1.w", {c1, 3, 3, 3}}, {"b1c1.b", {c1}}, {"b1c2.w", {c1, c1, 3, 3}}, {"b1c2.b", {c1}},
+        {"b2c1.w", {c2, c1, 3, 3}}, {"b2c1.b", {c2}}, {"b2c2.w", {c2, c2, 3, 3}}, {"b2c2.b", {c2}}, {"b2ds.w", {c2, c1}}, {"b2ds.b", {c2}},
+        {"b3c1.w", {c3, c2, 3, 3}}, {"b3c1.b", {c3}}, {"b3c2.w", {c3, c3, 3, 3}}, {"b3c2.b", {c3}}, {"b3ds.w", {c3, c2}}, {"b3ds.b", {c3}},
+        {"b4c1.w", {c4, c3, 3, 3}}, {"b4c1.b", {c4}}, {"b4c2.w", {c4, c4, 3, 3}}, {"b4c2.b", {c4}}, {"b4ds.w", {c4, c3}}, {"b4ds.b", {c4}},
+        {"agg1.w", {dim / 4, c1}}, {"agg2.w", {dim / 4, c2}}, {"agg3.w", {dim / 4, c3}}, {"agg4.w", {dim / 4, c4}},
+        {"head.w", {dim + 1, dim}}};
+    for (auto& nd : need)
+        if (!bl.get(nd.n, nd.d))
+            return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: tensor %s missing or not ALIKE-t shaped "
+                            "(this build supports c1..c4 = 8,16,32,64, dim = 64)", nd.n);
+    kpb_net* net = new kpb_net();
+    net->ctx = ctx; net->arch = arch;
+    net->c1 = c1; net->c2 = c2; net->c3 = c3; net->c4 = c4; net->dim = dim;
+    std::vector<float> host, tmp;
+    auto put = [&](const char* name, const std::vector<float>& v) {
+        while (host.size() % 64) host.push_back(0.0f);   // 256-byte alignment for scalar/vector loads
+        net->off[name] = host.size();
+        host.insert(host.end(), v.begin(), v.end());
+    };
+    auto put_raw = [&](const char* name, const float* p, size_t n) { put(name, std::vector<float>(p, p + n)); };
+    {   // block1 conv1: [co][ci][ky][kx] -> [(ci,ky,kx)][co]
+        const float* w = bl.get("b1c1.w", {c1, 3, 3, 3});
+        tmp.assign(27 * 8, 0.f);
+        for (int o = 0; o < 8; ++o) for (int k = 0; k < 27; ++k) tmp[k * 8 + o] = w[o * 27 + k];
+        put("b1c1.w", tmp);
+        put_raw("b1c1.b", bl.get("b1c1.b", {c1}), 8);
+        repack3x3(bl.get("b1c2.w", {c1, c1, 3, 3}), 8, 8, tmp); put("b1c2.w", tmp);
+        put_raw("b1c2.b", bl.get("b1c2.b", {c1}), 8);
+    }
+    const uint32_t ch[5] = {0, c1, c2, c3, c4};
+    for (int i = 2; i <= 4; ++i) {
+        char nm[16];
+        const uint32_t ci = ch[i - 1], co = ch[i];
+        snprintf(nm, 16, "b%dc1.w", i); repack3x3(bl.get(nm, {co, ci, 3, 3}), co, ci, tmp); put(nm, tmp);
+        snprintf(nm, 16, "b%dc1.b", i); put_raw(nm, bl.get(nm, {co}), co);
+        snprintf(nm, 16, "b%dc2.w", i); repack3x3(bl.get(nm, {co, co, 3, 3}), co, co, tmp); put(nm, tmp);
+        snprintf(nm, 16, "b%dc2.b", i); put_raw(nm, bl.get(nm, {co}), co);
+        snprintf(nm, 16, "b%dds.w", i); transpose(bl.get(nm, {co, ci}), co, ci, tmp); put(nm, tmp);
+        snprintf(nm, 16, "b%dds.b", i); put_raw(nm, bl.get(nm, {co}), co);
+    }
+    for (int i = 1; i <= 4; ++i) {
+        char nm[16];
+        snprintf(nm, 16, "agg%d.w", i);
+        transpose(bl.get(nm, {dim / 4, ch[i]}), dim / 4, ch[i], tmp); put(nm, tmp);
+    }
+    {
+        const float* hw = bl.get("head.w", {dim + 1, dim});
+        transpose(hw, 64, 64, tmp); put("head.wT", tmp);
+        put_raw("head.ws", hw + 64 * 64, 64);
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&net->wdev, host.size() * sizeof(float)) != hipSuccess) {
+        delete net;
+        return kpb_fail(ctx, KPB_E_NOMEM, "kpb_net_create: weight allocation failed");
+    }
+    if (hipMemcpy(net->wdev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(net->wdev);
+        delete net;
+        return kpb_fail(ctx, KPB_E_HIP, "kpb_net_create: weight upload failed");
+    }
+    *out = net;
+    return KPB_OK;
+}
+
+KPB_API void kpb_net_destroy(kpb_net* net)
+{
+    if (!net) return;
+    (void)hipSetDevice(net->ctx->device);
+    (void)hipStreamSynchronize(net->ctx->stream);
+    if (net->wdev) (void)hipFree(net->wdev);
+    if (net->act.p) (void)hipFree(net->act.p);
+    delete net;
+}
+
+KPB_API int kpb_net_desc_dim(const kpb_net* net) { return net ? net->dim : 0; }
+
+static HeadArgs head_args(kpb_net* net, float* score, float* desc)
+{
+    HeadArgs h;
+    h.x1 = net->x1; h.a2 = net->a2; h.a3 = net->a3; h.a4 = net->a4;
+    h.agg1 = net->wdev + net->off["agg1.w"];
+    h.whT = net->wdev + net->off["head.wT"];
+    h.wsc = net->wdev + net->off["head.ws"];
+    h.score = score; h.desc = desc; h.H = net->H; h.W = net->W;
+    return h;
+}
+
+KPB_API int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H, int W, float* score_out_dev,
+                            float* desc_out_dev)
+{
+    if (!net) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_net_forward: null net");
+    kpb_ctx* ctx = net->ctx;
+    if (!img_dev || !score_out_dev || batch <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32))
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: H and W must be positive multiples of 32 (got %dx%d)", H, W);
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t P = (size_t)H * W, B = batch;
+    const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
+                 n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
+    const size_t total = n_x1 + 3 * n_2 + 2 * n_3 + n_a3 + 2 * n_4 + n_a4;
+    if (int rc = kpb_reserve(ctx, net->act, total * sizeof(float))) return rc;
+    float* p = static_cast<float*>(net->act.p);
+    net->x1 = p; p += n_x1;
+    net->t2 = p; p += n_2; net->x2 = p; p += n_2; net->a2 = p; p += n_2;
+    net->t3 = p; p += n_3; net->x3 = p; p += n_3; net->a3 = p; p += n_a3;
+    net->t4 = p; p += n_4; net->x4 = p; p += n_4; net->a4 = p; p += n_a4;
+    net->B = batch; net->H = H; net->W = W;
+    hipStream_t st = ctx->stream;
+    auto wp = [&](const char* n) { return net->wdev + net->off[n]; };
+
+    Block1Args b1{img_dev, net->x1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
+    hipLaunchKernelGGL(alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
+
+    ConvArgs c;
+    // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
+    c = ConvArgs{net->x1, net->t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, H / 2, W / 2};
+    launch_conv<8, 16, 2, false, 4, 1>(st, c, batch);
+    c = ConvArgs{net->t2, net->x2, wp("b2c2.w"), wp("b2c2.b"), net->x1, wp("b2ds.w"), wp("b2ds.b"), H / 2, W / 2};
+    launch_conv<16, 16, 1, true, 8, 2>(st, c, batch);
+    // block3 @ H/8 (141-142): pool4
+    c = ConvArgs{net->x2, net->t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, nullptr, nullptr, H / 8, W / 8};
+    launch_conv<16, 32, 4, false, 4, 1>(st, c, batch);
+    c = ConvArgs{net->t3, net->x3, wp("b3c2.w"), wp("b3c2.b"), net->x2, wp("b3ds.w"), wp("b3ds.b"), H / 8, W / 8};
+    launch_conv<32, 32, 1, true, 16, 4>(st, c, batch);
+    // block4 @ H/32 (143-144): pool4
+    c = ConvArgs{net->x3, net->t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, nullptr, nullptr, H / 32, W / 32};
+    launch_conv<32, 64, 4, false, 4, 1>(st, c, batch);
+    c = ConvArgs{net->t4, net->x4, wp("b4c2.w"), wp("b4c2.b"), net->x3, wp("b4ds.w"), wp("b4ds.b"), H / 32, W / 32};
+    launch_conv<64, 64, 1, true, 32, 4>(st, c, batch);
+    // aggregation 1x1 + ReLU (147-150); agg1 is fused into the head
+    hipLaunchKernelGGL(conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, net->x2, net->a2, wp("agg2.w"), B * P / 4);
+    hipLaunchKernelGGL(conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, net->x3, net->a3, wp("agg3.w"), B * P / 64);
+    hipLaunchKernelGGL(conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, net->x4, net->a4, wp("agg4.w"), B * P / 1024);
+    // upsample + concat + head (151-162)
+    HeadArgs h = head_args(net, score_out_dev, desc_out_dev);
+    const dim3 hg(cdiv(W, 4 * 32 * HEAD_TILES), H, batch);
+    if (desc_out_dev) hipLaunchKernelGGL(alike_head<true>, hg, dim3(256), 0, st, h);
+    else hipLaunchKernelGGL(alike_head<false>, hg, dim3(256), 0, st, h);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+KPB_API int kpb_net_desc_at(kpb_net* net, const float* pts_dev, int pts_cols, int max_n, const int32_t* n_dev,
+                            float* out_dev)
+{
+    if (!net) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_net_desc_at: null net");
+    kpb_ctx* ctx = net->ctx;
+    if (net->B == 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_desc_at: no forward has run");
+    if (max_n == 0) return KPB_OK;
+    if (!pts_dev || !out_dev || pts_cols < 2 || max_n < 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_desc_at: bad argument");
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    DescAtArgs a{head_args(net, nullptr, nullptr), pts_dev, n_dev, out_dev, pts_cols, max_n};
+    hipLaunchKernelGGL(alike_desc_at, dim3(cdiv(max_n, 4), net->B), dim3(256), 0, ctx->stream, a);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
