@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- image-pairs/sec of the extract + NMS + brute-force-match hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs-per-step B] [--sparse]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): ALIKE-t extract + NMS(nms_dist 6, border 8, top_k 1000) + brute-force
+mutual match (euclidean, max_distance 5, cross_check) on synthetic 640x480 pairs,
+inputs resident in HBM before the timed region.  One step = one pass of the whole path over one batch of
+B pairs per GPU; pairs shard across ranks with no data-path collective (weak scaling); the only exchange
+is the end-of-run RCCL all-gather of per-pair metric rows, outside the timed region.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline     -- the kernel that takes the most time in the step, timed live with HIP events on the
+                  launch stream (kpb_prof_*), against its algorithmic FLOPs/bytes
+  cpu_baseline -- the CPU oracle (oracle/, a port of the reference algorithm) on a bounded sample of the
+                  same pairs, one single-threaded worker per host core, rank 0 at N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 480, 640
+EXTRACTOR = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)   # config/config_MHA.yaml:68-73
+BRUTE_FORCE = dict(metric="euclidean", max_distance=5, cross_check=True)                  # config/config_MHA.yaml:82-85
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 matrix (= vector) peak; the path computes in fp32
+PEAK_F64_TFLOPS = 78.6
+
+
+# ---------------------------------------------------------------------------------------- CPU baseline
+def _cpu_worker(i):
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    import oracle
+    from oracle import alike_ref
+    from keypoint_bench_amd import synthetic, weights
+    t = {k: torch.from_numpy(v) for k, v in weights.load_alike_t().items()}
+    v0, v1 = synthetic.image_pair(i, H, W)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        s0, d0 = alike_ref.alnet_forward(torch.from_numpy(v0)[None], t)
+        s1, d1 = alike_ref.alnet_forward(torch.from_numpy(v1)[None], t)
+    k0, _ = oracle.detection(s0[0, 0].numpy(), EXTRACTOR)
+    k1, _ = oracle.detection(s1[0, 0].numpy(), EXTRACTOR)
+    f0 = oracle.sample(d0[0].numpy(), k0)
+    f1 = oracle.sample(d1[0].numpy(), k1)
+    pairs, _ = oracle.match(f0, f1, BRUTE_FORCE["max_distance"], BRUTE_FORCE["cross_check"])
+    return time.perf_counter() - t0, len(pairs)
+
+
+def cpu_baseline(pairs_per_worker=2):
+    """Oracle pipeline on host cores: one single-threaded worker per core, each doing whole pairs."""
+    import multiprocessing as mp
+    import oracle
+    oracle.build()
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))   # the 1-GPU box's CPU share
+    n = cores * pairs_per_worker
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, range(n), chunksize=pairs_per_worker)
+    wall = time.perf_counter() - t0
+    busy = sum(r[0] for r in res)
+    # throughput from the workers' own timers (excludes interpreter start-up and input synthesis)
+    value = n / (busy / cores)
+    return dict(value=round(value, 4), unit="pairs/s", cores=cores, kind="port",
+                sample="%d synthetic 640x480 pairs, oracle/ (torch-fp32 ALIKE-t restatement + C NMS/top-k/match), "
+                       "%d single-thread workers, %.1f s wall, %.2f s/pair/core" % (n, cores, wall, busy / n))
+
+
+# ---------------------------------------------------------------------------------------- roofline table
+def kernel_costs(B2, B, K, C, dense, sweeps):
+    """Algorithmic (compulsory) FLOPs and HBM bytes PER LAUNCH of each kernel."""
+    P = H * W
+    c = {}
+    c["alike_block1"] = (2 * P * (27 * 8 + 72 * 8) * B2, P * (12 + 32) * B2)
+    c["conv3x3_b2c1"] = (2 * (P // 4) * 9 * 8 * 16 * B2, (P * 32 + (P // 4) * 64) * B2)
+    c["conv3x3_b2c2"] = (2 * (P // 4) * (9 * 16 * 16 + 8 * 16) * B2, ((P // 4) * 64 + P * 32 + (P // 4) * 64) * B2)
+    c["conv3x3_b3c1"] = (2 * (P // 64) * 9 * 16 * 32 * B2, ((P // 4) * 64 + (P // 64) * 128) * B2)
+    c["conv3x3_b3c2"] = (2 * (P // 64) * (9 * 32 * 32 + 16 * 32) * B2, ((P // 64) * 128 * 2 + (P // 4) * 64) * B2)
+    c["conv3x3_b4c1"] = (2 * (P // 1024) * 9 * 32 * 64 * B2, ((P // 64) * 128 + (P // 1024) * 256) * B2)
+    c["conv3x3_b4c2"] = (2 * (P // 1024) * (9 * 64 * 64 + 32 * 64) * B2, ((P // 1024) * 256 * 2 + (P // 64) * 128) * B2)
+    c["conv1x1_agg2"] = (2 * (P // 4) * 16 * 16 * B2, (P // 4) * 128 * B2)
+    c["conv1x1_agg3"] = (2 * (P // 64) * 32 * 16 * B2, (P // 64) * 192 * B2)
+    c["conv1x1_agg4"] = (2 * (P // 1024) * 64 * 16 * B2, (P // 1024) * 320 * B2)
+    feat = 2 * 8 * 16 + 3 * 16 * 8 + 2 * 64            # agg1 + three 4-tap lerps + score dot
+    c["alike_head_dense"] = ((feat + 2 * 64 * 64) * P * B2, P * (32 + 4 + 256) * B2 + (P // 4 + P // 64 + P // 1024) * 64 * B2)
+    c["alike_head_score"] = (feat * P * B2, P * (32 + 4) * B2 + (P // 4 + P // 64 + P // 1024) * 64 * B2)
+    c["nms_sweep"] = (0, 2 * P * 4 * B2 / max(sweeps, 1))       # map read once + written once, spread over the sweeps
+    c["select_topk"] = (0, (P * 4 + K * 16) * B2)
+    c["sample_bilinear"] = (7 * K * C * B2, (4 * K * C * 4 + K * C * 4) * B2)
+    c["alike_desc_at"] = ((2 * 64 * 64 + 4 * 64 * 8) * K * B2, (4 * 4 * 64 * 4 + K * 0 + 256) * K * B2)
+    c["match_tile"] = (3 * K * K * C * B, 2 * K * C * 4 * B)     # float64 sub/mul/add per element
+    c["match_finalize"] = (0, (2 * K * 16 * 12 + K * 20) * B)
+    c["gather_rows"] = (0, K * 32 * B)
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-step", type=int, default=64, help="pairs per GPU per step")
+    ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        print("warning: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus), file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()          # before anything touches the GPU (spawned workers, CPU only)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from keypoint_bench_amd import synthetic
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.pipeline import PairPipeline
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU; keypoint_bench_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.pairs_per_step
+    net = alike_t(dense_descriptors=not args.sparse).eval()
+    pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
+    # synthetic pairs, different per rank, resident in HBM
+    nd = min(args.distinct, B)
+    v0s, v1s = zip(*[synthetic.image_pair(rank * 1000 + i, H, W) for i in range(nd)])
+    sel = [i % nd for i in range(B)]
+    images = torch.from_numpy(np.stack([v0s[i] for i in sel] + [v1s[i] for i in sel])).to(dev).contiguous()
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        pipe.run(images)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run(images)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * B * args.steps / elapsed
+
+    # end-of-run exchange: fixed-width per-pair rows [n0, n1, matches], one RCCL all-gather
+    rows = torch.stack([pipe.n[:B].float(), pipe.n[B:].float(), pipe.k.float()], dim=1).contiguous()
+    if world > 1:
+        allrows = torch.empty((world * B, 3), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allrows, rows)
+    else:
+        allrows = rows
+    allrows = allrows.cpu().numpy()
+
+    # roofline leg: per-kernel durations from HIP events on the launch stream, same workload
+    roof = None
+    ctx = pipe.ctx
+    ctx.prof_enable(True)
+    prof_steps = 3
+    for _ in range(prof_steps):
+        pipe.run(images)
+    prof = ctx.prof_report()
+    ctx.prof_enable(False)
+    if rank == 0 and prof:
+        sweeps = prof.get("nms_sweep", (1, 0))[0] / prof_steps
+        costs = kernel_costs(2 * B, B, EXTRACTOR["top_k"], net.param["dim"], not args.sparse, sweeps)
+        name = max(prof, key=lambda k: prof[k][1])
+        calls, total_ms = prof[name]
+        avg_ms = total_ms / calls
+        flops, nbytes = costs.get(name, (0, 0))
+        tf, gbs = flops / avg_ms / 1e9, nbytes / avg_ms / 1e6
+        if name == "match_tile":
+            bound, achieved, peak, unit = "mfma", tf, PEAK_F64_TFLOPS, "TFLOP/s"     # fp64 vector peak (no MFMA used)
+        elif flops and (flops / max(nbytes, 1)) > (PEAK_F32_TFLOPS * 1e3 / PEAK_HBM_GBS):
+            bound, achieved, peak, unit = "mfma", tf, PEAK_F32_TFLOPS, "TFLOP/s"
+        else:
+            bound, achieved, peak, unit = "hbm", gbs, PEAK_HBM_GBS, "GB/s"
+        tot = sum(v[1] for v in prof.values())
+        roof = dict(bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit, frac=round(achieved / peak, 4),
+                    traffic=None, kernel=name, avg_ms=round(avg_ms, 4), launches_per_step=calls / prof_steps,
+                    share_of_step=round(total_ms / tot, 3),
+                    kernels_ms_per_step={k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
+
+    if rank == 0:
+        out = {
+            "metric": "image-pairs/sec (extract+NMS+BF-match, 640x480, top_k=1000)",
+            "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ALIKE-t extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
+                                   "(euclidean fp64, max_distance=5, cross_check), 640x480 pairs [BASELINE configs[1]]",
+                       "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
+                       "weights": "alike-t (reference checkpoint, BN folded)", "parallelism": "pairs sharded, dp%d" % world,
+                       "nms_reruns": pipe.reruns},
+            "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
+                        "pairs_gathered": int(allrows.shape[0])},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

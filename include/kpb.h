@@ -67,6 +67,12 @@ int kpb_ctx_create(int device, void* stream, kpb_ctx** out);
 void kpb_ctx_destroy(kpb_ctx* ctx);
 int kpb_sync(kpb_ctx* ctx);
 
+/* Per-kernel timing for bench.py's roofline leg: when enabled every kernel launch is bracketed by two
+ * HIP events on the context's stream.  kpb_prof_report synchronises, writes one text line per kernel
+ * ("<name> <launches> <total_ms>\n") into buf and clears the records. */
+int kpb_prof_enable(kpb_ctx* ctx, int on);
+int kpb_prof_report(kpb_ctx* ctx, char* buf, size_t cap);
+
 /* ---- A1: utils/extracter.py:6-100 fast_nms --------------------------------------------------
  * score_dev [batch][H][W] fp32, non-negative; out_map_dev same shape (may not alias score_dev).
  * Synchronous: iterates sweeps until every image reached the fixed point. */
@@ -86,7 +92,9 @@ int kpb_fast_nms(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W, 
 int kpb_detect(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W,
                const kpb_detect_params* params, float* out_kps_dev, int32_t* out_idx_dev,
                int32_t* out_n_dev, int sync);
-/* After kpb_sync(): status of the last kpb_detect(sync=0): KPB_OK, KPB_E_NOT_CONVERGED or KPB_E_NEGATIVE. */
+/* Completes the last kpb_detect(sync=0): synchronises and, if some image had not reached the NMS fixed
+ * point within the enqueued sweeps, runs more sweeps and rewrites the outputs.  Returns 0 (outputs were
+ * final), 1 (outputs were rewritten: redo whatever consumed them), or KPB_E_NEGATIVE. */
 int kpb_detect_check(kpb_ctx* ctx);
 
 /* ---- M1: utils/matcher.py:221-226 descriptor sampling (grid_sample, align_corners=True) -----

@@ -26,6 +26,8 @@ SIGNATURES = {
     "kpb_ctx_create": (c_int, [c_int, c_void_p, ctypes.POINTER(c_void_p)]),
     "kpb_ctx_destroy": (None, [c_void_p]),
     "kpb_sync": (c_int, [c_void_p]),
+    "kpb_prof_enable": (c_int, [c_void_p, c_int]),
+    "kpb_prof_report": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
     "kpb_fast_nms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "kpb_detect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(DetectParams), c_void_p, c_void_p,
                            c_void_p, c_int]),
@@ -56,6 +58,9 @@ def load():
     """Load libkpb.so and declare every prototype.  Raises if the library was not built."""
     global _lib
     if _lib is None:
+        # torch first: libkpb.so must bind to the HIP runtime torch already loaded (tensors are the
+        # containers for every device buffer); a second runtime loaded ahead of torch's sees no device.
+        import torch  # noqa: F401
         if not os.path.exists(SO_PATH):
             raise RuntimeError("%s is missing: run `python -m keypoint_bench_amd.build` (hipcc, gfx950). "
                                "keypoint_bench_amd has no CPU fallback." % SO_PATH)
@@ -102,6 +107,19 @@ class Context:
 
     def sync(self):
         self.check(self.lib.kpb_sync(self.handle))
+
+    def prof_enable(self, on: bool):
+        self.check(self.lib.kpb_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_report(self):
+        """{kernel name: (launches, total_ms)} since the last report (HIP events on the launch stream)."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        self.check(self.lib.kpb_prof_report(self.handle, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.split()
+            out[name] = (int(calls), float(ms))
+        return out
 
 
 def ptr(t):

@@ -476,10 +476,10 @@ void transpose(const float* w, int co, int ci, std::vector<float>& out)
 }
 
 template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL>
-void launch_conv(hipStream_t st, const ConvArgs& a, int B)
+void launch_conv(kpb_ctx* ctx, const char* name, hipStream_t st, const ConvArgs& a, int B)
 {
     constexpr int G = COUT / 16, TH = 4 * (4 / G), TW = 16;
-    hipLaunchKernelGGL((conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
+    KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
 }
 
 }  // namespace
@@ -605,33 +605,33 @@ KPB_API int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H
     auto wp = [&](const char* n) { return net->wdev + net->off[n]; };
 
     Block1Args b1{img_dev, net->x1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
-    hipLaunchKernelGGL(alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
+    KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
 
     ConvArgs c;
     // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
     c = ConvArgs{net->x1, net->t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, H / 2, W / 2};
-    launch_conv<8, 16, 2, false, 4, 1>(st, c, batch);
+    launch_conv<8, 16, 2, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
     c = ConvArgs{net->t2, net->x2, wp("b2c2.w"), wp("b2c2.b"), net->x1, wp("b2ds.w"), wp("b2ds.b"), H / 2, W / 2};
-    launch_conv<16, 16, 1, true, 8, 2>(st, c, batch);
+    launch_conv<16, 16, 1, true, 8, 2>(ctx, "conv3x3_b2c2", st, c, batch);
     // block3 @ H/8 (141-142): pool4
     c = ConvArgs{net->x2, net->t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, nullptr, nullptr, H / 8, W / 8};
-    launch_conv<16, 32, 4, false, 4, 1>(st, c, batch);
+    launch_conv<16, 32, 4, false, 4, 1>(ctx, "conv3x3_b3c1", st, c, batch);
     c = ConvArgs{net->t3, net->x3, wp("b3c2.w"), wp("b3c2.b"), net->x2, wp("b3ds.w"), wp("b3ds.b"), H / 8, W / 8};
-    launch_conv<32, 32, 1, true, 16, 4>(st, c, batch);
+    launch_conv<32, 32, 1, true, 16, 4>(ctx, "conv3x3_b3c2", st, c, batch);
     // block4 @ H/32 (143-144): pool4
     c = ConvArgs{net->x3, net->t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, nullptr, nullptr, H / 32, W / 32};
-    launch_conv<32, 64, 4, false, 4, 1>(st, c, batch);
+    launch_conv<32, 64, 4, false, 4, 1>(ctx, "conv3x3_b4c1", st, c, batch);
     c = ConvArgs{net->t4, net->x4, wp("b4c2.w"), wp("b4c2.b"), net->x3, wp("b4ds.w"), wp("b4ds.b"), H / 32, W / 32};
-    launch_conv<64, 64, 1, true, 32, 4>(st, c, batch);
+    launch_conv<64, 64, 1, true, 32, 4>(ctx, "conv3x3_b4c2", st, c, batch);
     // aggregation 1x1 + ReLU (147-150); agg1 is fused into the head
-    hipLaunchKernelGGL(conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, net->x2, net->a2, wp("agg2.w"), B * P / 4);
-    hipLaunchKernelGGL(conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, net->x3, net->a3, wp("agg3.w"), B * P / 64);
-    hipLaunchKernelGGL(conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, net->x4, net->a4, wp("agg4.w"), B * P / 1024);
+    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, net->x2, net->a2, wp("agg2.w"), B * P / 4);
+    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, net->x3, net->a3, wp("agg3.w"), B * P / 64);
+    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, net->x4, net->a4, wp("agg4.w"), B * P / 1024);
     // upsample + concat + head (151-162)
     HeadArgs h = head_args(net, score_out_dev, desc_out_dev);
     const dim3 hg(cdiv(W, 4 * 32 * HEAD_TILES), H, batch);
-    if (desc_out_dev) hipLaunchKernelGGL(alike_head<true>, hg, dim3(256), 0, st, h);
-    else hipLaunchKernelGGL(alike_head<false>, hg, dim3(256), 0, st, h);
+    if (desc_out_dev) KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, hg, dim3(256), 0, st, h);
+    else KPB_LAUNCH(ctx, "alike_head_score", alike_head<false>, hg, dim3(256), 0, st, h);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
@@ -646,7 +646,7 @@ KPB_API int kpb_net_desc_at(kpb_net* net, const float* pts_dev, int pts_cols, in
     if (!pts_dev || !out_dev || pts_cols < 2 || max_n < 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_desc_at: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     DescAtArgs a{head_args(net, nullptr, nullptr), pts_dev, n_dev, out_dev, pts_cols, max_n};
-    hipLaunchKernelGGL(alike_desc_at, dim3(cdiv(max_n, 4), net->B), dim3(256), 0, ctx->stream, a);
+    KPB_LAUNCH(ctx, "alike_desc_at", alike_desc_at, dim3(cdiv(max_n, 4), net->B), dim3(256), 0, ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }

@@ -46,3 +46,39 @@ extern "C" __attribute__((visibility("default"))) int kpb_sync(kpb_ctx* ctx)
     KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return KPB_OK;
 }
+
+extern "C" __attribute__((visibility("default"))) int kpb_prof_enable(kpb_ctx* ctx, int on)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_prof_enable: null context");
+    ctx->prof = on != 0;
+    return KPB_OK;
+}
+
+// Writes one line per kernel: "<name> <calls> <total_ms>\n"; clears the records.  Synchronises the stream.
+extern "C" __attribute__((visibility("default"))) int kpb_prof_report(kpb_ctx* ctx, char* buf, size_t cap)
+{
+    if (!ctx || !buf || cap == 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_prof_report: bad argument");
+    KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::string> names;
+    std::vector<double> ms;
+    std::vector<long> calls;
+    for (auto& r : ctx->prof_recs) {
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.e0, r.e1);
+        size_t i = 0;
+        for (; i < names.size(); ++i) if (names[i] == r.name) break;
+        if (i == names.size()) { names.push_back(r.name); ms.push_back(0.0); calls.push_back(0); }
+        ms[i] += t; calls[i] += 1;
+        ctx->prof_pool.push_back(r.e0);
+        ctx->prof_pool.push_back(r.e1);
+    }
+    ctx->prof_recs.clear();
+    size_t off = 0;
+    buf[0] = 0;
+    for (size_t i = 0; i < names.size(); ++i) {
+        int n = snprintf(buf + off, cap - off, "%s %ld %.6f\n", names[i].c_str(), calls[i], ms[i]);
+        if (n < 0 || (size_t)n >= cap - off) break;
+        off += (size_t)n;
+    }
+    return KPB_OK;
+}

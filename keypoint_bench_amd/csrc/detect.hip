@@ -405,7 +405,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.lastchg = p.lastchg; a.negflag = p.negflag;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s; a.max_local = 64;
-        hipLaunchKernelGGL(nms_sweep, dim3(p.ntiles, batch), dim3(NMS_THREADS), p.lds, ctx->stream, a);
+        KPB_LAUNCH(ctx, "nms_sweep", nms_sweep, dim3(p.ntiles, batch), dim3(NMS_THREADS), p.lds, ctx->stream, a);
     }
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
@@ -473,7 +473,7 @@ int det_select(kpb_ctx* ctx, const DetState& d)
     s.H = d.H; s.W = d.W; s.border = d.prm.border_dist; s.top_k = d.prm.top_k;
     s.kpad = d.prm.top_k >= d.H * d.W ? 0 : next_pow2(d.prm.top_k);
     s.threshold = d.prm.threshold; s.min_score = d.prm.min_score;
-    hipLaunchKernelGGL(select_topk, dim3(d.batch), dim3(SEL_THREADS), (size_t)s.kpad * sizeof(unsigned long long),
+    KPB_LAUNCH(ctx, "select_topk", select_topk, dim3(d.batch), dim3(SEL_THREADS), (size_t)s.kpad * sizeof(unsigned long long),
                        ctx->stream, s);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
@@ -514,7 +514,8 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     if (int rc = det_select(ctx, d)) return rc;
     ctx->det_pending = 1;
     if (!sync) return KPB_OK;
-    return kpb_detect_check(ctx);
+    const int rc = kpb_detect_check(ctx);
+    return rc > 0 ? KPB_OK : rc;
 }
 
 extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* ctx)
@@ -529,6 +530,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
         return KPB_OK;
     }
     const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+    int rerun = 0;
     for (;;) {
         int pending = 0, neg = 0;
         if (int rc = nms_status(ctx, d.plan, d.batch, d.sweeps_run, pending, neg)) return rc;
@@ -538,11 +540,13 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
                                                  "(the reference's zero padding makes them data dependent)");
         }
         if (!pending) break;
+        rerun = 1;
         if (d.sweeps_run > 100000) return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_detect: NMS did not converge");
         if (int rc = nms_launch(ctx, d.plan, d.score, d.cur, d.batch, d.H, d.W, d.prm.nms_dist, d.sweeps_run, chunk)) return rc;
         d.sweeps_run += chunk;
         if (int rc = det_select(ctx, d)) return rc;
     }
     ctx->det_pending = 0;
-    return KPB_OK;
+    if (rerun) KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rerun;   // 1: the outputs were rewritten after extra sweeps
 }

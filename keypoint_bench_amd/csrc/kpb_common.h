@@ -16,8 +16,17 @@ struct kpb_buf {
     size_t cap = 0;
 };
 
+struct kpb_prof_rec {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+
 struct kpb_ctx {
     int device = 0;
+    // per-kernel timing with HIP events on the launch stream (bench.py's roofline leg); off by default
+    bool prof = false;
+    std::vector<kpb_prof_rec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char err[512] = {0};
@@ -72,3 +81,28 @@ inline int kpb_reserve(kpb_ctx* ctx, kpb_buf& b, size_t bytes)
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Brackets one kernel launch with two events on the context's stream when profiling is enabled.
+struct ProfScope {
+    kpb_ctx* ctx;
+    hipEvent_t e1 = nullptr;
+    ProfScope(kpb_ctx* c, const char* name) : ctx(c)
+    {
+        if (!c->prof) return;
+        hipEvent_t ev[2];
+        for (int i = 0; i < 2; ++i) {
+            if (!c->prof_pool.empty()) { ev[i] = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else if (hipEventCreate(&ev[i]) != hipSuccess) return;
+        }
+        c->prof_recs.push_back({name, ev[0], ev[1]});
+        e1 = ev[1];
+        (void)hipEventRecord(ev[0], c->stream);
+    }
+    ~ProfScope() { if (e1) (void)hipEventRecord(e1, ctx->stream); }
+};
+
+#define KPB_LAUNCH(ctx_, name_, ...)            \
+    do {                                        \
+        ProfScope ps_(ctx_, name_);             \
+        hipLaunchKernelGGL(__VA_ARGS__);        \
+    } while (0)

@@ -254,7 +254,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_sample(kpb_ctx* ctx, c
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_sample: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     SampleArgs a{desc_dev, pts_dev, n_dev, out_dev, C, Hd, Wd, pts_cols, max_n, sb, sc, sh, sw};
-    hipLaunchKernelGGL(sample_bilinear, dim3(cdiv(max_n, 4), batch), dim3(256), 0, ctx->stream, a);
+    KPB_LAUNCH(ctx, "sample_bilinear", sample_bilinear, dim3(cdiv(max_n, 4), batch), dim3(256), 0, ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
@@ -282,10 +282,10 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
     int* rj = reinterpret_cast<int*>(cs + nc);
     int* ci = rj + nr;
     MatchArgs a{d0_dev, d1_dev, n_dev, m_dev, rs, rj, cs, ci, C, max_n, max_m, tiles_i, tiles_j};
-    hipLaunchKernelGGL(match_tile, dim3(tiles_j, tiles_i, batch), dim3(MATCH_THREADS), 0, ctx->stream, a);
+    KPB_LAUNCH(ctx, "match_tile", match_tile, dim3(tiles_j, tiles_i, batch), dim3(MATCH_THREADS), 0, ctx->stream, a);
     FinArgs f{rs, rj, cs, ci, n_dev, m_dev, out_pairs_dev, out_dist_dev, out_k_dev,
               max_n, max_m, tiles_i, tiles_j, prm->cross_check, prm->max_distance};
-    hipLaunchKernelGGL(match_finalize, dim3(batch), dim3(FIN_THREADS), (size_t)max_m * sizeof(int), ctx->stream, f);
+    KPB_LAUNCH(ctx, "match_finalize", match_finalize, dim3(batch), dim3(FIN_THREADS), (size_t)max_m * sizeof(int), ctx->stream, f);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
@@ -299,7 +299,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_gather_rows(kpb_ctx* c
     if (!src_dev || !idx_dev || !out_dev || batch <= 0 || cols <= 0 || idx_rows < 0 || idx_stride <= 0)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_gather_rows: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(gather_rows, dim3(cdiv(idx_rows * cols, 256), batch), dim3(256), 0, ctx->stream, src_dev,
+    KPB_LAUNCH(ctx, "gather_rows", gather_rows, dim3(cdiv(idx_rows * cols, 256), batch), dim3(256), 0, ctx->stream, src_dev,
                        src_rows, cols, idx_dev, idx_rows, idx_stride, idx_col, k_dev, out_dev);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;

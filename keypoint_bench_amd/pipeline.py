@@ -1,0 +1,93 @@
+"""Batched pair pipeline: the per-pair body of MInterface.test_step (models/model_interface.py:205-212
+-> tasks/*: detection x2, brute_force_matcher) for B independent pairs per launch wave.
+
+One call enqueues, with no host synchronisation in between,
+    net forward on 2B images -> detection on 2B score maps -> descriptors at the keypoints ->
+    brute-force mutual match of B pairs -> gather of the matched keypoint rows,
+then a single sync + NMS convergence check.  Every stage is the same C-ABI entry point the
+single-pair drop-ins use; counts stay on the device between stages.
+"""
+import ctypes
+
+import torch
+
+from ._lib import Context, DetectParams, MatchParams, ptr
+
+
+class PairPipeline:
+    def __init__(self, net, extractor_params, brute_force_params, batch, H, W, device="cuda:0"):
+        self.net, self.B, self.H, self.W = net, int(batch), int(H), int(W)
+        self.device = torch.device(device)
+        self.ctx = Context.get(self.device)
+        ep, bf = extractor_params, brute_force_params
+        if bf.get("metric", "euclidean") != "euclidean":
+            raise NotImplementedError("only metric='euclidean'")
+        self.top_k = min(int(ep["top_k"]), H * W)
+        self.dprm = DetectParams(int(ep["nms_dist"]), float(ep["threshold"]), int(ep["border_dist"]), self.top_k,
+                                 float(ep["min_score"]))
+        self.mprm = MatchParams(float(bf["max_distance"]), 1 if bf["cross_check"] else 0)
+        B2, K, C = 2 * self.B, self.top_k, net.param["dim"]
+        dev = self.device
+        f32, i32 = torch.float32, torch.int32
+        self.score = torch.empty((B2, 1, H, W), dtype=f32, device=dev)
+        self.desc = torch.empty((B2, H, W, C), dtype=f32, device=dev) if net.dense_descriptors else None
+        self.kps = torch.empty((B2, K, 3), dtype=f32, device=dev)
+        self.idx = torch.empty((B2, K), dtype=i32, device=dev)
+        self.n = torch.empty((B2,), dtype=i32, device=dev)
+        self.sdesc = torch.empty((B2, K, C), dtype=f32, device=dev)
+        self.pairs = torch.empty((self.B, K, 2), dtype=i32, device=dev)
+        self.dist = torch.empty((self.B, K), dtype=torch.float64, device=dev)
+        self.k = torch.empty((self.B,), dtype=i32, device=dev)
+        self.m0 = torch.empty((self.B, K, 3), dtype=f32, device=dev)
+        self.m1 = torch.empty((self.B, K, 3), dtype=f32, device=dev)
+        self.C = C
+        self.reruns = 0
+        net._ensure(self.device)
+
+    def enqueue(self, images):
+        """images [2B, 3, H, W]: rows 0..B-1 are image0 of each pair, rows B..2B-1 image1."""
+        ctx, L, net = self.ctx, self.ctx.lib, self.net
+        B, B2, K, C, H, W = self.B, 2 * self.B, self.top_k, self.C, self.H, self.W
+        assert images.shape == (B2, 3, H, W) and images.is_contiguous() and images.dtype == torch.float32
+        ctx.check(L.kpb_net_forward(net._handle, ptr(images), B2, H, W, ptr(self.score), ptr(self.desc)))
+        net._forward_count += 1
+        ctx.check(L.kpb_detect(ctx.handle, ptr(self.score), B2, H, W, ctypes.byref(self.dprm), ptr(self.kps),
+                               ptr(self.idx), ptr(self.n), 0))
+        self._enqueue_match()
+
+    def _enqueue_match(self):
+        ctx, L, net = self.ctx, self.ctx.lib, self.net
+        B, B2, K, C, H, W = self.B, 2 * self.B, self.top_k, self.C, self.H, self.W
+        if self.desc is not None:   # utils/matcher.py:221-226 on the dense map (channels-last strides)
+            ctx.check(L.kpb_sample(ctx.handle, ptr(self.desc), B2, C, H, W, H * W * C, 1, W * C, C, ptr(self.kps), 3, K,
+                                   ptr(self.n), ptr(self.sdesc)))
+        else:
+            ctx.check(L.kpb_net_desc_at(net._handle, ptr(self.kps), 3, K, ptr(self.n), ptr(self.sdesc)))
+        n0, n1 = self.n[:B], self.n[B:]
+        ctx.check(L.kpb_match(ctx.handle, ptr(self.sdesc[:B]), ptr(self.sdesc[B:]), B, C, K, K, ptr(n0), ptr(n1),
+                              ctypes.byref(self.mprm), ptr(self.pairs), ptr(self.dist), ptr(self.k)))
+        ctx.check(L.kpb_gather_rows(ctx.handle, ptr(self.kps[:B]), B, K, 3, ptr(self.pairs), K, 2, 0, ptr(self.k), ptr(self.m0)))
+        ctx.check(L.kpb_gather_rows(ctx.handle, ptr(self.kps[B:]), B, K, 3, ptr(self.pairs), K, 2, 1, ptr(self.k), ptr(self.m1)))
+
+    def finish(self):
+        """Sync; re-runs NMS sweeps + everything downstream for the (rare) batch that had not converged."""
+        ctx = self.ctx
+        rc = ctx.lib.kpb_detect_check(ctx.handle)
+        if rc == 1:     # keypoints were rewritten after extra sweeps: redo the stages that consumed them
+            self.reruns += 1
+            self._enqueue_match()
+            ctx.sync()
+        elif rc != 0:
+            ctx.check(rc)
+
+    def run(self, images):
+        self.enqueue(images)
+        self.finish()
+        return self
+
+    def pair(self, b):
+        """Host-side view of pair b's results (numpy): kps0, kps1, matched rows."""
+        n0, n1, k = int(self.n[b]), int(self.n[self.B + b]), int(self.k[b])
+        return dict(kps0=self.kps[b, :n0].cpu().numpy(), kps1=self.kps[self.B + b, :n1].cpu().numpy(),
+                    pairs=self.pairs[b, :k].cpu().numpy(), dist=self.dist[b, :k].cpu().numpy(),
+                    m0=self.m0[b, :k].cpu().numpy(), m1=self.m1[b, :k].cpu().numpy())
