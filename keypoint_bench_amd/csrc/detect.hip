@@ -151,6 +151,177 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep(NmsArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Specialised sweep for nms_dist 1..8 (compile-time radius): same rules as nms_sweep, with the two
+// window passes done on 8-pixel register strips -- a horizontal strip is five ds_read_b128 for
+// r = 6 instead of 104 ds_read_b32, the running maxima are built by doubling (width 2, 4, 8, 16) --
+// so one local round costs ~4 LDS accesses and ~15 VALU ops per pixel.
+template <int WIN, int NOUT, int NIN>
+__device__ __forceinline__ void window_max(const float (&a)[NIN], float (&o)[NOUT])
+{
+    // o[i] = max(a[i .. i+WIN-1]); NIN >= NOUT + WIN - 1
+    static_assert(NIN >= NOUT + WIN - 1, "window_max input too short");
+    if constexpr (WIN == 1) {
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) o[i] = a[i];
+    } else {
+        constexpr int P = WIN >= 16 ? 16 : (WIN >= 8 ? 8 : (WIN >= 4 ? 4 : 2));   // largest power of two <= WIN
+        float m[NIN];
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) m[i] = a[i];
+#pragma unroll
+        for (int w = 1; w < P; w <<= 1) {
+#pragma unroll
+            for (int i = 0; i + w < NIN; ++i) m[i] = fmaxf(m[i], m[i + w]);   // m[i] = max a[i .. i+2w-1] (in place, ascending i)
+        }
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) o[i] = fmaxf(m[i], m[i + WIN - P]);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
+{
+    constexpr int LH = TH + 4 * R, LW = TW + 4 * R;
+    constexpr int IW = LW - 2 * R, IH = LH - 2 * R;            // inset region: whole window inside the tile
+    constexpr int NHS = (IW + 7) / 8, NVS = (IH + 7) / 8;       // strips per row / per column
+    constexpr int PITCH = ((8 * NHS + 2 * R) + 3) / 4 * 4;      // floats per LDS row (16-byte aligned rows)
+    constexpr int ROWS = 8 * NVS + 2 * R;                       // rows incl. zero padding read by the last strip
+    constexpr int HIN = 8 + 2 * R, HQ = (HIN + 3) / 4;          // floats / float4s one horizontal strip reads
+    constexpr int KS = 2 * R + 1, KS2 = KS * KS;
+    __shared__ __attribute__((aligned(16))) float t[ROWS * PITCH];   // >0 alive, 0 dead, <0 confirmed maximum
+    __shared__ __attribute__((aligned(16))) float e[ROWS * PITCH];   // row maxima over [x-R, x+R]
+    __shared__ int maxlist[MAXLIST];
+    __shared__ int s_n[2], s_kill[2], s_owned, s_over;
+
+    const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int ntiles = a.tiles_x * a.tiles_y;
+    int* tcur = a.tchg_cur + (size_t)img * ntiles;
+    if (a.sweep > 0) {
+        const int* tprev = a.tchg_prev + (size_t)img * ntiles;
+        int need = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = ty + dy, xx = tx + dx;
+                if (yy >= 0 && yy < a.tiles_y && xx >= 0 && xx < a.tiles_x) need |= tprev[yy * a.tiles_x + xx];
+            }
+        if (!need) {
+            if (tid == 0) tcur[tile] = 0;
+            return;
+        }
+    }
+    const size_t P = (size_t)a.H * a.W;
+    const float* in = (a.sweep == 0 ? a.src : a.cur) + (size_t)img * P;
+    float* out = a.cur + (size_t)img * P;
+    const int gy0 = ty * TH - 2 * R, gx0 = tx * TW - 2 * R;
+
+    int neg = 0;
+    for (int i = tid; i < ROWS * PITCH; i += NMS_THREADS) {
+        const int ly = i / PITCH, lx = i - ly * PITCH;
+        const int gy = gy0 + ly, gx = gx0 + lx;
+        float v = 0.0f;   // zero padding outside the image (extracter.py:54-60) and in the pad rows/columns
+        if (ly < LH && lx < LW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)gy * a.W + gx];
+        neg |= (v < 0.0f);
+        t[i] = v;
+        e[i] = 0.0f;
+    }
+    if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_kill[0] = 0; s_kill[1] = 0; s_owned = 0; s_over = 0; }
+    __syncthreads();
+    if (neg) a.negflag[img] = 1;
+
+    float orig[TH * TW / NMS_THREADS];
+#pragma unroll
+    for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
+        const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
+        orig[k] = t[(oy + 2 * R) * PITCH + ox + 2 * R];
+    }
+
+    int unconverged = 1;
+    for (int iter = 0; iter < a.max_local; ++iter) {
+        const int par = iter & 1;
+        // horizontal pass: e[y][x] = max t[y][x-R .. x+R] for x in [R, R + 8*NHS)
+        for (int i = tid; i < LH * NHS; i += NMS_THREADS) {
+            const int y = i / NHS, s8 = i - y * NHS;
+            const float* row = t + y * PITCH + 8 * s8;
+            float v[HQ * 4];
+#pragma unroll
+            for (int q = 0; q < HQ; ++q) {
+                const float4 f = *reinterpret_cast<const float4*>(row + 4 * q);
+                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+            }
+            float o[8];
+            window_max<KS, 8, HQ * 4>(v, o);
+            float* er = e + y * PITCH + R + 8 * s8;   // (R + 8*s8) is not 16-byte aligned for odd R: scalar stores
+#pragma unroll
+            for (int k = 0; k < 8; ++k) er[k] = o[k];
+        }
+        __syncthreads();
+        // vertical pass on 8-row strips: a pixel is a maximum iff it is alive, equals its row maximum,
+        // is > every row maximum above and >= every one below (argmax = first index, extracter.py:69-70),
+        // and is > the R cells to its left.
+        for (int i = tid; i < NVS * IW; i += NMS_THREADS) {
+            const int s8 = i / IW, x = i - s8 * IW + R;
+            const int y0 = R + 8 * s8;
+            float col[8 + 2 * R];
+#pragma unroll
+            for (int k = 0; k < 8 + 2 * R; ++k) col[k] = e[(y0 - R + k) * PITCH + x];
+            float wr[8 + R + 1];
+            window_max<R, 8 + R + 1, 8 + 2 * R>(col, wr);    // wr[j] = max col[j .. j+R-1]
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int y = y0 + k;
+                const float v = t[y * PITCH + x];
+                if (y < LH - R && v > 0.0f && v == col[k + R] && v > wr[k] && v >= wr[k + R + 1]) {
+                    bool ok = true;
+#pragma unroll
+                    for (int d = 1; d <= R; ++d) ok = ok && (v > t[y * PITCH + x - d]);
+                    if (ok) {
+                        const int slot = atomicAdd(&s_n[par], 1);
+                        if (slot < MAXLIST) maxlist[slot] = y * PITCH + x;
+                        else s_over = 1;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int nmax = min(s_n[par], MAXLIST);
+        if (tid == 0) { s_n[par ^ 1] = 0; s_kill[par ^ 1] = 0; }
+        for (int i = tid; i < nmax * KS2; i += NMS_THREADS) {
+            const int m = i / KS2, c = i - m * KS2;
+            const int dy = c / KS - R, dx = c - (dy + R) * KS - R;
+            const int pos = maxlist[m] + dy * PITCH + dx;
+            if (dy == 0 && dx == 0) {
+                t[pos] = -t[pos];
+            } else if (t[pos] != 0.0f) {
+                t[pos] = 0.0f;
+                s_kill[par] = 1;
+                const int py = pos / PITCH - 2 * R, px = pos - (py + 2 * R) * PITCH - 2 * R;
+                if (py >= 0 && py < TH && px >= 0 && px < TW) s_owned = 1;
+            }
+        }
+        __syncthreads();
+        if (!s_kill[par] && !s_over) { unconverged = 0; break; }
+        if (s_over && tid == 0) s_over = 0;   // next round re-finds what did not fit
+    }
+
+    const int by = ty * TH, bx = tx * TW;
+#pragma unroll
+    for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
+        const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
+        const int gy = by + oy, gx = bx + ox;
+        if (gy < a.H && gx < a.W) {
+            const float v = fabsf(t[(oy + 2 * R) * PITCH + ox + 2 * R]);
+            if (a.sweep == 0 || v != orig[k]) out[(size_t)gy * a.W + gx] = v;
+        }
+    }
+    if (tid == 0) {
+        const int flag = (s_owned || unconverged) ? 1 : 0;
+        tcur[tile] = flag;
+        if (flag) atomicMax(&a.lastchg[img], a.sweep + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A2 + A3 + A4: one 1024-thread workgroup per image.
 __device__ __forceinline__ unsigned f2key(float v)
 {
@@ -405,7 +576,18 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.lastchg = p.lastchg; a.negflag = p.negflag;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s; a.max_local = 64;
-        KPB_LAUNCH(ctx, "nms_sweep", nms_sweep, dim3(p.ntiles, batch), dim3(NMS_THREADS), p.lds, ctx->stream, a);
+        const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
+        switch (r) {
+        case 1: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<1>, grid, block, 0, ctx->stream, a); break;
+        case 2: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<2>, grid, block, 0, ctx->stream, a); break;
+        case 3: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<3>, grid, block, 0, ctx->stream, a); break;
+        case 4: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<4>, grid, block, 0, ctx->stream, a); break;
+        case 5: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<5>, grid, block, 0, ctx->stream, a); break;
+        case 6: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<6>, grid, block, 0, ctx->stream, a); break;
+        case 7: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<7>, grid, block, 0, ctx->stream, a); break;
+        case 8: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<8>, grid, block, 0, ctx->stream, a); break;
+        default: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep, grid, block, p.lds, ctx->stream, a); break;
+        }
     }
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
