@@ -253,19 +253,21 @@ struct HeadArgs {
     int H, W;
 };
 
-// 16 channels of an align_corners=True bilinear upsample (nn.Upsample, ALike.py:126-129) at (y, x)
-__device__ __forceinline__ void up16(const float* m, int Hs, int Ws, float sy, float sx, int y, int x, float* f)
+constexpr int HEAD_TILES = 4;   // 32-pixel tiles per wave
+
+// 8 channels [c0, c0+8) of an align_corners=True bilinear upsample (nn.Upsample, ALike.py:126-129) at (y, x)
+__device__ __forceinline__ void up8ch(const float* m, int Hs, int Ws, float sy, float sx, int y, int x, int c0, float* f)
 {
     const float fy = sy * (float)y, fx = sx * (float)x;
     const int y0 = (int)fy, x0 = (int)fx;
     const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
-    const float* p00 = m + ((size_t)y0 * Ws + x0) * 16;
-    const float* p01 = m + ((size_t)y0 * Ws + x1) * 16;
-    const float* p10 = m + ((size_t)y1 * Ws + x0) * 16;
-    const float* p11 = m + ((size_t)y1 * Ws + x1) * 16;
+    const float* p00 = m + ((size_t)y0 * Ws + x0) * 16 + c0;
+    const float* p01 = m + ((size_t)y0 * Ws + x1) * 16 + c0;
+    const float* p10 = m + ((size_t)y1 * Ws + x0) * 16 + c0;
+    const float* p11 = m + ((size_t)y1 * Ws + x1) * 16 + c0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 2; ++q) {
         const float4 a = *reinterpret_cast<const float4*>(p00 + 4 * q), b = *reinterpret_cast<const float4*>(p01 + 4 * q);
         const float4 c = *reinterpret_cast<const float4*>(p10 + 4 * q), d = *reinterpret_cast<const float4*>(p11 + 4 * q);
         f[4 * q + 0] = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
@@ -275,67 +277,76 @@ __device__ __forceinline__ void up16(const float* m, int Hs, int Ws, float sy, f
     }
 }
 
-// channels [32h, 32h+32) of the concatenated feature x1234 (ALike.py:147-154) at pixel (y, x)
-__device__ __forceinline__ void features32(const HeadArgs& a, int b, int y, int x, int h, float* f)
-{
-    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
-    if (h == 0) {
-        const float* px = a.x1 + ((size_t)b * a.H * a.W + (size_t)y * a.W + x) * 8;
-        const float4 lo = *reinterpret_cast<const float4*>(px), hi = *reinterpret_cast<const float4*>(px + 4);
-        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-        for (int j = 0; j < 16; ++j) f[j] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) f[j] = fmaf(v[c], a.agg1[c * 16 + j], f[j]);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) f[j] = relu(f[j]);
-        up16(a.a2 + (size_t)b * H2 * W2 * 16, H2, W2, (float)(H2 - 1) / (float)(a.H - 1), (float)(W2 - 1) / (float)(a.W - 1), y, x, f + 16);
-    } else {
-        up16(a.a3 + (size_t)b * H8 * W8 * 16, H8, W8, (float)(H8 - 1) / (float)(a.H - 1), (float)(W8 - 1) / (float)(a.W - 1), y, x, f);
-        up16(a.a4 + (size_t)b * H32 * W32 * 16, H32, W32, (float)(H32 - 1) / (float)(a.H - 1), (float)(W32 - 1) / (float)(a.W - 1), y, x, f + 16);
-    }
-}
-
-constexpr int HEAD_TILES = 4;   // 32-pixel tiles per wave (amortises the B-fragment load)
-
+// Lane (p, h) of a wave owns pixel p of the tile and, of each 16-channel group of x1234, channels
+// 8h..8h+7: every lane runs the same instruction stream (no divergence between the wave halves) and
+// step s of the MFMA K loop consumes channel chan(s, h) = 16*(s/8) + 8h + (s%8) from A and B alike.
 template <bool DENSE>
 __global__ __launch_bounds__(256) void alike_head(HeadArgs a)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) float Bl[32 * 2 * 64];   // [s][h][out]: head weight of chan(s,h)
+    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j
+    __shared__ __attribute__((aligned(16))) float Ws[2 * 32];         // [h][s]:       score weight of chan(s,h)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z, y = blockIdx.y;
-    const int xbase = (blockIdx.x * 4 + wv) * 32 * HEAD_TILES;
-    if (xbase >= a.W) return;
-
-    float bw0[32], bw1[32], ws[32];
-#pragma unroll
-    for (int s = 0; s < 32; ++s) {
-        ws[s] = a.wsc[32 * h + s];
-        if (DENSE) {   // B[k = h][j = p] of step s: head weight of output p (+32) for input channel 32h+s
-            bw0[s] = a.whT[(32 * h + s) * 64 + p];
-            bw1[s] = a.whT[(32 * h + s) * 64 + 32 + p];
+    const int b = blockIdx.y;
+    if (DENSE)
+        for (int i = tid; i < 32 * 2 * 64; i += 256) {
+            const int o = i & 63, hh = (i >> 6) & 1, s = i >> 7;
+            Bl[i] = a.whT[(16 * (s >> 3) + 8 * hh + (s & 7)) * 64 + o];
         }
-    }
+    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j]; }
+    if (tid < 64) { const int s = tid & 31, hh = tid >> 5; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)]; }
+    __syncthreads();
+
+    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
+    const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
+    const float* a3 = a.a3 + (size_t)b * H8 * W8 * 16;
+    const float* a4 = a.a4 + (size_t)b * H32 * W32 * 16;
+    const float sy2 = (float)(H2 - 1) / (float)(a.H - 1), sx2 = (float)(W2 - 1) / (float)(a.W - 1);
+    const float sy8 = (float)(H8 - 1) / (float)(a.H - 1), sx8 = (float)(W8 - 1) / (float)(a.W - 1);
+    const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
+    const int tiles_per_row = a.W / 32, ntiles = a.H * tiles_per_row;
+    const int tile0 = (blockIdx.x * 4 + wv) * HEAD_TILES;
+
     for (int t = 0; t < HEAD_TILES; ++t) {
-        const int x0 = xbase + 32 * t;
-        if (x0 >= a.W) break;
-        const int x = x0 + p;   // W is a multiple of 32: the tile is whole
+        const int tile = tile0 + t;
+        if (tile >= ntiles) break;
+        const int y = tile / tiles_per_row, x0 = (tile - y * tiles_per_row) * 32, x = x0 + p;
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
         float f[32];
-        features32(a, b, y, x, h, f);
+        {   // group 0: relu(agg1 . x1), outputs 8h..8h+7 (ALike.py:147)
+            const float4 lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8), hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 w0 = *reinterpret_cast<const float4*>(&A1[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1[(h * 8 + c) * 8 + 4]);
+                f[0] = fmaf(v[c], w0.x, f[0]); f[1] = fmaf(v[c], w0.y, f[1]); f[2] = fmaf(v[c], w0.z, f[2]); f[3] = fmaf(v[c], w0.w, f[3]);
+                f[4] = fmaf(v[c], w1.x, f[4]); f[5] = fmaf(v[c], w1.y, f[5]); f[6] = fmaf(v[c], w1.z, f[6]); f[7] = fmaf(v[c], w1.w, f[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
+        }
+        up8ch(a2, H2, W2, sy2, sx2, y, x, 8 * h, f + 8);      // ALike.py:151-153
+        up8ch(a3, H8, W8, sy8, sx8, y, x, 8 * h, f + 16);
+        up8ch(a4, H32, W32, sy32, sx32, y, x, 8 * h, f + 24);
+
         float sc = 0.0f;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) sc = fmaf(f[s], ws[s], sc);
+        for (int q = 0; q < 8; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(&Ws[h * 32 + 4 * q]);
+            sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
+        }
         sc += __shfl_xor(sc, 32, 64);
-        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
         if (DENSE) {
             f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
             for (int s = 0; s < 32; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], bw0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], bw1[s], acc1, 0, 0, 0);
+                const float b0 = Bl[(s * 2 + h) * 64 + p], b1 = Bl[(s * 2 + h) * 64 + 32 + p];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b1, acc1, 0, 0, 0);
             }
             // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
             float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
@@ -629,7 +640,7 @@ KPB_API int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H
     KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, net->x4, net->a4, wp("agg4.w"), B * P / 1024);
     // upsample + concat + head (151-162)
     HeadArgs h = head_args(net, score_out_dev, desc_out_dev);
-    const dim3 hg(cdiv(W, 4 * 32 * HEAD_TILES), H, batch);
+    const dim3 hg(cdiv(H * (W / 32), 4 * HEAD_TILES), batch);
     if (desc_out_dev) KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, hg, dim3(256), 0, st, h);
     else KPB_LAUNCH(ctx, "alike_head_score", alike_head<false>, hg, dim3(256), 0, st, h);
     KPB_HIP(ctx, hipGetLastError());
