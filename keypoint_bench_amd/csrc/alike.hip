@@ -27,7 +27,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float relu(float v) { return fmaxf(v, 0.0f); }
 
 // ------------------------------------------------------------------------------------------------ block1
-constexpr int B1_TH = 16, B1_TW = 32;
+constexpr int B1_TH = 32, B1_TW = 32;
 
 struct Block1Args {
     const float* img;   // [B][3][H][W]
@@ -39,73 +39,122 @@ struct Block1Args {
     int H, W;
 };
 
+// 32x32 output tile per workgroup.  conv1 is evaluated on the 34x34 halo'd positions as 1x2 strips,
+// conv2 as 1x4 strips per thread, so every scalar-loaded weight feeds 2 / 4 FMAs and the sliding
+// window re-uses LDS reads across kx.
 __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
 {
-    __shared__ float in[3][B1_TH + 4][B1_TW + 4];
-    __shared__ __attribute__((aligned(16))) float mid[B1_TH + 2][B1_TW + 2][8];
+    constexpr int IH = B1_TH + 4, IW = B1_TW + 4, MH = B1_TH + 2, MW = B1_TW + 2;
+    __shared__ float in[3][IH][IW];
+    __shared__ __attribute__((aligned(16))) float mid[MH][MW][8];
     const int tid = threadIdx.x, b = blockIdx.z;
     const int ty0 = blockIdx.y * B1_TH, tx0 = blockIdx.x * B1_TW;
     const size_t P = (size_t)a.H * a.W;
     const float* img = a.img + (size_t)b * 3 * P;
-    for (int i = tid; i < 3 * (B1_TH + 4) * (B1_TW + 4); i += 256) {
-        const int c = i / ((B1_TH + 4) * (B1_TW + 4)), rem = i - c * (B1_TH + 4) * (B1_TW + 4);
-        const int y = rem / (B1_TW + 4), x = rem - y * (B1_TW + 4);
-        const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
-        float v = 0.0f;
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = img[c * P + (size_t)gy * a.W + gx];
-        in[c][y][x] = v;
+    {   // all of a thread's loads are issued before the first LDS store (one memory latency, not sixteen)
+        constexpr int N = 3 * IH * IW, PER = (N + 255) / 256;
+        float buf[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * 256;
+            const int c = i / (IH * IW), rem = i - c * IH * IW;
+            const int y = rem / IW, x = rem - y * IW;
+            const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
+            buf[k] = 0.0f;
+            if (i < N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) buf[k] = img[c * P + (size_t)gy * a.W + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * 256;
+            if (i < N) (&in[0][0][0])[i] = buf[k];
+        }
     }
     __syncthreads();
-    for (int pos = tid; pos < (B1_TH + 2) * (B1_TW + 2); pos += 256) {
-        const int my = pos / (B1_TW + 2), mx = pos - my * (B1_TW + 2);
-        const int gy = ty0 - 1 + my, gx = tx0 - 1 + mx;
-        float acc[8];
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+    // conv1 + ReLU on MH x MW positions, two per item
+    for (int it = tid; it < MH * (MW / 2); it += 256) {
+        const int my = it / (MW / 2), mx = (it - my * (MW / 2)) * 2;
+        float acc[2][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = a.b1[j];
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int j = 0; j < 8; ++j) acc[q][j] = a.b1[j];
+#pragma unroll 1
+        for (int cky = 0; cky < 9; ++cky) {   // rolled: 24 scalar-loaded weights live per trip, no SGPR spills
+                const int c = cky / 3, ky = cky - 3 * c;
+                float v[4];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int k = 0; k < 4; ++k) v[k] = in[c][my + ky][mx + k];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float v = in[c][my + ky][mx + kx];
+                for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, a.w1[((c * 3 + ky) * 3 + kx) * 8 + j], acc[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = a.w1[((c * 3 + ky) * 3 + kx) * 8 + j];
+                        acc[0][j] = fmaf(v[kx], w, acc[0][j]);
+                        acc[1][j] = fmaf(v[kx + 1], w, acc[1][j]);
                     }
+            }
+        const int gy = ty0 - 1 + my;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = relu(acc[j]);
-        } else {   // conv2 pads its INPUT (the ReLU'd map) with zeros
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int q = 0; q < 2; ++q) {
+            const int gx = tx0 - 1 + mx + q;
+            // conv2 pads its INPUT (the ReLU'd map) with zeros outside the image
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            if (inside) {
+                lo = make_float4(relu(acc[q][0]), relu(acc[q][1]), relu(acc[q][2]), relu(acc[q][3]));
+                hi = make_float4(relu(acc[q][4]), relu(acc[q][5]), relu(acc[q][6]), relu(acc[q][7]));
+            }
+            *reinterpret_cast<float4*>(&mid[my][mx + q][0]) = lo;
+            *reinterpret_cast<float4*>(&mid[my][mx + q][4]) = hi;
         }
-        *reinterpret_cast<float4*>(&mid[my][mx][0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(&mid[my][mx][4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
     }
     __syncthreads();
-    for (int px = tid; px < B1_TH * B1_TW; px += 256) {
-        const int oy = px / B1_TW, ox = px - oy * B1_TW;
-        const int gy = ty0 + oy, gx = tx0 + ox;
-        float acc[8];
+    // conv2 + ReLU: thread = row tid/8, pixels 4*(tid%8) .. +3
+    const int oy = tid >> 3, ox = (tid & 7) * 4;
+    float acc[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = a.b2[j];
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int j = 0; j < 8; ++j) acc[q][j] = a.b2[j];
+#pragma unroll 1
+    for (int ky = 0; ky < 3; ++ky) {
+        float v[6][8];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float4 lo = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx][0]);
-                const float4 hi = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx][4]);
-                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(v[c], a.w2[((ky * 3 + kx) * 8 + c) * 8 + j], acc[j]);
-            }
-        if (gy < a.H && gx < a.W) {
-            float* o = a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8;
-            *reinterpret_cast<float4*>(o) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
-            *reinterpret_cast<float4*>(o + 4) = make_float4(relu(acc[4]), relu(acc[5]), relu(acc[6]), relu(acc[7]));
+        for (int k = 0; k < 6; ++k) {
+            const float4 lo = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + k][0]);
+            const float4 hi = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + k][4]);
+            v[k][0] = lo.x; v[k][1] = lo.y; v[k][2] = lo.z; v[k][3] = lo.w;
+            v[k][4] = hi.x; v[k][5] = hi.y; v[k][6] = hi.z; v[k][7] = hi.w;
         }
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx)   // rolled: 64 scalar-loaded weights live per trip
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float w = a.w2[((ky * 3 + kx) * 8 + c) * 8 + j];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q][j] = fmaf(v[kx + q][c], w, acc[q][j]);
+                }
+    }
+    // stage the 32x32x8 result through LDS (the mid tile is dead now) so that every wave store
+    // instruction writes one whole 1 KiB pixel row segment instead of 64 scattered 16-byte pieces
+    __syncthreads();
+    float* stage = &mid[0][0][0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<float4*>(stage + (oy * B1_TW + ox + q) * 8) = make_float4(relu(acc[q][0]), relu(acc[q][1]), relu(acc[q][2]), relu(acc[q][3]));
+        *reinterpret_cast<float4*>(stage + (oy * B1_TW + ox + q) * 8 + 4) = make_float4(relu(acc[q][4]), relu(acc[q][5]), relu(acc[q][6]), relu(acc[q][7]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < B1_TH * B1_TW * 8 / 4 / 256; ++k) {
+        const int i = tid + k * 256;              // float4 index inside the tile: row = i / 64, 64 float4 per row
+        const int ry = i >> 6, rx4 = i & 63;
+        const int gy = ty0 + ry, gx = tx0 + (rx4 >> 1);
+        if (gy < a.H && gx < a.W)
+            *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + tx0) * 8 + rx4 * 4) =
+                *reinterpret_cast<const float4*>(stage + i * 4);
     }
 }
 

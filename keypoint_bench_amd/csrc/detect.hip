@@ -216,14 +216,40 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     const int gy0 = ty * TH - 2 * R, gx0 = tx * TW - 2 * R;
 
     int neg = 0;
-    for (int i = tid; i < ROWS * PITCH; i += NMS_THREADS) {
-        const int ly = i / PITCH, lx = i - ly * PITCH;
-        const int gy = gy0 + ly, gx = gx0 + lx;
-        float v = 0.0f;   // zero padding outside the image (extracter.py:54-60) and in the pad rows/columns
-        if (ly < LH && lx < LW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)gy * a.W + gx];
-        neg |= (v < 0.0f);
-        t[i] = v;
-        e[i] = 0.0f;
+    // zero padding outside the image (extracter.py:54-60) and in the pad rows/columns
+    if ((R % 2 == 0) && (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0)) {
+        // gx0 is a multiple of 4: whole float4s are inside or outside the image; all loads of a thread in flight
+        constexpr int Q = PITCH / 4, NQ = ROWS * Q, PER = (NQ + NMS_THREADS - 1) / NMS_THREADS;
+        float4 buf[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * NMS_THREADS;
+            const int ly = i / Q, lx = (i - ly * Q) * 4;
+            const int gy = gy0 + ly, gx = gx0 + lx;
+            buf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < NQ && ly < LH && lx < LW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                buf[k] = *reinterpret_cast<const float4*>(in + (size_t)gy * a.W + gx);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * NMS_THREADS;
+            if (i < NQ) {
+                neg |= (buf[k].x < 0.0f) | (buf[k].y < 0.0f) | (buf[k].z < 0.0f) | (buf[k].w < 0.0f);
+                *reinterpret_cast<float4*>(t + 4 * i) = buf[k];
+                *reinterpret_cast<float4*>(e + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    } else {
+#pragma unroll 8
+        for (int i = tid; i < ROWS * PITCH; i += NMS_THREADS) {
+            const int ly = i / PITCH, lx = i - ly * PITCH;
+            const int gy = gy0 + ly, gx = gx0 + lx;
+            float v = 0.0f;
+            if (ly < LH && lx < LW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)gy * a.W + gx];
+            neg |= (v < 0.0f);
+            t[i] = v;
+            e[i] = 0.0f;
+        }
     }
     if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_kill[0] = 0; s_kill[1] = 0; s_owned = 0; s_over = 0; }
     __syncthreads();
