@@ -55,7 +55,7 @@ def _cpu_worker(i):
     return time.perf_counter() - t0, len(pairs)
 
 
-def cpu_baseline(pairs_per_worker=2):
+def cpu_baseline(pairs_per_worker=6):
     """Oracle pipeline on host cores: one single-threaded worker per core, each doing whole pairs."""
     import multiprocessing as mp
     import oracle
