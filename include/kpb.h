@@ -123,14 +123,18 @@ int kpb_gather_rows(kpb_ctx* ctx, const float* src_dev, int batch, int src_rows,
 /* ---- N1..: extractor networks (models/ALike.py:136-164 ALNet.forward, ...) ---------------------
  * arch: KPB_ARCH_*.  blob: a .kpbw container (keypoint_bench_amd/weights.py) holding the folded
  * tensors; copied, the caller may free it. */
-#define KPB_ARCH_ALIKE 1
+#define KPB_ARCH_ALIKE 1        /* models/ALike.py      ALNet (ALIKE-t channel plan), BN folded */
+#define KPB_ARCH_SUPERPOINT 2   /* models/SuperPoint.py SuperPointNet, tensors named as its state_dict */
+#define KPB_ARCH_XFEAT 3        /* models/XFeat.py      XFeatModel, BN folded */
 int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len, kpb_net** out);
 void kpb_net_destroy(kpb_net* net);
-int kpb_net_desc_dim(const kpb_net* net);
+int kpb_net_desc_dim(const kpb_net* net);   /* descriptor channels C */
+int kpb_net_desc_div(const kpb_net* net);   /* descriptor map is (H/div) x (W/div): 1 for ALIKE, 8 for SuperPoint/XFeat */
 /* img_dev [batch][3][H][W] fp32 RGB in [0,1], H and W multiples of 32 (model_interface.py:192-204).
- * score_out_dev [batch][H][W]; desc_out_dev [batch][H][W][C] (channels-last storage of the
- * reference's [B,C,H,W] tensor) or NULL to skip the dense descriptor map (the features needed by
- * kpb_net_desc_at stay resident in the context until the next forward). */
+ * score_out_dev [batch][H][W]; desc_out_dev [batch][H/div][W/div][C] (channels-last storage of the
+ * reference's [B,C,H/div,W/div] tensor).  ALIKE only: NULL skips the dense descriptor map (the features
+ * needed by kpb_net_desc_at stay resident in the net until the next forward).
+ * SuperPoint: H, W multiples of 8; RGB is summed to one channel (SuperPoint.py:42); descriptors L2-normalised. */
 int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H, int W,
                     float* score_out_dev, float* desc_out_dev);
 /* Descriptors of the last forward at keypoints, equal to sampling the dense map with kpb_sample

@@ -41,6 +41,7 @@ SIGNATURES = {
     "kpb_net_create": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "kpb_net_destroy": (None, [c_void_p]),
     "kpb_net_desc_dim": (c_int, [c_void_p]),
+    "kpb_net_desc_div": (c_int, [c_void_p]),
     "kpb_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "kpb_net_desc_at": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
 }

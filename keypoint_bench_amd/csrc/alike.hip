@@ -16,9 +16,7 @@
 //                  v_mfma_f32_32x32x2_f32 with the A operand taken straight from the registers that
 //                  built f (K permuted so lane (p,h) owns channels 32h..32h+31) and B resident in VGPRs
 //   alike_desc_at  descriptors at keypoints only: bilinear taps on f, then one 64x64 mat-vec
-#include "kpb_common.h"
-
-#include <map>
+#include "net.h"
 
 namespace {
 
@@ -471,52 +469,21 @@ __global__ __launch_bounds__(256) void alike_desc_at(DescAtArgs a)
 }  // namespace
 
 // ================================================================================================ host side
-struct kpb_net {
-    kpb_ctx* ctx = nullptr;
-    int arch = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, dim = 0;
-    float* wdev = nullptr;                 // all repacked weights
-    std::map<std::string, size_t> off;     // name -> float offset in wdev
-    kpb_buf act;                           // activations of the last forward
-    int B = 0, H = 0, W = 0;
-    float *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
-          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr;
-};
-
 namespace {
 
-struct Rec { char name[40]; uint32_t ndim; uint32_t dims[4]; uint32_t off; };
-
-struct Blob {
-    std::map<std::string, std::pair<const float*, std::vector<uint32_t>>> t;
-    uint32_t arch = 0;
-    bool parse(const void* blob, size_t len)
+struct AlikeNet : kpb_net {
+    float *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
+          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr;
+    HeadArgs head_args(float* score, float* desc)
     {
-        const unsigned char* p = static_cast<const unsigned char*>(blob);
-        if (len < 16 || memcmp(p, "KPBWGT1\0", 8) != 0) return false;
-        uint32_t n;
-        memcpy(&arch, p + 8, 4);
-        memcpy(&n, p + 12, 4);
-        const size_t base = 16 + (size_t)n * sizeof(Rec);
-        if (base > len) return false;
-        for (uint32_t i = 0; i < n; ++i) {
-            Rec r;
-            memcpy(&r, p + 16 + (size_t)i * sizeof(Rec), sizeof(Rec));
-            if (r.ndim > 4) return false;
-            size_t cnt = 1;
-            std::vector<uint32_t> d(r.dims, r.dims + r.ndim);
-            for (uint32_t v : d) cnt *= v;
-            if (base + 4 * ((size_t)r.off + cnt) > len) return false;
-            r.name[39] = 0;
-            t[r.name] = {reinterpret_cast<const float*>(p + base + 4 * (size_t)r.off), d};
-        }
-        return true;
+        HeadArgs h;
+        h.x1 = x1; h.a2 = a2; h.a3 = a3; h.a4 = a4;
+        h.agg1 = wp("agg1.w"); h.whT = wp("head.wT"); h.wsc = wp("head.ws");
+        h.score = score; h.desc = desc; h.H = H; h.W = W;
+        return h;
     }
-    const float* get(const char* name, std::vector<uint32_t> dims) const
-    {
-        auto it = t.find(name);
-        if (it == t.end() || it->second.second != dims) return nullptr;
-        return it->second.first;
-    }
+    int forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev) override;
+    int desc_at(const float* pts_dev, int pts_cols, int max_n, const int32_t* n_dev, float* out_dev) override;
 };
 
 // OIHW [co][ci][3][3] -> [tap][ci][co]
@@ -542,17 +509,69 @@ void launch_conv(kpb_ctx* ctx, const char* name, hipStream_t st, const ConvArgs&
     KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
 }
 
+int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev)
+{
+    if ((H_ % 32) || (W_ % 32))
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: ALIKE needs H and W multiples of 32 (got %dx%d)", H_, W_);
+    const int H = H_, W = W_;
+    const size_t P = (size_t)H * W, B = batch;
+    const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
+                 n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
+    const size_t total = n_x1 + 3 * n_2 + 2 * n_3 + n_a3 + 2 * n_4 + n_a4;
+    if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
+    float* p = static_cast<float*>(act.p);
+    x1 = p; p += n_x1;
+    t2 = p; p += n_2; x2 = p; p += n_2; a2 = p; p += n_2;
+    t3 = p; p += n_3; x3 = p; p += n_3; a3 = p; p += n_a3;
+    t4 = p; p += n_4; x4 = p; p += n_4; a4 = p; p += n_a4;
+    this->B = batch; this->H = H; this->W = W;
+    hipStream_t st = ctx->stream;
+
+    Block1Args b1{img_dev, x1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
+    KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
+
+    ConvArgs c;
+    // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
+    c = ConvArgs{x1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, H / 2, W / 2};
+    launch_conv<8, 16, 2, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
+    c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), x1, wp("b2ds.w"), wp("b2ds.b"), H / 2, W / 2};
+    launch_conv<16, 16, 1, true, 8, 2>(ctx, "conv3x3_b2c2", st, c, batch);
+    // block3 @ H/8 (141-142): pool4
+    c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, nullptr, nullptr, H / 8, W / 8};
+    launch_conv<16, 32, 4, false, 4, 1>(ctx, "conv3x3_b3c1", st, c, batch);
+    c = ConvArgs{t3, x3, wp("b3c2.w"), wp("b3c2.b"), x2, wp("b3ds.w"), wp("b3ds.b"), H / 8, W / 8};
+    launch_conv<32, 32, 1, true, 16, 4>(ctx, "conv3x3_b3c2", st, c, batch);
+    // block4 @ H/32 (143-144): pool4
+    c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, nullptr, nullptr, H / 32, W / 32};
+    launch_conv<32, 64, 4, false, 4, 1>(ctx, "conv3x3_b4c1", st, c, batch);
+    c = ConvArgs{t4, x4, wp("b4c2.w"), wp("b4c2.b"), x3, wp("b4ds.w"), wp("b4ds.b"), H / 32, W / 32};
+    launch_conv<64, 64, 1, true, 32, 4>(ctx, "conv3x3_b4c2", st, c, batch);
+    // aggregation 1x1 + ReLU (147-150); agg1 is fused into the head
+    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), B * P / 4);
+    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), B * P / 64);
+    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), B * P / 1024);
+    // upsample + concat + head (151-162)
+    HeadArgs h = head_args(score_out_dev, desc_out_dev);
+    const dim3 hg(cdiv(H * (W / 32), 4 * HEAD_TILES), batch);
+    if (desc_out_dev) KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, hg, dim3(256), 0, st, h);
+    else KPB_LAUNCH(ctx, "alike_head_score", alike_head<false>, hg, dim3(256), 0, st, h);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+int AlikeNet::desc_at(const float* pts_dev, int pts_cols, int max_n, const int32_t* n_dev, float* out_dev)
+{
+    if (B == 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_desc_at: no forward has run");
+    DescAtArgs a{head_args(nullptr, nullptr), pts_dev, n_dev, out_dev, pts_cols, max_n};
+    KPB_LAUNCH(ctx, "alike_desc_at", alike_desc_at, dim3(cdiv(max_n, 4), B), dim3(256), 0, ctx->stream, a);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
 }  // namespace
 
-#define KPB_API extern "C" __attribute__((visibility("default")))
-
-KPB_API int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len, kpb_net** out)
+int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
 {
-    if (!ctx || !out || !blob) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: null argument");
-    *out = nullptr;
-    if (arch != KPB_ARCH_ALIKE) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: unknown arch %d", arch);
-    Blob bl;
-    if (!bl.parse(blob, len) || (int)bl.arch != arch) return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: malformed .kpbw blob");
     // this build carries the ALIKE-t channel plan (c1..c4 = 8,16,32,64, dim 64: config/config_MHA.yaml Alike_params)
     const uint32_t c1 = 8, c2 = 16, c3 = 32, c4 = 64, dim = 64;
     struct { const char* n; std::vector<uint32_t> d; } need[] = {
@@ -566,147 +585,41 @@ KPB_API int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len,
         if (!bl.get(nd.n, nd.d))
             return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: tensor %s missing or not ALIKE-t shaped "
                             "(this build supports c1..c4 = 8,16,32,64, dim = 64)", nd.n);
-    kpb_net* net = new kpb_net();
-    net->ctx = ctx; net->arch = arch;
-    net->c1 = c1; net->c2 = c2; net->c3 = c3; net->c4 = c4; net->dim = dim;
-    std::vector<float> host, tmp;
-    auto put = [&](const char* name, const std::vector<float>& v) {
-        while (host.size() % 64) host.push_back(0.0f);   // 256-byte alignment for scalar/vector loads
-        net->off[name] = host.size();
-        host.insert(host.end(), v.begin(), v.end());
-    };
-    auto put_raw = [&](const char* name, const float* p, size_t n) { put(name, std::vector<float>(p, p + n)); };
+    AlikeNet* net = new AlikeNet();
+    net->ctx = ctx; net->arch = KPB_ARCH_ALIKE; net->dim = dim; net->desc_div = 1;
+    WeightStage ws;
+    std::vector<float> tmp;
     {   // block1 conv1: [co][ci][ky][kx] -> [(ci,ky,kx)][co]
         const float* w = bl.get("b1c1.w", {c1, 3, 3, 3});
         tmp.assign(27 * 8, 0.f);
         for (int o = 0; o < 8; ++o) for (int k = 0; k < 27; ++k) tmp[k * 8 + o] = w[o * 27 + k];
-        put("b1c1.w", tmp);
-        put_raw("b1c1.b", bl.get("b1c1.b", {c1}), 8);
-        repack3x3(bl.get("b1c2.w", {c1, c1, 3, 3}), 8, 8, tmp); put("b1c2.w", tmp);
-        put_raw("b1c2.b", bl.get("b1c2.b", {c1}), 8);
+        ws.put("b1c1.w", tmp);
+        ws.put_raw("b1c1.b", bl.get("b1c1.b", {c1}), 8);
+        repack3x3(bl.get("b1c2.w", {c1, c1, 3, 3}), 8, 8, tmp); ws.put("b1c2.w", tmp);
+        ws.put_raw("b1c2.b", bl.get("b1c2.b", {c1}), 8);
     }
     const uint32_t ch[5] = {0, c1, c2, c3, c4};
     for (int i = 2; i <= 4; ++i) {
         char nm[16];
         const uint32_t ci = ch[i - 1], co = ch[i];
-        snprintf(nm, 16, "b%dc1.w", i); repack3x3(bl.get(nm, {co, ci, 3, 3}), co, ci, tmp); put(nm, tmp);
-        snprintf(nm, 16, "b%dc1.b", i); put_raw(nm, bl.get(nm, {co}), co);
-        snprintf(nm, 16, "b%dc2.w", i); repack3x3(bl.get(nm, {co, co, 3, 3}), co, co, tmp); put(nm, tmp);
-        snprintf(nm, 16, "b%dc2.b", i); put_raw(nm, bl.get(nm, {co}), co);
-        snprintf(nm, 16, "b%dds.w", i); transpose(bl.get(nm, {co, ci}), co, ci, tmp); put(nm, tmp);
-        snprintf(nm, 16, "b%dds.b", i); put_raw(nm, bl.get(nm, {co}), co);
+        snprintf(nm, 16, "b%dc1.w", i); repack3x3(bl.get(nm, {co, ci, 3, 3}), co, ci, tmp); ws.put(nm, tmp);
+        snprintf(nm, 16, "b%dc1.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
+        snprintf(nm, 16, "b%dc2.w", i); repack3x3(bl.get(nm, {co, co, 3, 3}), co, co, tmp); ws.put(nm, tmp);
+        snprintf(nm, 16, "b%dc2.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
+        snprintf(nm, 16, "b%dds.w", i); transpose(bl.get(nm, {co, ci}), co, ci, tmp); ws.put(nm, tmp);
+        snprintf(nm, 16, "b%dds.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
     }
     for (int i = 1; i <= 4; ++i) {
         char nm[16];
         snprintf(nm, 16, "agg%d.w", i);
-        transpose(bl.get(nm, {dim / 4, ch[i]}), dim / 4, ch[i], tmp); put(nm, tmp);
+        transpose(bl.get(nm, {dim / 4, ch[i]}), dim / 4, ch[i], tmp); ws.put(nm, tmp);
     }
     {
         const float* hw = bl.get("head.w", {dim + 1, dim});
-        transpose(hw, 64, 64, tmp); put("head.wT", tmp);
-        put_raw("head.ws", hw + 64 * 64, 64);
+        transpose(hw, 64, 64, tmp); ws.put("head.wT", tmp);
+        ws.put_raw("head.ws", hw + 64 * 64, 64);
     }
-    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&net->wdev, host.size() * sizeof(float)) != hipSuccess) {
-        delete net;
-        return kpb_fail(ctx, KPB_E_NOMEM, "kpb_net_create: weight allocation failed");
-    }
-    if (hipMemcpy(net->wdev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(net->wdev);
-        delete net;
-        return kpb_fail(ctx, KPB_E_HIP, "kpb_net_create: weight upload failed");
-    }
+    if (int rc = ws.upload(net)) { delete net; return rc; }
     *out = net;
-    return KPB_OK;
-}
-
-KPB_API void kpb_net_destroy(kpb_net* net)
-{
-    if (!net) return;
-    (void)hipSetDevice(net->ctx->device);
-    (void)hipStreamSynchronize(net->ctx->stream);
-    if (net->wdev) (void)hipFree(net->wdev);
-    if (net->act.p) (void)hipFree(net->act.p);
-    delete net;
-}
-
-KPB_API int kpb_net_desc_dim(const kpb_net* net) { return net ? net->dim : 0; }
-
-static HeadArgs head_args(kpb_net* net, float* score, float* desc)
-{
-    HeadArgs h;
-    h.x1 = net->x1; h.a2 = net->a2; h.a3 = net->a3; h.a4 = net->a4;
-    h.agg1 = net->wdev + net->off["agg1.w"];
-    h.whT = net->wdev + net->off["head.wT"];
-    h.wsc = net->wdev + net->off["head.ws"];
-    h.score = score; h.desc = desc; h.H = net->H; h.W = net->W;
-    return h;
-}
-
-KPB_API int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H, int W, float* score_out_dev,
-                            float* desc_out_dev)
-{
-    if (!net) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_net_forward: null net");
-    kpb_ctx* ctx = net->ctx;
-    if (!img_dev || !score_out_dev || batch <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32))
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: H and W must be positive multiples of 32 (got %dx%d)", H, W);
-    KPB_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t P = (size_t)H * W, B = batch;
-    const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
-                 n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
-    const size_t total = n_x1 + 3 * n_2 + 2 * n_3 + n_a3 + 2 * n_4 + n_a4;
-    if (int rc = kpb_reserve(ctx, net->act, total * sizeof(float))) return rc;
-    float* p = static_cast<float*>(net->act.p);
-    net->x1 = p; p += n_x1;
-    net->t2 = p; p += n_2; net->x2 = p; p += n_2; net->a2 = p; p += n_2;
-    net->t3 = p; p += n_3; net->x3 = p; p += n_3; net->a3 = p; p += n_a3;
-    net->t4 = p; p += n_4; net->x4 = p; p += n_4; net->a4 = p; p += n_a4;
-    net->B = batch; net->H = H; net->W = W;
-    hipStream_t st = ctx->stream;
-    auto wp = [&](const char* n) { return net->wdev + net->off[n]; };
-
-    Block1Args b1{img_dev, net->x1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
-    KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
-
-    ConvArgs c;
-    // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
-    c = ConvArgs{net->x1, net->t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, H / 2, W / 2};
-    launch_conv<8, 16, 2, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
-    c = ConvArgs{net->t2, net->x2, wp("b2c2.w"), wp("b2c2.b"), net->x1, wp("b2ds.w"), wp("b2ds.b"), H / 2, W / 2};
-    launch_conv<16, 16, 1, true, 8, 2>(ctx, "conv3x3_b2c2", st, c, batch);
-    // block3 @ H/8 (141-142): pool4
-    c = ConvArgs{net->x2, net->t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, nullptr, nullptr, H / 8, W / 8};
-    launch_conv<16, 32, 4, false, 4, 1>(ctx, "conv3x3_b3c1", st, c, batch);
-    c = ConvArgs{net->t3, net->x3, wp("b3c2.w"), wp("b3c2.b"), net->x2, wp("b3ds.w"), wp("b3ds.b"), H / 8, W / 8};
-    launch_conv<32, 32, 1, true, 16, 4>(ctx, "conv3x3_b3c2", st, c, batch);
-    // block4 @ H/32 (143-144): pool4
-    c = ConvArgs{net->x3, net->t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, nullptr, nullptr, H / 32, W / 32};
-    launch_conv<32, 64, 4, false, 4, 1>(ctx, "conv3x3_b4c1", st, c, batch);
-    c = ConvArgs{net->t4, net->x4, wp("b4c2.w"), wp("b4c2.b"), net->x3, wp("b4ds.w"), wp("b4ds.b"), H / 32, W / 32};
-    launch_conv<64, 64, 1, true, 32, 4>(ctx, "conv3x3_b4c2", st, c, batch);
-    // aggregation 1x1 + ReLU (147-150); agg1 is fused into the head
-    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, net->x2, net->a2, wp("agg2.w"), B * P / 4);
-    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, net->x3, net->a3, wp("agg3.w"), B * P / 64);
-    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, net->x4, net->a4, wp("agg4.w"), B * P / 1024);
-    // upsample + concat + head (151-162)
-    HeadArgs h = head_args(net, score_out_dev, desc_out_dev);
-    const dim3 hg(cdiv(H * (W / 32), 4 * HEAD_TILES), batch);
-    if (desc_out_dev) KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, hg, dim3(256), 0, st, h);
-    else KPB_LAUNCH(ctx, "alike_head_score", alike_head<false>, hg, dim3(256), 0, st, h);
-    KPB_HIP(ctx, hipGetLastError());
-    return KPB_OK;
-}
-
-KPB_API int kpb_net_desc_at(kpb_net* net, const float* pts_dev, int pts_cols, int max_n, const int32_t* n_dev,
-                            float* out_dev)
-{
-    if (!net) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_net_desc_at: null net");
-    kpb_ctx* ctx = net->ctx;
-    if (net->B == 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_desc_at: no forward has run");
-    if (max_n == 0) return KPB_OK;
-    if (!pts_dev || !out_dev || pts_cols < 2 || max_n < 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_desc_at: bad argument");
-    KPB_HIP(ctx, hipSetDevice(ctx->device));
-    DescAtArgs a{head_args(net, nullptr, nullptr), pts_dev, n_dev, out_dev, pts_cols, max_n};
-    KPB_LAUNCH(ctx, "alike_desc_at", alike_desc_at, dim3(cdiv(max_n, 4), net->B), dim3(256), 0, ctx->stream, a);
-    KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }

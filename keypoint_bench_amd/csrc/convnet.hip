@@ -1,0 +1,395 @@
+// convnet.hip -- N2 SuperPoint (models/SuperPoint.py:30-71) on gfx950: a generic fp32 NHWC convolution on
+// v_mfma_f32_32x32x2_f32 for the wide layers, a VALU convolution for the thin ones, and the small
+// head kernels (RGB sum, softmax + depth-to-space heat-map, descriptor L2 normalisation).
+//
+// conv_mfma: implicit GEMM, M = 128 output pixels (8x16 tile, 32 per wave), N = 64 output channels per
+// workgroup (two 32-wide MFMA tiles per wave), K = taps x CIN in chunks of CC channels staged in LDS with a
+// 4-float pad per pixel (16 lanes x ds_read_b128 then hit 16 distinct 4-bank groups).  Lane (p, h) owns
+// pixel p and, of every chunk, channels h*CC/2 .. +CC/2: the A operand is CC/8 ds_read_b128 per tap and the
+// weights are pre-packed in exactly that fragment order so B is CC/8 global float4 loads per 32-wide tile.
+// The 2x2 max-pools of the VGG trunk are fused: on the input read (POOL_IN) or lane-locally on the
+// accumulators (POOL_OUT: the four pixels of a pool window live in registers r, r+1, r+8, r+9 of one lane).
+#include "net.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float relu(float v) { return fmaxf(v, 0.0f); }
+
+struct ConvM {
+    const float* in;    // [B][Hi][Wi][CIN]
+    float* out;         // [B][Ho][Wo][COUT]   (Ho, Wo) = (H, W) or (H/2, W/2) with POOL_OUT
+    const float* wp;    // packed: [ntile][tap][chunk][h][32][KC]
+    const float* bias;  // [COUTP] (zero padded)
+    int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
+};
+
+template <int KS, int S, bool POOL_IN, bool POOL_OUT>
+__global__ __launch_bounds__(256) void conv_mfma(ConvM a)
+{
+    constexpr int CC = (S == 1) ? 32 : 16, KC = CC / 2, PITCH = CC + 4, T = KS * KS, PAD = KS / 2;
+    constexpr int IH = 7 * S + KS, IW = 15 * S + KS, Q = CC / 4;
+    constexpr int NLD = (IH * IW * Q + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float tile[IH * IW * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * 2;
+    const int ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 16;
+    const int Hc = POOL_IN ? a.Hi / 2 : a.Hi, Wc = POOL_IN ? a.Wi / 2 : a.Wi;   // conv input extent
+    const int iy0 = ty0 * S - PAD, ix0 = tx0 * S - PAD;
+    const float* in = a.in + (size_t)b * a.Hi * a.Wi * a.CIN;
+    const int orow = 2 * wv + (p >> 4), ocol = p & 15;
+    const size_t ntile_stride = (size_t)T * a.NCH * 2 * 32 * KC;
+
+    f32x16 acc0 = {0}, acc1 = {0};
+    for (int ch = 0; ch < a.NCH; ++ch) {
+        __syncthreads();
+        {   // stage one CC-channel slab of the input tile; every load of a thread is in flight before the first LDS store
+            float4 buf[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                const int pix = idx / Q, q = idx - pix * Q;
+                const int y = pix / IW, x = pix - y * IW;
+                const int gy = iy0 + y, gx = ix0 + x;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < IH * IW * Q && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
+                    if (POOL_IN) {
+                        const float* s = in + ((size_t)(2 * gy) * a.Wi + 2 * gx) * a.CIN + ch * CC + 4 * q;
+                        const float4 v00 = *reinterpret_cast<const float4*>(s), v01 = *reinterpret_cast<const float4*>(s + a.CIN);
+                        const float4 v10 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.CIN);
+                        const float4 v11 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.CIN + a.CIN);
+                        v.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)); v.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+                        v.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); v.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+                    } else {
+                        v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.CIN + ch * CC + 4 * q);
+                    }
+                }
+                buf[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                const int pix = idx / Q, q = idx - pix * Q;
+                if (idx < IH * IW * Q) *reinterpret_cast<float4*>(&tile[pix * PITCH + 4 * q]) = buf[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const float* ap = &tile[((orow * S + ky) * IW + ocol * S + kx) * PITCH + h * KC];
+            const float* bp = a.wp + ((((size_t)nt0 * T + tap) * a.NCH + ch) * 2 + h) * 32 * KC + p * KC;
+            float A[KC], B0[KC], B1[KC];
+#pragma unroll
+            for (int q = 0; q < KC / 4; ++q) {
+                const float4 va = *reinterpret_cast<const float4*>(ap + 4 * q);
+                const float4 v0 = *reinterpret_cast<const float4*>(bp + 4 * q);
+                const float4 v1 = *reinterpret_cast<const float4*>(bp + ntile_stride + 4 * q);
+                A[4 * q] = va.x; A[4 * q + 1] = va.y; A[4 * q + 2] = va.z; A[4 * q + 3] = va.w;
+                B0[4 * q] = v0.x; B0[4 * q + 1] = v0.y; B0[4 * q + 2] = v0.z; B0[4 * q + 3] = v0.w;
+                B1[4 * q] = v1.x; B1[4 * q + 1] = v1.y; B1[4 * q + 2] = v1.z; B1[4 * q + 3] = v1.w;
+            }
+#pragma unroll
+            for (int s = 0; s < KC; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], B0[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], B1[s], acc1, 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: D[row = pixel i][col = channel]; lane holds channel p of each 32-wide tile, pixels (r&3) + 8*(r>>2) + 4h
+    const int co0 = nt0 * 32 + p, co1 = co0 + 32;
+    const float bias0 = a.bias[co0], bias1 = a.bias[co1];
+    float v0[16], v1[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        v0[r] = acc0[r] + bias0; v1[r] = acc1[r] + bias1;
+        if (a.relu) { v0[r] = relu(v0[r]); v1[r] = relu(v1[r]); }
+    }
+    if (!POOL_OUT) {
+        float* out = a.out + (size_t)b * a.H * a.W * a.COUT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int gy = ty0 + 2 * wv + (i >> 4), gx = tx0 + (i & 15);
+            if (gy < a.H && gx < a.W) {
+                float* o = out + ((size_t)gy * a.W + gx) * a.COUT;
+                if (co0 < a.COUT) o[co0] = v0[r];
+                if (co1 < a.COUT) o[co1] = v1[r];
+            }
+        }
+    } else {
+        const int Ho = a.H / 2, Wo = a.W / 2;
+        float* out = a.out + (size_t)b * Ho * Wo * a.COUT;
+        const int gy = ty0 / 2 + wv;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int c = 2 * h + (cc & 1) + 4 * (cc >> 1);       // pooled column inside the tile
+            const int rA = 2 * (cc & 1) + 4 * (cc >> 1);          // = 2*(c&1) + 4*(c>>2)
+            const int gx = tx0 / 2 + c;
+            if (gy < Ho && gx < Wo) {
+                float* o = out + ((size_t)gy * Wo + gx) * a.COUT;
+                if (co0 < a.COUT) o[co0] = fmaxf(fmaxf(v0[rA], v0[rA + 1]), fmaxf(v0[rA + 8], v0[rA + 9]));
+                if (co1 < a.COUT) o[co1] = fmaxf(fmaxf(v1[rA], v1[rA + 1]), fmaxf(v1[rA + 8], v1[rA + 9]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// VALU convolution for thin layers (CIN or COUT not MFMA shaped): one pixel x 8 output channels per thread,
+// weights [tap][cin][COUT8] wave-uniform (scalar loads), inputs straight from L1/L2.
+struct ConvV {
+    const float* in; float* out; const float* w; const float* bias;
+    int Hi, Wi, H, W, CIN, COUT, COUT8, KS, S, PAD, relu;
+};
+
+__global__ __launch_bounds__(256) void conv_valu(ConvV a)
+{
+    const int b = blockIdx.z, cg = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= a.H * a.W) return;
+    const int oy = pix / a.W, ox = pix - oy * a.W;
+    const float* in = a.in + (size_t)b * a.Hi * a.Wi * a.CIN;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = a.bias[cg * 8 + j];
+    for (int ky = 0; ky < a.KS; ++ky) {
+        const int iy = oy * a.S + ky - a.PAD;
+        if (iy < 0 || iy >= a.Hi) continue;
+        for (int kx = 0; kx < a.KS; ++kx) {
+            const int ix = ox * a.S + kx - a.PAD;
+            if (ix < 0 || ix >= a.Wi) continue;
+            const float* src = in + ((size_t)iy * a.Wi + ix) * a.CIN;
+            const float* w = a.w + ((size_t)(ky * a.KS + kx) * a.CIN) * a.COUT8 + cg * 8;
+            for (int c = 0; c < a.CIN; ++c) {
+                const float v = src[c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[(size_t)c * a.COUT8 + j], acc[j]);
+            }
+        }
+    }
+    float* o = a.out + ((size_t)b * a.H * a.W + pix) * a.COUT + cg * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (cg * 8 + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+// SuperPoint.py:42  x = torch.sum(x, dim=1, keepdim=True)
+__global__ void rgb_sum(const float* img, float* gray, size_t P)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t b = blockIdx.y;
+    if (i < P) gray[b * P + i] = (img[(b * 3 + 0) * P + i] + img[(b * 3 + 1) * P + i]) + img[(b * 3 + 2) * P + i];
+}
+
+// SuperPoint.py:64-69: softmax over the 65 logits of a cell, drop the dustbin, depth-to-space 8x8.
+// One wave per cell: lane c holds logit c, lane 0 also folds in logit 64.
+__global__ __launch_bounds__(256) void softmax65_d2s(const float* semi, float* heat, int Hc, int Wc, int ncell)
+{
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (cell >= ncell) return;
+    const float* s = semi + ((size_t)b * ncell + cell) * 65;
+    const float v = s[lane], d = s[64];
+    float m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m = fmaxf(m, d);
+    const float e = expf(v - m), ed = expf(d - m);
+    float sum = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum += ed;
+    const int cy = cell / Wc, cx = cell - cy * Wc;
+    const int W = Wc * 8;
+    heat[(size_t)b * Hc * 8 * W + (size_t)(cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)] = __fdiv_rn(e, sum);
+}
+
+// SuperPoint.py:61-62: desc / ||desc||_2 over the C channels of each pixel (no epsilon).  One wave per pixel.
+__global__ __launch_bounds__(256) void l2norm_nhwc(float* desc, int C, size_t npix, float eps_clamp)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= npix) return;
+    float* d = desc + pix * C;
+    float ss = 0.0f;
+    for (int c = lane; c < C; c += 64) ss = fmaf(d[c], d[c], ss);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    float n = sqrtf(ss);
+    if (eps_clamp > 0.0f) n = fmaxf(n, eps_clamp);     // F.normalize clamps; torch.norm + div does not
+    for (int c = lane; c < C; c += 64) d[c] = __fdiv_rn(d[c], n);
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+// OIHW [COUT][CIN][KS][KS] -> conv_mfma fragment order [ntile][tap][chunk][h][32][KC]
+std::vector<float> pack_mfma(const float* w, int COUT, int CIN, int KS, int CC)
+{
+    const int KC = CC / 2, T = KS * KS, NCH = CIN / CC, NT = ((COUT + 63) / 64) * 2;
+    std::vector<float> out((size_t)NT * T * NCH * 2 * 32 * KC, 0.0f);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int tap = 0; tap < T; ++tap)
+            for (int ch = 0; ch < NCH; ++ch)
+                for (int h = 0; h < 2; ++h)
+                    for (int j = 0; j < 32; ++j)
+                        for (int s = 0; s < KC; ++s) {
+                            const int o = nt * 32 + j, c = ch * CC + h * KC + s;
+                            if (o < COUT)
+                                out[(((((size_t)nt * T + tap) * NCH + ch) * 2 + h) * 32 + j) * KC + s] = w[((size_t)o * CIN + c) * T + tap];
+                        }
+    return out;
+}
+
+std::vector<float> pad_bias(const float* b, int COUT, int mult)
+{
+    std::vector<float> out(((COUT + mult - 1) / mult) * mult, 0.0f);
+    if (b) for (int i = 0; i < COUT; ++i) out[i] = b[i];
+    return out;
+}
+
+// OIHW -> [tap][cin][COUT8]
+std::vector<float> pack_valu(const float* w, int COUT, int CIN, int KS)
+{
+    const int T = KS * KS, C8 = ((COUT + 7) / 8) * 8;
+    std::vector<float> out((size_t)T * CIN * C8, 0.0f);
+    for (int o = 0; o < COUT; ++o)
+        for (int c = 0; c < CIN; ++c)
+            for (int t = 0; t < T; ++t) out[((size_t)t * CIN + c) * C8 + o] = w[((size_t)o * CIN + c) * T + t];
+    return out;
+}
+
+struct Layer {      // one convolution of a network plan
+    std::string name;
+    int cin, cout, ks, stride;
+    bool mfma;
+};
+
+int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
+                bool pool_in, bool pool_out, bool relu_)
+{
+    const int S = L.stride, CC = S == 1 ? 32 : 16, PAD = L.ks / 2;
+    const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
+    ConvM a;
+    a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str());
+    a.Hi = Hi; a.Wi = Wi;
+    a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
+    a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 63) / 64;
+    const dim3 grid(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk), block(256);
+    hipStream_t st = ctx->stream;
+    if (L.ks == 3 && S == 1 && !pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, false, false>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 1 && !pool_in && pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, false, true>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 1 && pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, true, false>), grid, block, 0, st, a);
+    else if (L.ks == 1 && S == 1 && !pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<1, 1, false, false>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 2 && !pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 2, false, false>), grid, block, 0, st, a);
+    else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma: no instance for ks=%d stride=%d pool_in=%d pool_out=%d", L.ks, S, pool_in, pool_out);
+    return KPB_OK;
+}
+
+int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
+                bool relu_)
+{
+    ConvV a;
+    a.in = in; a.out = out; a.w = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str());
+    a.Hi = Hi; a.Wi = Wi; a.KS = L.ks; a.S = L.stride; a.PAD = L.ks / 2;
+    a.H = (Hi + 2 * a.PAD - L.ks) / L.stride + 1; a.W = (Wi + 2 * a.PAD - L.ks) / L.stride + 1;
+    a.CIN = L.cin; a.COUT = L.cout; a.COUT8 = ((L.cout + 7) / 8) * 8; a.relu = relu_ ? 1 : 0;
+    KPB_LAUNCH(ctx, name, conv_valu, dim3(cdiv(a.H * a.W, 256), a.COUT8 / 8, B), dim3(256), 0, ctx->stream, a);
+    return KPB_OK;
+}
+
+void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b)
+{
+    if (L.mfma) {
+        ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.stride == 1 ? 32 : 16));
+        ws.put(L.name + ".b", pad_bias(b, L.cout, 64));
+    } else {
+        ws.put(L.name + ".w", pack_valu(w, L.cout, L.cin, L.ks));
+        ws.put(L.name + ".b", pad_bias(b, L.cout, 8));
+    }
+}
+
+// ================================================================================================ SuperPoint
+struct SuperPointNet : kpb_net {
+    std::map<std::string, Layer> L;
+    int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
+    {
+        if ((H_ % 8) || (W_ % 8)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: SuperPoint needs H and W multiples of 8 (got %dx%d)", H_, W_);
+        if (!desc_out) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: SuperPoint writes its 256 x H/8 x W/8 descriptor map; desc_out_dev is required");
+        const int H = H_, W = W_, Hc = H / 8, Wc = W / 8;
+        const size_t P = (size_t)H * W, B = batch;
+        // activations (floats per image)
+        const size_t n_gray = P, n_1a = P * 64, n_1b = P / 4 * 64, n_2a = P / 4 * 64, n_2b = P / 16 * 64, n_3a = P / 16 * 128,
+                     n_3b = P / 64 * 128, n_4a = P / 64 * 128, n_4b = P / 64 * 128, n_pa = P / 64 * 256, n_semi = P / 64 * 65, n_da = P / 64 * 256;
+        const size_t total = B * (n_gray + n_1a + n_1b + n_2a + n_2b + n_3a + n_3b + n_4a + n_4b + n_pa + n_semi + n_da);
+        if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
+        float* p = static_cast<float*>(act.p);
+        float* gray = p; p += B * n_gray;
+        float* x1a = p; p += B * n_1a;
+        float* x1b = p; p += B * n_1b;
+        float* x2a = p; p += B * n_2a;
+        float* x2b = p; p += B * n_2b;
+        float* x3a = p; p += B * n_3a;
+        float* x3b = p; p += B * n_3b;
+        float* x4a = p; p += B * n_4a;
+        float* x4b = p; p += B * n_4b;
+        float* cpa = p; p += B * n_pa;
+        float* semi = p; p += B * n_semi;
+        float* cda = p; p += B * n_da;
+        this->B = batch; this->H = H; this->W = W;
+        hipStream_t st = ctx->stream;
+        KPB_LAUNCH(ctx, "sp_rgb_sum", rgb_sum, dim3((unsigned)((P + 255) / 256), batch), dim3(256), 0, st, img, gray, P);
+        int rc;
+        if ((rc = launch_valu(ctx, "sp_conv1a", this, L["conv1a"], gray, x1a, batch, H, W, true))) return rc;          // :44
+        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], x1a, x1b, batch, H, W, false, true, true))) return rc;      // :45-46 (+pool)
+        if ((rc = launch_mfma(ctx, "sp_conv2a", this, L["conv2a"], x1b, x2a, batch, H / 2, W / 2, false, false, true))) return rc;
+        if ((rc = launch_mfma(ctx, "sp_conv2b", this, L["conv2b"], x2a, x2b, batch, H / 2, W / 2, false, true, true))) return rc;
+        if ((rc = launch_mfma(ctx, "sp_conv3a", this, L["conv3a"], x2b, x3a, batch, H / 4, W / 4, false, false, true))) return rc;
+        if ((rc = launch_mfma(ctx, "sp_conv3b", this, L["conv3b"], x3a, x3b, batch, H / 4, W / 4, false, true, true))) return rc;
+        if ((rc = launch_mfma(ctx, "sp_conv4a", this, L["conv4a"], x3b, x4a, batch, Hc, Wc, false, false, true))) return rc;
+        if ((rc = launch_mfma(ctx, "sp_conv4b", this, L["conv4b"], x4a, x4b, batch, Hc, Wc, false, false, true))) return rc;
+        if ((rc = launch_mfma(ctx, "sp_convPa", this, L["convPa"], x4b, cpa, batch, Hc, Wc, false, false, true))) return rc;    // :56
+        if ((rc = launch_mfma(ctx, "sp_convPb", this, L["convPb"], cpa, semi, batch, Hc, Wc, false, false, false))) return rc;  // :57
+        if ((rc = launch_mfma(ctx, "sp_convDa", this, L["convDa"], x4b, cda, batch, Hc, Wc, false, false, true))) return rc;    // :59
+        if ((rc = launch_mfma(ctx, "sp_convDb", this, L["convDb"], cda, desc_out, batch, Hc, Wc, false, false, false))) return rc; // :60
+        KPB_LAUNCH(ctx, "sp_l2norm", l2norm_nhwc, dim3((unsigned)((B * Hc * Wc + 3) / 4)), dim3(256), 0, st, desc_out, 256, B * Hc * Wc, 0.0f);
+        KPB_LAUNCH(ctx, "sp_softmax_d2s", softmax65_d2s, dim3(cdiv(Hc * Wc, 4), batch), dim3(256), 0, st, semi, score_out, Hc, Wc, Hc * Wc);
+        KPB_HIP(ctx, hipGetLastError());
+        return KPB_OK;
+    }
+};
+
+}  // namespace
+
+int superpoint_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
+{
+    const Layer plan[] = {
+        {"conv1a", 1, 64, 3, 1, false}, {"conv1b", 64, 64, 3, 1, true}, {"conv2a", 64, 64, 3, 1, true}, {"conv2b", 64, 64, 3, 1, true},
+        {"conv3a", 64, 128, 3, 1, true}, {"conv3b", 128, 128, 3, 1, true}, {"conv4a", 128, 128, 3, 1, true}, {"conv4b", 128, 128, 3, 1, true},
+        {"convPa", 128, 256, 3, 1, true}, {"convPb", 256, 65, 1, 1, true}, {"convDa", 128, 256, 3, 1, true}, {"convDb", 256, 256, 1, 1, true}};
+    SuperPointNet* net = new SuperPointNet();
+    net->ctx = ctx; net->arch = KPB_ARCH_SUPERPOINT; net->dim = 256; net->desc_div = 8;
+    WeightStage ws;
+    for (const Layer& L : plan) {
+        const float* w = bl.get((L.name + ".weight").c_str(), {(uint32_t)L.cout, (uint32_t)L.cin, (uint32_t)L.ks, (uint32_t)L.ks});
+        const float* b = bl.get((L.name + ".bias").c_str(), {(uint32_t)L.cout});
+        if (!w || !b) {
+            delete net;
+            return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: SuperPoint tensor %s.weight/.bias missing or mis-shaped", L.name.c_str());
+        }
+        stage_layer(ws, L, w, b);
+        net->L[L.name] = L;
+    }
+    if (int rc = ws.upload(net)) { delete net; return rc; }
+    *out = net;
+    return KPB_OK;
+}
+
+int xfeat_create(kpb_ctx* ctx, const KpbwBlob&, kpb_net** out)
+{
+    *out = nullptr;
+    return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: XFeat kernels are not in this build yet");
+}

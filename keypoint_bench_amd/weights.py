@@ -13,6 +13,8 @@ import numpy as np
 
 MAGIC = b"KPBWGT1\0"
 ARCH_ALIKE = 1
+ARCH_SUPERPOINT = 2
+ARCH_XFEAT = 3
 _REC = struct.Struct("<40sI4II")
 
 
@@ -79,3 +81,32 @@ def load_alike_t():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "weights", "alike-t.kpbw")
     with open(path, "rb") as f:
         return unpack(f.read())[1]
+
+
+SUPERPOINT_LAYERS = ("conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b",
+                     "convPa", "convPb", "convDa", "convDb")
+
+
+def tensors_superpoint(sd) -> dict:
+    """state_dict of SuperPointNet (models/SuperPoint.py:9-28) -> fp32 tensors under the same names."""
+    t = {}
+    for n in SUPERPOINT_LAYERS:
+        t[n + ".weight"] = _np(sd[n + ".weight"]).astype(np.float32)
+        t[n + ".bias"] = _np(sd[n + ".bias"]).astype(np.float32)
+    return t
+
+
+def random_superpoint(seed: int) -> dict:
+    """Seeded stand-in for the absent superpoint_v1.pth (.MISSING_LARGE_BLOBS): He-uniform conv weights, small
+    biases, drawn from numpy so the same seed gives the same tensors on every machine."""
+    rng = np.random.default_rng(seed)
+    shapes = dict(conv1a=(64, 1, 3), conv1b=(64, 64, 3), conv2a=(64, 64, 3), conv2b=(64, 64, 3), conv3a=(128, 64, 3),
+                  conv3b=(128, 128, 3), conv4a=(128, 128, 3), conv4b=(128, 128, 3), convPa=(256, 128, 3),
+                  convPb=(65, 256, 1), convDa=(256, 128, 3), convDb=(256, 256, 1))
+    t = {}
+    for n in SUPERPOINT_LAYERS:
+        co, ci, k = shapes[n]
+        bound = np.sqrt(6.0 / (ci * k * k))
+        t[n + ".weight"] = rng.uniform(-bound, bound, size=(co, ci, k, k)).astype(np.float32)
+        t[n + ".bias"] = rng.uniform(-0.05, 0.05, size=(co,)).astype(np.float32)
+    return t

@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Golden fixtures for the nets whose checkpoints are absent from the reference tree (SuperPoint, XFeat):
+runs the REFERENCE model classes (models/SuperPoint.py, models/XFeat.py; only `utils.export` is stood in for,
+an ONNX/TensorRT exporter their forward never touches) with seeded random weights from
+keypoint_bench_amd.weights.random_*.  Build container only; see make_golden.py for the ground rules."""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference checkout not present; nothing to do")
+        return 0
+    import torch
+    sys.path.insert(0, ROOT)
+    from keypoint_bench_amd import synthetic, weights
+    uexp = types.ModuleType("utils.export")
+    uexp.export_model = lambda *a, **k: None
+    upkg = types.ModuleType("utils")
+    upkg.__path__ = []
+    upkg.export = uexp
+    sys.modules.update({"utils": upkg, "utils.export": uexp})
+    torch.set_num_threads(8)
+    out = {}
+
+    sp = _load("ref_superpoint", os.path.join(REF, "models", "SuperPoint.py"))
+    net = sp.SuperPointNet()
+    t = weights.random_superpoint(7)
+    print("  superpoint load_state_dict:", net.load_state_dict({k: torch.from_numpy(v) for k, v in t.items()}))
+    net.eval()
+    out["sp.seed"] = np.array(7)
+    out["sp.wsum"] = np.array(synthetic.checksum(np.concatenate([t[k].ravel() for k in sorted(t)])))
+    with torch.no_grad():
+        for tag, (H, W) in (("small", (64, 96)), ("full", (480, 640))):
+            v0, _ = synthetic.image_pair(0, H, W)
+            heat, desc = net(torch.from_numpy(v0)[None])
+            out["sp.%s.img.sum" % tag] = np.array(synthetic.checksum(v0))
+            out["sp.%s.heat" % tag] = heat[0, 0].numpy()
+            out["sp.%s.desc" % tag] = desc[0].numpy() if tag == "small" else desc[0, :, ::4, ::4].numpy()
+            print("  superpoint", tag, tuple(heat.shape), tuple(desc.shape), float(heat.min()), float(heat.max()))
+    np.savez_compressed(os.path.join(HERE, "nets.npz"), **out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

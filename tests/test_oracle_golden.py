@@ -136,3 +136,18 @@ def test_weight_blob_roundtrip():
     for k in t:
         np.testing.assert_array_equal(t[k], t2[k])
     assert t["head.w"].shape == (65, 64) and t["b1c1.w"].shape == (8, 3, 3, 3)
+
+
+def test_superpoint_restatement_matches_reference_forward():
+    import torch
+    from oracle import superpoint_ref
+    g = load_golden("nets.npz")
+    tw = weights.random_superpoint(int(g["sp.seed"]))
+    assert synthetic.checksum(np.concatenate([tw[k].ravel() for k in sorted(tw)])) == str(g["sp.wsum"])
+    t = {k: torch.from_numpy(v) for k, v in tw.items()}
+    v0, _ = synthetic.image_pair(0, 64, 96)
+    assert synthetic.checksum(v0) == str(g["sp.small.img.sum"])
+    with torch.no_grad():
+        heat, desc = superpoint_ref.superpoint_forward(torch.from_numpy(v0)[None], t)
+    np.testing.assert_allclose(heat[0, 0].numpy(), g["sp.small.heat"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(desc[0].numpy(), g["sp.small.desc"], rtol=0, atol=1e-5)
