@@ -103,6 +103,27 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     return c
 
 
+def superpoint_costs(B2):
+    """(FLOPs, bytes) per launch of the SuperPoint conv kernels (2*MAC; NHWC fp32 in + out, weights negligible)."""
+    P = H * W
+    c = {}
+    def conv(name, px, cin, cout, k, in_px=None, out_px=None):
+        c[name] = (2 * px * k * k * cin * cout * B2, ((in_px or px) * cin + (out_px or px) * cout) * 4 * B2)
+    conv("sp_conv1a", P, 1, 64, 3)
+    conv("sp_conv1b", P, 64, 64, 3, out_px=P // 4)
+    conv("sp_conv2a", P // 4, 64, 64, 3)
+    conv("sp_conv2b", P // 4, 64, 64, 3, out_px=P // 16)
+    conv("sp_conv3a", P // 16, 64, 128, 3)
+    conv("sp_conv3b", P // 16, 128, 128, 3, out_px=P // 64)
+    conv("sp_conv4a", P // 64, 128, 128, 3)
+    conv("sp_conv4b", P // 64, 128, 128, 3)
+    conv("sp_convPa", P // 64, 128, 256, 3)
+    conv("sp_convPb", P // 64, 256, 65, 1)
+    conv("sp_convDa", P // 64, 128, 256, 3)
+    conv("sp_convDb", P // 64, 256, 256, 1)
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +133,8 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
+    ap.add_argument("--model", default="alike", choices=["alike", "superpoint"],
+                    help="alike = BASELINE configs[1] (the headline); superpoint = configs[2] with seeded random weights")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,7 +163,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.pairs_per_step
-    net = alike_t(dense_descriptors=not args.sparse).eval()
+    if args.model == "superpoint":
+        from keypoint_bench_amd.models.SuperPoint import superpoint_random
+        net = superpoint_random(7).eval()
+        if args.pairs_per_step == 64:
+            B = 16
+    else:
+        net = alike_t(dense_descriptors=not args.sparse).eval()
     pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
     # synthetic pairs, different per rank, resident in HBM
     nd = min(args.distinct, B)
@@ -188,7 +217,8 @@ def main():
     ctx.prof_enable(False)
     if rank == 0 and prof:
         sweeps = prof.get("nms_sweep", (1, 0))[0] / prof_steps
-        costs = kernel_costs(2 * B, B, EXTRACTOR["top_k"], net.param["dim"], not args.sparse, sweeps)
+        costs = kernel_costs(2 * B, B, EXTRACTOR["top_k"], net.dim, not args.sparse, sweeps)
+        costs.update(superpoint_costs(2 * B))
         name = max(prof, key=lambda k: prof[k][1])
         calls, total_ms = prof[name]
         avg_ms = total_ms / calls
@@ -212,10 +242,10 @@ def main():
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ALIKE-t extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
+            "config": {"workload": ("SuperPoint" if args.model == "superpoint" else "ALIKE-t") + " extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
                                    "(euclidean fp64, max_distance=5, cross_check), 640x480 pairs [BASELINE configs[1]]",
                        "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
-                       "weights": "alike-t (reference checkpoint, BN folded)", "parallelism": "pairs sharded, dp%d" % world,
+                       "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else "superpoint, seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
                         "pairs_gathered": int(allrows.shape[0])},

@@ -60,6 +60,7 @@ class ALNet:
         self._blob = None
         self._forward_count = 0
         self.training = False
+        self.dim, self.desc_div = self.param["dim"], 1
 
     # ---- torch.nn.Module surface used by model_interface.py:43-86
     def load_state_dict(self, state_dict, strict=True):

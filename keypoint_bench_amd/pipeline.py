@@ -26,11 +26,15 @@ class PairPipeline:
         self.dprm = DetectParams(int(ep["nms_dist"]), float(ep["threshold"]), int(ep["border_dist"]), self.top_k,
                                  float(ep["min_score"]))
         self.mprm = MatchParams(float(bf["max_distance"]), 1 if bf["cross_check"] else 0)
-        B2, K, C = 2 * self.B, self.top_k, net.param["dim"]
+        net._ensure(self.device)
+        self.dense = getattr(net, "dense_descriptors", True)
+        self.div = getattr(net, "desc_div", 1)
+        B2, K, C = 2 * self.B, self.top_k, (net.param["dim"] if hasattr(net, "param") else net.dim)
         dev = self.device
         f32, i32 = torch.float32, torch.int32
         self.score = torch.empty((B2, 1, H, W), dtype=f32, device=dev)
-        self.desc = torch.empty((B2, H, W, C), dtype=f32, device=dev) if net.dense_descriptors else None
+        self.Hd, self.Wd = H // self.div, W // self.div
+        self.desc = torch.empty((B2, self.Hd, self.Wd, C), dtype=f32, device=dev) if self.dense else None
         self.kps = torch.empty((B2, K, 3), dtype=f32, device=dev)
         self.idx = torch.empty((B2, K), dtype=i32, device=dev)
         self.n = torch.empty((B2,), dtype=i32, device=dev)
@@ -59,7 +63,8 @@ class PairPipeline:
         ctx, L, net = self.ctx, self.ctx.lib, self.net
         B, B2, K, C, H, W = self.B, 2 * self.B, self.top_k, self.C, self.H, self.W
         if self.desc is not None:   # utils/matcher.py:221-226 on the dense map (channels-last strides)
-            ctx.check(L.kpb_sample(ctx.handle, ptr(self.desc), B2, C, H, W, H * W * C, 1, W * C, C, ptr(self.kps), 3, K,
+            Hd, Wd = self.Hd, self.Wd
+            ctx.check(L.kpb_sample(ctx.handle, ptr(self.desc), B2, C, Hd, Wd, Hd * Wd * C, 1, Wd * C, C, ptr(self.kps), 3, K,
                                    ptr(self.n), ptr(self.sdesc)))
         else:
             ctx.check(L.kpb_net_desc_at(net._handle, ptr(self.kps), 3, K, ptr(self.n), ptr(self.sdesc)))
