@@ -225,6 +225,96 @@ __global__ __launch_bounds__(256) void l2norm_nhwc(float* desc, int C, size_t np
     for (int c = lane; c < C; c += 64) d[c] = __fdiv_rn(d[c], n);
 }
 
+// ------------------------------------------------------------------------------------------------ XFeat pieces
+// XFeat.py:121-123: x.mean(dim=1) then InstanceNorm2d(1): (x - mean) / sqrt(var + 1e-5), biased variance per image.
+__global__ __launch_bounds__(256) void gray_mean_stats(const float* img, float* gray, double* stats, size_t P)
+{
+    __shared__ double s1[4], s2[4];
+    const size_t b = blockIdx.y;
+    double a = 0.0, q = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)gridDim.x * 256) {
+        const float g = ((img[(b * 3 + 0) * P + i] + img[(b * 3 + 1) * P + i]) + img[(b * 3 + 2) * P + i]) / 3.0f;
+        gray[b * P + i] = g;
+        a += (double)g; q += (double)g * (double)g;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); q += __shfl_xor(q, o, 64); }
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[2 * b], s1[0] + s1[1] + s1[2] + s1[3]);
+        atomicAdd(&stats[2 * b + 1], s2[0] + s2[1] + s2[2] + s2[3]);
+    }
+}
+
+__global__ void instnorm_apply(float* gray, const double* stats, size_t P)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= P) return;
+    const double mean = stats[2 * b] / (double)P;
+    const double var = fmax(stats[2 * b + 1] / (double)P - mean * mean, 0.0);
+    gray[b * P + i] = (gray[b * P + i] - (float)mean) * (1.0f / sqrtf((float)var + 1e-5f));
+}
+
+// XFeat.py:27-28: skip1 = AvgPool2d(4) -> Conv2d(1, 24, 1); added to block1's output (XFeat.py:127): out += w*avg + b
+__global__ void skip_add(const float* gray, float* x1, const float* w, const float* bias, int H, int W)
+{
+    const int H4 = H / 4, W4 = W / 4;
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= H4 * W4) return;
+    const int y = i / W4, x = i - y * W4;
+    const float* g = gray + (size_t)b * H * W + (size_t)(4 * y) * W + 4 * x;
+    float sacc = 0.0f;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) sacc += g[(size_t)dy * W + dx];
+    const float avg = sacc * (1.0f / 16.0f);
+    float* o = x1 + ((size_t)b * H4 * W4 + i) * 24;
+#pragma unroll
+    for (int c = 0; c < 24; ++c) o[c] += fmaf(avg, w[c], bias[c]);
+}
+
+// XFeat.py:133-135: x3 + interpolate(x4, size(x3), bilinear) + interpolate(x5, ...) (align_corners=False), 64 channels
+__device__ __forceinline__ float4 bilerp4(const float* m, int Hs, int Ws, int Hd, int Wd, int y, int x, int c4)
+{
+    const float sy = (float)Hs / (float)Hd, sx = (float)Ws / (float)Wd;
+    const float fy = fmaxf(((float)y + 0.5f) * sy - 0.5f, 0.0f), fx = fmaxf(((float)x + 0.5f) * sx - 0.5f, 0.0f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float4 a = *reinterpret_cast<const float4*>(m + ((size_t)y0 * Ws + x0) * 64 + c4);
+    const float4 b = *reinterpret_cast<const float4*>(m + ((size_t)y0 * Ws + x1) * 64 + c4);
+    const float4 c = *reinterpret_cast<const float4*>(m + ((size_t)y1 * Ws + x0) * 64 + c4);
+    const float4 d = *reinterpret_cast<const float4*>(m + ((size_t)y1 * Ws + x1) * 64 + c4);
+    return make_float4(hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x), hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y),
+                       hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z), hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w));
+}
+
+__global__ void pyramid_sum(const float* x3, const float* x4, const float* x5, float* out, int H8, int W8, int H16, int W16, int H32, int W32)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= H8 * W8 * 16) return;
+    const int pix = i >> 4, c4 = (i & 15) * 4;
+    const int y = pix / W8, x = pix - y * W8;
+    const float4 a = *reinterpret_cast<const float4*>(x3 + ((size_t)b * H8 * W8 + pix) * 64 + c4);
+    const float4 u4 = bilerp4(x4 + (size_t)b * H16 * W16 * 64, H16, W16, H8, W8, y, x, c4);
+    const float4 u5 = bilerp4(x5 + (size_t)b * H32 * W32 * 64, H32, W32, H8, W8, y, x, c4);
+    *reinterpret_cast<float4*>(out + ((size_t)b * H8 * W8 + pix) * 64 + c4) =
+        make_float4((a.x + u4.x) + u5.x, (a.y + u4.y) + u5.y, (a.z + u4.z) + u5.z, (a.w + u4.w) + u5.w);
+}
+
+// XFeat.py:96-103 _unfold2d(x, ws=8): [B,1,H,W] -> [B,64,H/8,W/8], channel = wy*8 + wx (stored NHWC)
+__global__ void unfold8(const float* gray, float* out, int H, int W)
+{
+    const int Wc = W / 8, Hc = H / 8;
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= Hc * Wc * 64) return;
+    const int cell = i >> 6, c = i & 63;
+    const int cy = cell / Wc, cx = cell - cy * Wc;
+    out[((size_t)b * Hc * Wc + cell) * 64 + c] = gray[(size_t)b * H * W + (size_t)(cy * 8 + (c >> 3)) * W + cx * 8 + (c & 7)];
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 // OIHW [COUT][CIN][KS][KS] -> conv_mfma fragment order [ntile][tap][chunk][h][32][KC]
 std::vector<float> pack_mfma(const float* w, int COUT, int CIN, int KS, int CC)
@@ -388,8 +478,119 @@ int superpoint_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
     return KPB_OK;
 }
 
-int xfeat_create(kpb_ctx* ctx, const KpbwBlob&, kpb_net** out)
+namespace {
+
+struct XFeatPlan { const char* name; int cin, cout, ks, stride; bool relu; };
+// BasicLayer = conv(no bias) + BatchNorm(affine=False) + ReLU, folded at pack time (weights.py fold_xfeat)
+const XFeatPlan XF[] = {
+    {"block1.0", 1, 4, 3, 1, true}, {"block1.1", 4, 8, 3, 2, true}, {"block1.2", 8, 8, 3, 1, true}, {"block1.3", 8, 24, 3, 2, true},
+    {"block2.0", 24, 24, 3, 1, true}, {"block2.1", 24, 24, 3, 1, true},
+    {"block3.0", 24, 64, 3, 2, true}, {"block3.1", 64, 64, 3, 1, true}, {"block3.2", 64, 64, 1, 1, true},
+    {"block4.0", 64, 64, 3, 2, true}, {"block4.1", 64, 64, 3, 1, true}, {"block4.2", 64, 64, 3, 1, true},
+    {"block5.0", 64, 128, 3, 2, true}, {"block5.1", 128, 128, 3, 1, true}, {"block5.2", 128, 128, 3, 1, true}, {"block5.3", 128, 64, 1, 1, true},
+    {"block_fusion.0", 64, 64, 3, 1, true}, {"block_fusion.1", 64, 64, 3, 1, true}, {"block_fusion.2", 64, 64, 1, 1, false},
+    {"keypoint_head.0", 64, 64, 1, 1, true}, {"keypoint_head.1", 64, 64, 1, 1, true}, {"keypoint_head.2", 64, 64, 1, 1, true},
+    {"keypoint_head.3", 64, 65, 1, 1, false}};
+
+struct XFeatNet : kpb_net {
+    std::map<std::string, Layer> L;
+    std::map<std::string, bool> relu_of;
+    int conv(const char* n, const float* in, float* out, int batch, int Hi, int Wi)
+    {
+        const Layer& l = L.at(n);
+        const std::string tag = std::string("xf_") + n;
+        if (l.mfma) return launch_mfma(ctx, tag.c_str(), this, l, in, out, batch, Hi, Wi, false, false, relu_of.at(n));
+        return launch_valu(ctx, tag.c_str(), this, l, in, out, batch, Hi, Wi, relu_of.at(n));
+    }
+    int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
+    {
+        if ((H_ % 32) || (W_ % 32)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: XFeat needs H and W multiples of 32 (got %dx%d)", H_, W_);
+        if (!desc_out) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: XFeat writes its 64 x H/8 x W/8 feature map; desc_out_dev is required");
+        const int H = H_, W = W_;
+        const size_t P = (size_t)H * W, B = batch;
+        const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
+        // floats per image of each activation
+        const size_t n_gray = P, n_a = P * 4, n_b = P / 4 * 8, n_c = P / 4 * 8, n_x1 = P / 16 * 24, n_t = P / 16 * 24, n_x2 = P / 16 * 24,
+                     n_8 = P / 64 * 64, n_16 = P / 256 * 64, n_32a = P / 1024 * 128, n_semi = P / 64 * 65;
+        const size_t total = B * (n_gray + n_a + n_b + n_c + n_x1 + n_t + n_x2 + 6 * n_8 + 3 * n_16 + 3 * n_32a + n_semi) + 64;
+        if (int rc = kpb_reserve(ctx, act, total * sizeof(float) + 16 * B)) return rc;
+        float* p = static_cast<float*>(act.p);
+        double* stats = reinterpret_cast<double*>(p); p += 2 * ((2 * B + 1) / 2 * 2);     // 2 doubles per image
+        float* gray = p; p += B * n_gray;
+        float* a1 = p; p += B * n_a; float* b1 = p; p += B * n_b; float* c1 = p; p += B * n_c;
+        float* x1 = p; p += B * n_x1; float* t2 = p; p += B * n_t; float* x2 = p; p += B * n_x2;
+        float* u8[6]; for (auto& q : u8) { q = p; p += B * n_8; }
+        float* u16[3]; for (auto& q : u16) { q = p; p += B * n_16; }
+        float* u32[3]; for (auto& q : u32) { q = p; p += B * n_32a; }
+        float* semi = p; p += B * n_semi;
+        this->B = batch; this->H = H; this->W = W;
+        hipStream_t st = ctx->stream;
+        KPB_HIP(ctx, hipMemsetAsync(stats, 0, 2 * B * sizeof(double), st));
+        KPB_LAUNCH(ctx, "xf_gray_stats", gray_mean_stats, dim3(64, batch), dim3(256), 0, st, img, gray, stats, P);
+        KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
+        int rc;
+        // block1 (XFeat.py:30-35) and the skip connection (27-28, 127)
+        if ((rc = conv("block1.0", gray, a1, batch, H, W))) return rc;
+        if ((rc = conv("block1.1", a1, b1, batch, H, W))) return rc;
+        if ((rc = conv("block1.2", b1, c1, batch, H2, W2))) return rc;
+        if ((rc = conv("block1.3", c1, x1, batch, H2, W2))) return rc;
+        KPB_LAUNCH(ctx, "xf_skip_add", skip_add, dim3(cdiv(H4 * W4, 256), batch), dim3(256), 0, st, gray, x1, wp("skip1.w"), wp("skip1.b"), H, W);
+        if ((rc = conv("block2.0", x1, t2, batch, H4, W4))) return rc;
+        if ((rc = conv("block2.1", t2, x2, batch, H4, W4))) return rc;
+        if ((rc = conv("block3.0", x2, u8[0], batch, H4, W4))) return rc;
+        if ((rc = conv("block3.1", u8[0], u8[1], batch, H8, W8))) return rc;
+        if ((rc = conv("block3.2", u8[1], u8[2], batch, H8, W8))) return rc;          // x3
+        if ((rc = conv("block4.0", u8[2], u16[0], batch, H8, W8))) return rc;
+        if ((rc = conv("block4.1", u16[0], u16[1], batch, H16, W16))) return rc;
+        if ((rc = conv("block4.2", u16[1], u16[2], batch, H16, W16))) return rc;       // x4
+        if ((rc = conv("block5.0", u16[2], u32[0], batch, H16, W16))) return rc;
+        if ((rc = conv("block5.1", u32[0], u32[1], batch, H32, W32))) return rc;
+        if ((rc = conv("block5.2", u32[1], u32[2], batch, H32, W32))) return rc;
+        float* x5 = u32[0];                                                             // 64 channels reuse the 128-channel slot
+        if ((rc = conv("block5.3", u32[2], x5, batch, H32, W32))) return rc;
+        KPB_LAUNCH(ctx, "xf_pyramid_sum", pyramid_sum, dim3(cdiv(H8 * W8 * 16, 256), batch), dim3(256), 0, st, u8[2], u16[2], x5, u8[3],
+                   H8, W8, H16, W16, H32, W32);
+        if ((rc = conv("block_fusion.0", u8[3], u8[4], batch, H8, W8))) return rc;
+        if ((rc = conv("block_fusion.1", u8[4], u8[5], batch, H8, W8))) return rc;
+        if ((rc = conv("block_fusion.2", u8[5], desc_out, batch, H8, W8))) return rc;
+        KPB_LAUNCH(ctx, "xf_l2norm", l2norm_nhwc, dim3((unsigned)((B * H8 * W8 + 3) / 4)), dim3(256), 0, st, desc_out, 64, B * H8 * W8, 1e-12f);   // F.normalize
+        // keypoint head on the 8x8-unfolded normalised image (XFeat.py:138-139)
+        KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 64, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
+        if ((rc = conv("keypoint_head.0", u8[0], u8[1], batch, H8, W8))) return rc;
+        if ((rc = conv("keypoint_head.1", u8[1], u8[0], batch, H8, W8))) return rc;
+        if ((rc = conv("keypoint_head.2", u8[0], u8[1], batch, H8, W8))) return rc;
+        if ((rc = conv("keypoint_head.3", u8[1], semi, batch, H8, W8))) return rc;
+        KPB_LAUNCH(ctx, "xf_softmax_d2s", softmax65_d2s, dim3(cdiv(H8 * W8, 4), batch), dim3(256), 0, st, semi, score_out, H8, W8, H8 * W8);
+        KPB_HIP(ctx, hipGetLastError());
+        return KPB_OK;
+    }
+};
+
+}  // namespace
+
+int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
 {
-    *out = nullptr;
-    return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: XFeat kernels are not in this build yet");
+    XFeatNet* net = new XFeatNet();
+    net->ctx = ctx; net->arch = KPB_ARCH_XFEAT; net->dim = 64; net->desc_div = 8;
+    WeightStage ws;
+    for (const XFeatPlan& q : XF) {
+        Layer L{q.name, q.cin, q.cout, q.ks, q.stride, (q.cin % 32 == 0) && !(q.stride == 2 && q.cin % 16 != 0)};
+        const float* w = bl.get((L.name + ".w").c_str(), {(uint32_t)L.cout, (uint32_t)L.cin, (uint32_t)L.ks, (uint32_t)L.ks});
+        const float* b = bl.get((L.name + ".b").c_str(), {(uint32_t)L.cout});
+        if (!w || !b) {
+            delete net;
+            return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: XFeat tensor %s.w/.b missing or mis-shaped", L.name.c_str());
+        }
+        stage_layer(ws, L, w, b);
+        net->L[L.name] = L;
+        net->relu_of[L.name] = q.relu;
+    }
+    const float* sw = bl.get("skip1.w", {24});
+    const float* sb = bl.get("skip1.b", {24});
+    if (!sw || !sb) { delete net; return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: XFeat skip1 tensors missing"); }
+    ws.put_raw("skip1.w", sw, 24);
+    ws.put_raw("skip1.b", sb, 24);
+    if (int rc = ws.upload(net)) { delete net; return rc; }
+    *out = net;
+    return KPB_OK;
 }

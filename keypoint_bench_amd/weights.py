@@ -110,3 +110,53 @@ def random_superpoint(seed: int) -> dict:
         t[n + ".weight"] = rng.uniform(-bound, bound, size=(co, ci, k, k)).astype(np.float32)
         t[n + ".bias"] = rng.uniform(-0.05, 0.05, size=(co,)).astype(np.float32)
     return t
+
+
+XFEAT_BASIC = ("block1.0", "block1.1", "block1.2", "block1.3", "block2.0", "block2.1", "block3.0", "block3.1", "block3.2",
+               "block4.0", "block4.1", "block4.2", "block5.0", "block5.1", "block5.2", "block5.3",
+               "block_fusion.0", "block_fusion.1", "keypoint_head.0", "keypoint_head.1", "keypoint_head.2")
+XFEAT_SHAPES = {"block1.0": (4, 1, 3), "block1.1": (8, 4, 3), "block1.2": (8, 8, 3), "block1.3": (24, 8, 3),
+                "block2.0": (24, 24, 3), "block2.1": (24, 24, 3), "block3.0": (64, 24, 3), "block3.1": (64, 64, 3),
+                "block3.2": (64, 64, 1), "block4.0": (64, 64, 3), "block4.1": (64, 64, 3), "block4.2": (64, 64, 3),
+                "block5.0": (128, 64, 3), "block5.1": (128, 128, 3), "block5.2": (128, 128, 3), "block5.3": (64, 128, 1),
+                "block_fusion.0": (64, 64, 3), "block_fusion.1": (64, 64, 3), "keypoint_head.0": (64, 64, 1),
+                "keypoint_head.1": (64, 64, 1), "keypoint_head.2": (64, 64, 1)}
+
+
+def fold_xfeat(sd, eps=1e-5) -> dict:
+    """state_dict of XFeatModel (models/XFeat.py:22-94) -> folded tensors.  BasicLayer (XFeat.py:7-19) is
+    conv(bias=False) + BatchNorm2d(affine=False) + ReLU: w' = w / sqrt(var + eps), b' = -mean / sqrt(var + eps).
+    heatmap_head and fine_matcher are constructed by the reference but never used by forward (XFeat.py:112-140)."""
+    t = {}
+    for n in XFEAT_BASIC:
+        w = _np(sd[n + ".layer.0.weight"])
+        mu, var = _np(sd[n + ".layer.1.running_mean"]), _np(sd[n + ".layer.1.running_var"])
+        s = 1.0 / np.sqrt(var + eps)
+        t[n + ".w"] = (w * s[:, None, None, None]).astype(np.float32)
+        t[n + ".b"] = (-mu * s).astype(np.float32)
+    t["block_fusion.2.w"] = _np(sd["block_fusion.2.weight"]).astype(np.float32)
+    t["block_fusion.2.b"] = _np(sd["block_fusion.2.bias"]).astype(np.float32)
+    t["keypoint_head.3.w"] = _np(sd["keypoint_head.3.weight"]).astype(np.float32)
+    t["keypoint_head.3.b"] = _np(sd["keypoint_head.3.bias"]).astype(np.float32)
+    t["skip1.w"] = _np(sd["skip1.1.weight"]).astype(np.float32).reshape(24)
+    t["skip1.b"] = _np(sd["skip1.1.bias"]).astype(np.float32)
+    return t
+
+
+def random_xfeat_state_dict(seed: int) -> dict:
+    """Seeded stand-in for the absent xfeat.pt: the state_dict entries XFeatModel.forward reads."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for n in XFEAT_BASIC:
+        co, ci, k = XFEAT_SHAPES[n]
+        bound = np.sqrt(6.0 / (ci * k * k))
+        sd[n + ".layer.0.weight"] = rng.uniform(-bound, bound, size=(co, ci, k, k)).astype(np.float32)
+        sd[n + ".layer.1.running_mean"] = rng.normal(0.0, 0.1, size=(co,)).astype(np.float32)
+        sd[n + ".layer.1.running_var"] = rng.uniform(0.5, 1.5, size=(co,)).astype(np.float32)
+    for n, (co, ci) in (("block_fusion.2", (64, 64)), ("keypoint_head.3", (65, 64))):
+        bound = np.sqrt(6.0 / ci)
+        sd[n + ".weight"] = rng.uniform(-bound, bound, size=(co, ci, 1, 1)).astype(np.float32)
+        sd[n + ".bias"] = rng.uniform(-0.05, 0.05, size=(co,)).astype(np.float32)
+    sd["skip1.1.weight"] = rng.uniform(-1, 1, size=(24, 1, 1, 1)).astype(np.float32)
+    sd["skip1.1.bias"] = rng.uniform(-0.05, 0.05, size=(24,)).astype(np.float32)
+    return sd

@@ -53,6 +53,22 @@ def main():
             out["sp.%s.heat" % tag] = heat[0, 0].numpy()
             out["sp.%s.desc" % tag] = desc[0].numpy() if tag == "small" else desc[0, :, ::4, ::4].numpy()
             print("  superpoint", tag, tuple(heat.shape), tuple(desc.shape), float(heat.min()), float(heat.max()))
+    xf = _load("ref_xfeat", os.path.join(REF, "models", "XFeat.py"))
+    net = xf.XFeatModel()
+    sd = weights.random_xfeat_state_dict(9)
+    r = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    used = [k for k in r.missing_keys if not (k.startswith("heatmap_head") or k.startswith("fine_matcher") or k.endswith("num_batches_tracked"))]
+    print("  xfeat load_state_dict: unexpected", r.unexpected_keys, "missing (used by forward):", used)
+    assert not r.unexpected_keys and not used
+    net.eval()
+    out["xf.seed"] = np.array(9)
+    with torch.no_grad():
+        for tag, (H, W) in (("small", (64, 96)), ("full", (480, 640))):
+            v0, _ = synthetic.image_pair(0, H, W)
+            heat, feats = net(torch.from_numpy(v0)[None])
+            out["xf.%s.heat" % tag] = heat[0, 0].numpy()
+            out["xf.%s.desc" % tag] = feats[0].numpy() if tag == "small" else feats[0, :, ::4, ::4].numpy()
+            print("  xfeat", tag, tuple(heat.shape), tuple(feats.shape), float(heat.min()), float(heat.max()))
     np.savez_compressed(os.path.join(HERE, "nets.npz"), **out)
     return 0
 

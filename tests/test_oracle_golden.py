@@ -151,3 +151,15 @@ def test_superpoint_restatement_matches_reference_forward():
         heat, desc = superpoint_ref.superpoint_forward(torch.from_numpy(v0)[None], t)
     np.testing.assert_allclose(heat[0, 0].numpy(), g["sp.small.heat"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(desc[0].numpy(), g["sp.small.desc"], rtol=0, atol=1e-5)
+
+
+def test_xfeat_restatement_matches_reference_forward():
+    import torch
+    from oracle import xfeat_ref
+    g = load_golden("nets.npz")
+    t = {k: torch.from_numpy(v) for k, v in weights.fold_xfeat(weights.random_xfeat_state_dict(int(g["xf.seed"]))).items()}
+    v0, _ = synthetic.image_pair(0, 64, 96)
+    with torch.no_grad():
+        heat, feats = xfeat_ref.xfeat_forward(torch.from_numpy(v0)[None], t)
+    np.testing.assert_allclose(heat[0, 0].numpy(), g["xf.small.heat"], rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(feats[0].numpy(), g["xf.small.desc"], rtol=0, atol=2e-5)
