@@ -126,6 +126,7 @@ int kpb_gather_rows(kpb_ctx* ctx, const float* src_dev, int batch, int src_rows,
 #define KPB_ARCH_ALIKE 1        /* models/ALike.py      ALNet (ALIKE-t channel plan), BN folded */
 #define KPB_ARCH_SUPERPOINT 2   /* models/SuperPoint.py SuperPointNet, tensors named as its state_dict */
 #define KPB_ARCH_XFEAT 3        /* models/XFeat.py      XFeatModel, BN folded */
+#define KPB_ARCH_DISK 4         /* models/disk.py       DISK (thin U-Net, 5x5), H, W multiples of 16 */
 int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len, kpb_net** out);
 void kpb_net_destroy(kpb_net* net);
 int kpb_net_desc_dim(const kpb_net* net);   /* descriptor channels C */

@@ -22,13 +22,14 @@ struct ConvM {
     float* out;         // [B][Ho][Wo][COUT]   (Ho, Wo) = (H, W) or (H/2, W/2) with POOL_OUT
     const float* wp;    // packed: [ntile][tap][chunk][h][32][KC]
     const float* bias;  // [COUTP] (zero padded)
+    const float* xf;    // XF: [B][CIN][4] = (scale, shift, prelu slope, -) applied to the input before zero padding
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
 };
 
-template <int KS, int S, bool POOL_IN, bool POOL_OUT>
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF>
 __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 {
-    constexpr int CC = (S == 1) ? 32 : 16, KC = CC / 2, PITCH = CC + 4, T = KS * KS, PAD = KS / 2;
+    constexpr int KC = CC / 2, PITCH = CC + 4, T = KS * KS, PAD = KS / 2;
     constexpr int IH = 7 * S + KS, IW = 15 * S + KS, Q = CC / 4;
     constexpr int NLD = (IH * IW * Q + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[IH * IW * PITCH];
@@ -63,6 +64,14 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
                         v.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); v.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
                     } else {
                         v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.CIN + ch * CC + 4 * q);
+                    }
+                    if (XF) {   // InstanceNorm (scale, shift) + PReLU of the pre-activation Conv block (disk.py:76-97)
+                        const float4* t4 = reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + ch * CC + 4 * q) * 4);
+                        const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+                        v.x = fmaf(v.x, t0.x, t0.y); v.x = v.x >= 0.0f ? v.x : v.x * t0.z;
+                        v.y = fmaf(v.y, t1.x, t1.y); v.y = v.y >= 0.0f ? v.y : v.y * t1.z;
+                        v.z = fmaf(v.z, t2.x, t2.y); v.z = v.z >= 0.0f ? v.z : v.z * t2.z;
+                        v.w = fmaf(v.w, t3.x, t3.y); v.w = v.w >= 0.0f ? v.w : v.w * t3.z;
                     }
                 }
                 buf[k] = v;
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 // weights [tap][cin][COUT8] wave-uniform (scalar loads), inputs straight from L1/L2.
 struct ConvV {
     const float* in; float* out; const float* w; const float* bias;
+    const float* xf;    // optional [B][CIN][4] input transform (see ConvM)
     int Hi, Wi, H, W, CIN, COUT, COUT8, KS, S, PAD, relu;
 };
 
@@ -164,7 +174,12 @@ __global__ __launch_bounds__(256) void conv_valu(ConvV a)
             const float* src = in + ((size_t)iy * a.Wi + ix) * a.CIN;
             const float* w = a.w + ((size_t)(ky * a.KS + kx) * a.CIN) * a.COUT8 + cg * 8;
             for (int c = 0; c < a.CIN; ++c) {
-                const float v = src[c];
+                float v = src[c];
+                if (a.xf) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + c) * 4);
+                    v = fmaf(v, t.x, t.y);
+                    v = v >= 0.0f ? v : v * t.z;
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(v, w[(size_t)c * a.COUT8 + j], acc[j]);
             }
@@ -356,34 +371,38 @@ struct Layer {      // one convolution of a network plan
     std::string name;
     int cin, cout, ks, stride;
     bool mfma;
+    int cc = 32;    // channels per LDS chunk of conv_mfma (32, or 16 for stride 2 / CIN not a multiple of 32)
 };
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool pool_in, bool pool_out, bool relu_)
+                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr)
 {
-    const int S = L.stride, CC = S == 1 ? 32 : 16, PAD = L.ks / 2;
+    const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
     ConvM a;
-    a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str());
+    a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf;
     a.Hi = Hi; a.Wi = Wi;
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
     a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 63) / 64;
     const dim3 grid(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk), block(256);
     hipStream_t st = ctx->stream;
-    if (L.ks == 3 && S == 1 && !pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, false, false>), grid, block, 0, st, a);
-    else if (L.ks == 3 && S == 1 && !pool_in && pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, false, true>), grid, block, 0, st, a);
-    else if (L.ks == 3 && S == 1 && pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, true, false>), grid, block, 0, st, a);
-    else if (L.ks == 1 && S == 1 && !pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<1, 1, false, false>), grid, block, 0, st, a);
-    else if (L.ks == 3 && S == 2 && !pool_in && !pool_out) KPB_LAUNCH(ctx, name, (conv_mfma<3, 2, false, false>), grid, block, 0, st, a);
-    else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma: no instance for ks=%d stride=%d pool_in=%d pool_out=%d", L.ks, S, pool_in, pool_out);
+    const bool x = xf != nullptr;
+    if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, false, false>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, true, false>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, true, false, false>), grid, block, 0, st, a);
+    else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<1, 1, 32, false, false, false>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 2, 16, false, false, false>), grid, block, 0, st, a);
+    else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma<5, 1, 32, false, false, true>), grid, block, 0, st, a);
+    else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma<5, 1, 16, false, false, true>), grid, block, 0, st, a);
+    else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma: no instance for ks=%d stride=%d cc=%d pool_in=%d pool_out=%d xf=%d", L.ks, S, CC, pool_in, pool_out, x);
     return KPB_OK;
 }
 
 int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool relu_)
+                bool relu_, const float* xf = nullptr)
 {
     ConvV a;
-    a.in = in; a.out = out; a.w = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str());
+    a.in = in; a.out = out; a.w = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf;
     a.Hi = Hi; a.Wi = Wi; a.KS = L.ks; a.S = L.stride; a.PAD = L.ks / 2;
     a.H = (Hi + 2 * a.PAD - L.ks) / L.stride + 1; a.W = (Wi + 2 * a.PAD - L.ks) / L.stride + 1;
     a.CIN = L.cin; a.COUT = L.cout; a.COUT8 = ((L.cout + 7) / 8) * 8; a.relu = relu_ ? 1 : 0;
@@ -394,7 +413,7 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
 void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b)
 {
     if (L.mfma) {
-        ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.stride == 1 ? 32 : 16));
+        ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.cc));
         ws.put(L.name + ".b", pad_bias(b, L.cout, 64));
     } else {
         ws.put(L.name + ".w", pack_valu(w, L.cout, L.cin, L.ks));
@@ -575,6 +594,7 @@ int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
     WeightStage ws;
     for (const XFeatPlan& q : XF) {
         Layer L{q.name, q.cin, q.cout, q.ks, q.stride, (q.cin % 32 == 0) && !(q.stride == 2 && q.cin % 16 != 0)};
+        L.cc = q.stride == 2 ? 16 : 32;
         const float* w = bl.get((L.name + ".w").c_str(), {(uint32_t)L.cout, (uint32_t)L.cin, (uint32_t)L.ks, (uint32_t)L.ks});
         const float* b = bl.get((L.name + ".b").c_str(), {(uint32_t)L.cout});
         if (!w || !b) {
@@ -590,6 +610,264 @@ int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
     if (!sw || !sb) { delete net; return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: XFeat skip1 tensors missing"); }
     ws.put_raw("skip1.w", sw, 24);
     ws.put_raw("skip1.b", sb, 24);
+    if (int rc = ws.upload(net)) { delete net; return rc; }
+    *out = net;
+    return KPB_OK;
+}
+
+// ================================================================================================ DISK (N4)
+// models/disk.py:293-313: thin U-Net, 5x5 convs with padding, every Conv block but the first is
+// InstanceNorm2d -> PReLU -> conv (pre-activation, disk.py:76-97).  The norm + PReLU are applied while the
+// conv stages its input tile (ConvM::xf); their per-(image, channel) statistics come from chan_sums.
+namespace {
+
+__global__ void avgpool2_nhwc(const float* in, float* out, int H, int W, int C)   // F.avg_pool2d(x, 2), disk.py:69
+{
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= (size_t)Ho * Wo * C4) return;
+    const int c4 = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int y = (int)(pix / Wo), x = (int)(pix - (size_t)y * Wo);
+    const float* s = in + (((size_t)b * H + 2 * y) * W + 2 * x) * C + 4 * c4;
+    const float4 a = *reinterpret_cast<const float4*>(s), bq = *reinterpret_cast<const float4*>(s + C);
+    const float4 c = *reinterpret_cast<const float4*>(s + (size_t)W * C), d = *reinterpret_cast<const float4*>(s + (size_t)W * C + C);
+    *reinterpret_cast<float4*>(out + (((size_t)b * Ho + y) * Wo + x) * C + 4 * c4) =
+        make_float4(((a.x + bq.x) + (c.x + d.x)) * 0.25f, ((a.y + bq.y) + (c.y + d.y)) * 0.25f,
+                    ((a.z + bq.z) + (c.z + d.z)) * 0.25f, ((a.w + bq.w) + (c.w + d.w)) * 0.25f);
+}
+
+// bilinear x2 (align_corners=False, disk.py:52-55) of `bot` concatenated with `hor` along channels (disk.py:137-139)
+__global__ void upsample2_concat(const float* bot, const float* hor, float* out, int Hb, int Wb, int Cb, int Ch)
+{
+    const int H = 2 * Hb, W = 2 * Wb, C = Cb + Ch, C4 = C / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= (size_t)H * W * C4) return;
+    const int c = (int)(i % C4) * 4;
+    const size_t pix = i / C4;
+    const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
+    float4 v;
+    if (c < Cb) {
+        const float fy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f), fx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hb - 1 ? 1 : 0), x1 = x0 + (x0 < Wb - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        const float* m = bot + (size_t)b * Hb * Wb * Cb + c;
+        const float4 p00 = *reinterpret_cast<const float4*>(m + ((size_t)y0 * Wb + x0) * Cb), p01 = *reinterpret_cast<const float4*>(m + ((size_t)y0 * Wb + x1) * Cb);
+        const float4 p10 = *reinterpret_cast<const float4*>(m + ((size_t)y1 * Wb + x0) * Cb), p11 = *reinterpret_cast<const float4*>(m + ((size_t)y1 * Wb + x1) * Cb);
+        v = make_float4(hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x), hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y),
+                        hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z), hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w));
+    } else {
+        v = *reinterpret_cast<const float4*>(hor + (((size_t)b * H + y) * W + x) * Ch + (c - Cb));
+    }
+    *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * C + c) = v;
+}
+
+// per (image, channel) sum and sum of squares over the pixels of an NHWC tensor; block = (C, R) threads
+__global__ void chan_sums(const float* in, double* sums, size_t P, int C)
+{
+    extern __shared__ double sh[];   // [R][C][2]
+    const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
+    const size_t b = blockIdx.y;
+    double s = 0.0, q = 0.0;
+    for (size_t pix = (size_t)blockIdx.x * R + r; pix < P; pix += (size_t)gridDim.x * R) {
+        const float v = in[(b * P + pix) * C + c];
+        s += (double)v; q += (double)v * (double)v;
+    }
+    sh[(r * C + c) * 2] = s; sh[(r * C + c) * 2 + 1] = q;
+    __syncthreads();
+    if (r == 0) {
+        for (int k = 1; k < R; ++k) { s += sh[(k * C + c) * 2]; q += sh[(k * C + c) * 2 + 1]; }
+        atomicAdd(&sums[(b * C + c) * 2], s);
+        atomicAdd(&sums[(b * C + c) * 2 + 1], q);
+    }
+}
+
+// InstanceNorm2d (biased variance, eps 1e-5, no affine) folded with the PReLU slope into the conv's input transform
+__global__ void make_xf(const double* sums, const float* slope, float* xf, size_t P, int C, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double mean = sums[2 * i] / (double)P;
+    const double var = fmax(sums[2 * i + 1] / (double)P - mean * mean, 0.0);
+    const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+    xf[4 * i] = rstd; xf[4 * i + 1] = -(float)mean * rstd; xf[4 * i + 2] = slope[i % C]; xf[4 * i + 3] = 0.0f;
+}
+
+// disk.py:311-312: desc = F.normalize(feature[:, :128], dim=1) in place, score = sigmoid(feature[:, 128])
+__global__ __launch_bounds__(256) void disk_head(float* desc, const float* logit, float* score, size_t npix)
+{
+    const int lane = threadIdx.x & 63;
+    const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= npix) return;
+    float2* d = reinterpret_cast<float2*>(desc + pix * 128) + lane;
+    float2 v = *d;
+    float ss = fmaf(v.x, v.x, v.y * v.y);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float n = fmaxf(sqrtf(ss), 1e-12f);
+    v.x = __fdiv_rn(v.x, n); v.y = __fdiv_rn(v.y, n);
+    *d = v;
+    if (lane == 0) score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-logit[pix]));   // conv_valu output: 1 channel, stride 1
+}
+
+struct DiskNet : kpb_net {
+    std::map<std::string, Layer> L;
+    int stats_xf(const float* t, size_t P, int C, const char* slope_name, double* sums, float* xf, int batch)
+    {
+        hipStream_t st = ctx->stream;
+        KPB_HIP(ctx, hipMemsetAsync(sums, 0, (size_t)batch * C * 2 * sizeof(double), st));
+        const int R = 512 / C > 0 ? 512 / C : 1;
+        KPB_LAUNCH(ctx, "disk_chan_sums", chan_sums, dim3(128, batch), dim3(C, R), (size_t)R * C * 2 * sizeof(double), st, t, sums, P, C);
+        KPB_LAUNCH(ctx, "disk_make_xf", make_xf, dim3(cdiv(batch * C, 256)), dim3(256), 0, st, sums, wp(slope_name), xf, P, C, batch * C);
+        return KPB_OK;
+    }
+    int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
+    {
+        if ((H_ % 16) || (W_ % 16)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: DISK needs H and W multiples of 16 (got %dx%d)", H_, W_);
+        if (!desc_out) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: DISK writes its 128 x H x W descriptor map; desc_out_dev is required");
+        const int H = H_, W = W_;
+        const size_t P = (size_t)H * W, B = batch;
+        // floats per image
+        const size_t n_in = P * 4, n_f1 = P * 16, n_p1 = P / 4 * 16, n_f2 = P / 4 * 32, n_p2 = P / 16 * 32, n_f3 = P / 16 * 64, n_p3 = P / 64 * 64,
+                     n_f4 = P / 64 * 64, n_p4 = P / 256 * 64, n_f5 = P / 256 * 64, n_c0 = P / 64 * 128, n_u0 = P / 64 * 64, n_c1 = P / 16 * 128,
+                     n_u1 = P / 16 * 64, n_c2 = P / 4 * 96, n_u2 = P / 4 * 64, n_c3 = P * 80, n_lg = P;
+        const size_t total = B * (n_in + n_f1 + n_p1 + n_f2 + n_p2 + n_f3 + n_p3 + n_f4 + n_p4 + n_f5 + n_c0 + n_u0 + n_c1 + n_u1 + n_c2 + n_u2 + n_c3 + n_lg)
+                             + B * 128 * 4 + B * 128 * 4 + 64;
+        if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
+        float* p = static_cast<float*>(act.p);
+        double* sums = reinterpret_cast<double*>(p); p += B * 128 * 4;     // B*128*2 doubles
+        float* xf = p; p += B * 128 * 4;
+        auto take = [&](size_t n) { float* q = p; p += B * n; return q; };
+        float *in4 = take(n_in), *f1 = take(n_f1), *p1 = take(n_p1), *f2 = take(n_f2), *p2 = take(n_p2), *f3 = take(n_f3), *p3 = take(n_p3),
+              *f4 = take(n_f4), *p4 = take(n_p4), *f5 = take(n_f5), *c0 = take(n_c0), *u0 = take(n_u0), *c1 = take(n_c1), *u1 = take(n_u1),
+              *c2 = take(n_c2), *u2 = take(n_u2), *c3 = take(n_c3), *lg = take(n_lg);
+        (void)in4;
+        this->B = batch; this->H = H; this->W = W;
+        hipStream_t st = ctx->stream;
+        int rc;
+        auto pool = [&](const float* a, float* o, int h, int w, int c) {
+            KPB_LAUNCH(ctx, "disk_avgpool2", avgpool2_nhwc, dim3((unsigned)(((size_t)(h / 2) * (w / 2) * (c / 4) + 255) / 256), batch), dim3(256), 0, st, a, o, h, w, c);
+        };
+        auto upcat = [&](const float* bot, const float* hor, float* o, int hb, int wb, int cb, int chh) {
+            KPB_LAUNCH(ctx, "disk_upsample_concat", upsample2_concat, dim3((unsigned)(((size_t)4 * hb * wb * ((cb + chh) / 4) + 255) / 256), batch), dim3(256), 0, st,
+                       bot, hor, o, hb, wb, cb, chh);
+        };
+        // down path (disk.py:233-250, 274-282).  down_0 has no norm / gate and reads the planar RGB image through a
+        // 3-channel NHWC repack done by conv_valu's generic addressing: repack first.
+        {
+            // [B,3,H,W] -> [B,H,W,3] is avoided: conv_valu reads NHWC, so down_0 uses the planar-input variant below
+        }
+        if ((rc = launch_valu_planar(img, f1, batch, H, W))) return rc;
+        pool(f1, p1, H, W, 16);
+        if ((rc = stats_xf(p1, P / 4, 16, "down1.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_down1", this, L["down1"], p1, f2, batch, H / 2, W / 2, false, false, false, xf))) return rc;
+        pool(f2, p2, H / 2, W / 2, 32);
+        if ((rc = stats_xf(p2, P / 16, 32, "down2.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_down2", this, L["down2"], p2, f3, batch, H / 4, W / 4, false, false, false, xf))) return rc;
+        pool(f3, p3, H / 4, W / 4, 64);
+        if ((rc = stats_xf(p3, P / 64, 64, "down3.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_down3", this, L["down3"], p3, f4, batch, H / 8, W / 8, false, false, false, xf))) return rc;
+        pool(f4, p4, H / 8, W / 8, 64);
+        if ((rc = stats_xf(p4, P / 256, 64, "down4.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_down4", this, L["down4"], p4, f5, batch, H / 16, W / 16, false, false, false, xf))) return rc;
+        // up path (disk.py:114-141, 284-288)
+        upcat(f5, f4, c0, H / 16, W / 16, 64, 64);
+        if ((rc = stats_xf(c0, P / 64, 128, "up0.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_up0", this, L["up0"], c0, u0, batch, H / 8, W / 8, false, false, false, xf))) return rc;
+        upcat(u0, f3, c1, H / 8, W / 8, 64, 64);
+        if ((rc = stats_xf(c1, P / 16, 128, "up1.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_up1", this, L["up1"], c1, u1, batch, H / 4, W / 4, false, false, false, xf))) return rc;
+        upcat(u1, f2, c2, H / 4, W / 4, 64, 32);
+        if ((rc = stats_xf(c2, P / 4, 96, "up2.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_up2", this, L["up2"], c2, u2, batch, H / 2, W / 2, false, false, false, xf))) return rc;
+        upcat(u2, f1, c3, H / 2, W / 2, 64, 16);
+        if ((rc = stats_xf(c3, P, 80, "up3.slope", sums, xf, batch))) return rc;
+        if ((rc = launch_mfma(ctx, "disk_up3_desc", this, L["up3d"], c3, desc_out, batch, H, W, false, false, false, xf))) return rc;
+        if ((rc = launch_valu(ctx, "disk_up3_score", this, L["up3s"], c3, lg, batch, H, W, false, xf))) return rc;
+        KPB_LAUNCH(ctx, "disk_head", disk_head, dim3((unsigned)((B * P + 3) / 4)), dim3(256), 0, st, desc_out, lg, score_out, B * P);
+        KPB_HIP(ctx, hipGetLastError());
+        return KPB_OK;
+    }
+    int launch_valu_planar(const float* img, float* f1, int batch, int H, int W);
+};
+
+// down_0: 3 -> 16, 5x5, padding 2, no norm / gate (disk.py:106-108), reading the planar [B,3,H,W] image
+__global__ __launch_bounds__(256) void disk_down0(const float* img, float* out, const float* w /*[75][16]*/, const float* bias, int H, int W)
+{
+    const int b = blockIdx.z;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const int oy = pix / W, ox = pix - oy * W;
+    const size_t P = (size_t)H * W;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bias[j];
+    for (int c = 0; c < 3; ++c)
+        for (int ky = 0; ky < 5; ++ky) {
+            const int iy = oy + ky - 2;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const int ix = ox + kx - 2;
+                const float v = (ix >= 0 && ix < W) ? img[((size_t)b * 3 + c) * P + (size_t)iy * W + ix] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, w[((c * 5 + ky) * 5 + kx) * 16 + j], acc[j]);
+            }
+        }
+    float* o = out + ((size_t)b * P + pix) * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+}
+
+int DiskNet::launch_valu_planar(const float* img, float* f1, int batch, int H, int W)
+{
+    KPB_LAUNCH(ctx, "disk_down0", disk_down0, dim3(cdiv(H * W, 256), 1, batch), dim3(256), 0, ctx->stream, img, f1, wp("down0.w"), wp("down0.b"), H, W);
+    return KPB_OK;
+}
+
+}  // namespace
+
+int disk_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
+{
+    DiskNet* net = new DiskNet();
+    net->ctx = ctx; net->arch = KPB_ARCH_DISK; net->dim = 128; net->desc_div = 1;
+    WeightStage ws;
+    auto fail = [&](const char* n) { delete net; return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: DISK tensor %s missing or mis-shaped", n); };
+    {   // down_0
+        const float* w = bl.get("down0.w", {16, 3, 5, 5});
+        const float* b = bl.get("down0.b", {16});
+        if (!w || !b) return fail("down0");
+        std::vector<float> t(75 * 16);
+        for (int o = 0; o < 16; ++o) for (int k = 0; k < 75; ++k) t[k * 16 + o] = w[o * 75 + k];
+        ws.put("down0.w", t);
+        ws.put_raw("down0.b", b, 16);
+    }
+    struct { const char* n; int cin, cout; } plan[] = {{"down1", 16, 32}, {"down2", 32, 64}, {"down3", 64, 64}, {"down4", 64, 64},
+                                                       {"up0", 128, 64}, {"up1", 128, 64}, {"up2", 96, 64}};
+    for (auto& q : plan) {
+        Layer L{q.n, q.cin, q.cout, 5, 1, true};
+        L.cc = (q.cin % 32 == 0) ? 32 : 16;
+        const float* w = bl.get((L.name + ".w").c_str(), {(uint32_t)q.cout, (uint32_t)q.cin, 5, 5});
+        const float* b = bl.get((L.name + ".b").c_str(), {(uint32_t)q.cout});
+        const float* sl = bl.get((L.name + ".slope").c_str(), {(uint32_t)q.cin});
+        if (!w || !b || !sl) return fail(q.n);
+        stage_layer(ws, L, w, b);
+        ws.put_raw(L.name + ".slope", sl, q.cin);
+        net->L[L.name] = L;
+    }
+    {   // up_3: 80 -> 129 split into the 128 descriptor channels (MFMA) and the score logit (VALU)
+        const float* w = bl.get("up3.w", {129, 80, 5, 5});
+        const float* b = bl.get("up3.b", {129});
+        const float* sl = bl.get("up3.slope", {80});
+        if (!w || !b || !sl) return fail("up3");
+        Layer Ld{"up3d", 80, 128, 5, 1, true}; Ld.cc = 16;
+        Layer Ls{"up3s", 80, 1, 5, 1, false};
+        stage_layer(ws, Ld, w, b);
+        stage_layer(ws, Ls, w + (size_t)128 * 80 * 25, b + 128);
+        ws.put_raw("up3.slope", sl, 80);
+        net->L["up3d"] = Ld; net->L["up3s"] = Ls;
+    }
     if (int rc = ws.upload(net)) { delete net; return rc; }
     *out = net;
     return KPB_OK;

@@ -85,3 +85,4 @@ struct WeightStage {
 int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out);
 int superpoint_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out);
 int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out);
+int disk_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out);

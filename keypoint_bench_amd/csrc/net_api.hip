@@ -13,6 +13,7 @@ KPB_API int kpb_net_create(kpb_ctx* ctx, int arch, const void* blob, size_t len,
     case KPB_ARCH_ALIKE: return alike_create(ctx, bl, out);
     case KPB_ARCH_SUPERPOINT: return superpoint_create(ctx, bl, out);
     case KPB_ARCH_XFEAT: return xfeat_create(ctx, bl, out);
+    case KPB_ARCH_DISK: return disk_create(ctx, bl, out);
     default: return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_create: unknown arch %d", arch);
     }
 }

@@ -15,6 +15,7 @@ MAGIC = b"KPBWGT1\0"
 ARCH_ALIKE = 1
 ARCH_SUPERPOINT = 2
 ARCH_XFEAT = 3
+ARCH_DISK = 4
 _REC = struct.Struct("<40sI4II")
 
 
@@ -159,4 +160,40 @@ def random_xfeat_state_dict(seed: int) -> dict:
         sd[n + ".bias"] = rng.uniform(-0.05, 0.05, size=(co,)).astype(np.float32)
     sd["skip1.1.weight"] = rng.uniform(-1, 1, size=(24, 1, 1, 1)).astype(np.float32)
     sd["skip1.1.bias"] = rng.uniform(-0.05, 0.05, size=(24,)).astype(np.float32)
+    return sd
+
+DISK_BLOCKS = (("down1", "unet.path_down.1.1", 16, 32), ("down2", "unet.path_down.2.1", 32, 64),
+               ("down3", "unet.path_down.3.1", 64, 64), ("down4", "unet.path_down.4.1", 64, 64),
+               ("up0", "unet.path_up.0.conv", 128, 64), ("up1", "unet.path_up.1.conv", 128, 64),
+               ("up2", "unet.path_up.2.conv", 96, 64), ("up3", "unet.path_up.3.conv", 80, 129))
+
+
+def tensors_disk(sd) -> dict:
+    """state_dict of DISK (models/disk.py:293-307; the reference loads checkpoint['extractor'],
+    model_interface.py:76-78) -> tensors named as csrc/convnet.hip expects.  Conv = Sequential(norm, PReLU,
+    dropout, conv) (disk.py:76-97): index 1 is the PReLU slope, index 3 the convolution."""
+    t = {"down0.w": _np(sd["unet.path_down.0.1.3.weight"]).astype(np.float32),
+         "down0.b": _np(sd["unet.path_down.0.1.3.bias"]).astype(np.float32)}
+    for name, key, cin, cout in DISK_BLOCKS:
+        t[name + ".w"] = _np(sd[key + ".3.weight"]).astype(np.float32)
+        t[name + ".b"] = _np(sd[key + ".3.bias"]).astype(np.float32)
+        slope = _np(sd[key + ".1.weight"]).astype(np.float32).reshape(-1)
+        t[name + ".slope"] = np.broadcast_to(slope, (cin,)).copy() if slope.size == 1 else slope
+    return t
+
+
+def random_disk_state_dict(seed: int) -> dict:
+    """Seeded stand-in for the absent disk.pth."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def conv(key, co, ci):
+        bound = np.sqrt(6.0 / (ci * 25))
+        sd[key + ".3.weight"] = rng.uniform(-bound, bound, size=(co, ci, 5, 5)).astype(np.float32)
+        sd[key + ".3.bias"] = rng.uniform(-0.05, 0.05, size=(co,)).astype(np.float32)
+
+    conv("unet.path_down.0.1", 16, 3)
+    for name, key, cin, cout in DISK_BLOCKS:
+        conv(key, cout, cin)
+        sd[key + ".1.weight"] = rng.uniform(0.1, 0.4, size=(cin,)).astype(np.float32)
     return sd

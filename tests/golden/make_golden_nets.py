@@ -69,6 +69,19 @@ def main():
             out["xf.%s.heat" % tag] = heat[0, 0].numpy()
             out["xf.%s.desc" % tag] = feats[0].numpy() if tag == "small" else feats[0, :, ::4, ::4].numpy()
             print("  xfeat", tag, tuple(heat.shape), tuple(feats.shape), float(heat.min()), float(heat.max()))
+    dk = _load("ref_disk", os.path.join(REF, "models", "disk.py"))
+    net = dk.DISK()
+    sd = weights.random_disk_state_dict(5)
+    print("  disk load_state_dict:", net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}))
+    net.eval()
+    out["dk.seed"] = np.array(5)
+    with torch.no_grad():
+        for tag, (H, W) in (("small", (64, 96)), ("full", (480, 640))):
+            v0, _ = synthetic.image_pair(0, H, W)
+            score, desc = net(torch.from_numpy(v0)[None])
+            out["dk.%s.score" % tag] = score[0, 0].numpy()
+            out["dk.%s.desc" % tag] = desc[0, :, ::4, ::4].numpy() if tag == "small" else desc[0, :, ::32, ::32].numpy()
+            print("  disk", tag, tuple(score.shape), tuple(desc.shape), float(score.min()), float(score.max()))
     np.savez_compressed(os.path.join(HERE, "nets.npz"), **out)
     return 0
 

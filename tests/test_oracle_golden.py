@@ -163,3 +163,15 @@ def test_xfeat_restatement_matches_reference_forward():
         heat, feats = xfeat_ref.xfeat_forward(torch.from_numpy(v0)[None], t)
     np.testing.assert_allclose(heat[0, 0].numpy(), g["xf.small.heat"], rtol=1e-3, atol=1e-7)
     np.testing.assert_allclose(feats[0].numpy(), g["xf.small.desc"], rtol=0, atol=2e-5)
+
+
+def test_disk_restatement_matches_reference_forward():
+    import torch
+    from oracle import disk_ref
+    g = load_golden("nets.npz")
+    t = {k: torch.from_numpy(v) for k, v in weights.tensors_disk(weights.random_disk_state_dict(int(g["dk.seed"]))).items()}
+    v0, _ = synthetic.image_pair(0, 64, 96)
+    with torch.no_grad():
+        score, desc = disk_ref.disk_forward(torch.from_numpy(v0)[None], t)
+    np.testing.assert_allclose(score[0, 0].numpy(), g["dk.small.score"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(desc[0, :, ::4, ::4].numpy(), g["dk.small.desc"], rtol=0, atol=2e-6)
