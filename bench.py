@@ -133,7 +133,7 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
-    ap.add_argument("--model", default="alike", choices=["alike", "superpoint"],
+    ap.add_argument("--model", default="alike", choices=["alike", "superpoint", "xfeat", "disk"],
                     help="alike = BASELINE configs[1] (the headline); superpoint = configs[2] with seeded random weights")
     args = ap.parse_args()
 
@@ -168,6 +168,14 @@ def main():
         net = superpoint_random(7).eval()
         if args.pairs_per_step == 64:
             B = 16
+    elif args.model == "xfeat":
+        from keypoint_bench_amd.models.XFeat import xfeat_random
+        net = xfeat_random(9).eval()
+    elif args.model == "disk":
+        from keypoint_bench_amd.models.disk import disk_random
+        net = disk_random(5).eval()
+        if args.pairs_per_step == 64:
+            B = 4
     else:
         net = alike_t(dense_descriptors=not args.sparse).eval()
     pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
@@ -242,10 +250,10 @@ def main():
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("SuperPoint" if args.model == "superpoint" else "ALIKE-t") + " extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
+            "config": {"workload": {"alike": "ALIKE-t", "superpoint": "SuperPoint", "xfeat": "XFeat", "disk": "DISK"}[args.model] + " extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
                                    "(euclidean fp64, max_distance=5, cross_check), 640x480 pairs [BASELINE configs[1]]",
                        "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
-                       "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else "superpoint, seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
+                       "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
                         "pairs_gathered": int(allrows.shape[0])},

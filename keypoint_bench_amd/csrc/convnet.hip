@@ -26,7 +26,7 @@ struct ConvM {
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
 };
 
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF>
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2>
 __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 {
     constexpr int KC = CC / 2, PITCH = CC + 4, T = KS * KS, PAD = KS / 2;
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
     constexpr int NLD = (IH * IW * Q + 255) / 256;
     __shared__ __attribute__((aligned(16))) float tile[IH * IW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * 2;
+    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
     const int ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 16;
     const int Hc = POOL_IN ? a.Hi / 2 : a.Hi, Wc = POOL_IN ? a.Wi / 2 : a.Wi;   // conv input extent
     const int iy0 = ty0 * S - PAD, ix0 = tx0 * S - PAD;
@@ -42,7 +42,11 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
     const int orow = 2 * wv + (p >> 4), ocol = p & 15;
     const size_t ntile_stride = (size_t)T * a.NCH * 2 * 32 * KC;
 
-    f32x16 acc0 = {0}, acc1 = {0};
+    f32x16 acc[NTB];
+#pragma unroll
+    for (int n = 0; n < NTB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
     for (int ch = 0; ch < a.NCH; ++ch) {
         __syncthreads();
         {   // stage one CC-channel slab of the input tile; every load of a thread is in flight before the first LDS store
@@ -89,58 +93,55 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
             const int ky = tap / KS, kx = tap - ky * KS;
             const float* ap = &tile[((orow * S + ky) * IW + ocol * S + kx) * PITCH + h * KC];
             const float* bp = a.wp + ((((size_t)nt0 * T + tap) * a.NCH + ch) * 2 + h) * 32 * KC + p * KC;
-            float A[KC], B0[KC], B1[KC];
+            float A[KC], Bw[NTB][KC];
 #pragma unroll
             for (int q = 0; q < KC / 4; ++q) {
                 const float4 va = *reinterpret_cast<const float4*>(ap + 4 * q);
-                const float4 v0 = *reinterpret_cast<const float4*>(bp + 4 * q);
-                const float4 v1 = *reinterpret_cast<const float4*>(bp + ntile_stride + 4 * q);
                 A[4 * q] = va.x; A[4 * q + 1] = va.y; A[4 * q + 2] = va.z; A[4 * q + 3] = va.w;
-                B0[4 * q] = v0.x; B0[4 * q + 1] = v0.y; B0[4 * q + 2] = v0.z; B0[4 * q + 3] = v0.w;
-                B1[4 * q] = v1.x; B1[4 * q + 1] = v1.y; B1[4 * q + 2] = v1.z; B1[4 * q + 3] = v1.w;
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) {
+                    const float4 v = *reinterpret_cast<const float4*>(bp + n * ntile_stride + 4 * q);
+                    Bw[n][4 * q] = v.x; Bw[n][4 * q + 1] = v.y; Bw[n][4 * q + 2] = v.z; Bw[n][4 * q + 3] = v.w;
+                }
             }
 #pragma unroll
-            for (int s = 0; s < KC; ++s) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], B0[s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], B1[s], acc1, 0, 0, 0);
-            }
+            for (int s = 0; s < KC; ++s)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], Bw[n][s], acc[n], 0, 0, 0);
         }
     }
 
     // epilogue: D[row = pixel i][col = channel]; lane holds channel p of each 32-wide tile, pixels (r&3) + 8*(r>>2) + 4h
-    const int co0 = nt0 * 32 + p, co1 = co0 + 32;
-    const float bias0 = a.bias[co0], bias1 = a.bias[co1];
-    float v0[16], v1[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        v0[r] = acc0[r] + bias0; v1[r] = acc1[r] + bias1;
-        if (a.relu) { v0[r] = relu(v0[r]); v1[r] = relu(v1[r]); }
-    }
-    if (!POOL_OUT) {
-        float* out = a.out + (size_t)b * a.H * a.W * a.COUT;
+    for (int n = 0; n < NTB; ++n) {
+        const int co = (nt0 + n) * 32 + p;
+        const float bias = a.bias[co];
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int gy = ty0 + 2 * wv + (i >> 4), gx = tx0 + (i & 15);
-            if (gy < a.H && gx < a.W) {
-                float* o = out + ((size_t)gy * a.W + gx) * a.COUT;
-                if (co0 < a.COUT) o[co0] = v0[r];
-                if (co1 < a.COUT) o[co1] = v1[r];
-            }
+            v[r] = acc[n][r] + bias;
+            if (a.relu) v[r] = relu(v[r]);
         }
-    } else {
-        const int Ho = a.H / 2, Wo = a.W / 2;
-        float* out = a.out + (size_t)b * Ho * Wo * a.COUT;
-        const int gy = ty0 / 2 + wv;
+        if (co >= a.COUT) continue;
+        if (!POOL_OUT) {
+            float* out = a.out + (size_t)b * a.H * a.W * a.COUT;
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = 2 * h + (cc & 1) + 4 * (cc >> 1);       // pooled column inside the tile
-            const int rA = 2 * (cc & 1) + 4 * (cc >> 1);          // = 2*(c&1) + 4*(c>>2)
-            const int gx = tx0 / 2 + c;
-            if (gy < Ho && gx < Wo) {
-                float* o = out + ((size_t)gy * Wo + gx) * a.COUT;
-                if (co0 < a.COUT) o[co0] = fmaxf(fmaxf(v0[rA], v0[rA + 1]), fmaxf(v0[rA + 8], v0[rA + 9]));
-                if (co1 < a.COUT) o[co1] = fmaxf(fmaxf(v1[rA], v1[rA + 1]), fmaxf(v1[rA + 8], v1[rA + 9]));
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gy = ty0 + 2 * wv + (i >> 4), gx = tx0 + (i & 15);
+                if (gy < a.H && gx < a.W) out[((size_t)gy * a.W + gx) * a.COUT + co] = v[r];
+            }
+        } else {
+            const int Ho = a.H / 2, Wo = a.W / 2;
+            float* out = a.out + (size_t)b * Ho * Wo * a.COUT;
+            const int gy = ty0 / 2 + wv;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = 2 * h + (cc & 1) + 4 * (cc >> 1);       // pooled column inside the tile
+                const int rA = 2 * (cc & 1) + 4 * (cc >> 1);          // = 2*(c&1) + 4*(c>>2)
+                const int gx = tx0 / 2 + c;
+                if (gy < Ho && gx < Wo)
+                    out[((size_t)gy * Wo + gx) * a.COUT + co] = fmaxf(fmaxf(v[rA], v[rA + 1]), fmaxf(v[rA + 8], v[rA + 9]));
             }
         }
     }
@@ -332,9 +333,9 @@ __global__ void unfold8(const float* gray, float* out, int H, int W)
 
 // ------------------------------------------------------------------------------------------------ host helpers
 // OIHW [COUT][CIN][KS][KS] -> conv_mfma fragment order [ntile][tap][chunk][h][32][KC]
-std::vector<float> pack_mfma(const float* w, int COUT, int CIN, int KS, int CC)
+std::vector<float> pack_mfma(const float* w, int COUT, int CIN, int KS, int CC, int NTB)
 {
-    const int KC = CC / 2, T = KS * KS, NCH = CIN / CC, NT = ((COUT + 63) / 64) * 2;
+    const int KC = CC / 2, T = KS * KS, NCH = CIN / CC, NT = ((COUT + 32 * NTB - 1) / (32 * NTB)) * NTB;
     std::vector<float> out((size_t)NT * T * NCH * 2 * 32 * KC, 0.0f);
     for (int nt = 0; nt < NT; ++nt)
         for (int tap = 0; tap < T; ++tap)
@@ -372,6 +373,7 @@ struct Layer {      // one convolution of a network plan
     int cin, cout, ks, stride;
     bool mfma;
     int cc = 32;    // channels per LDS chunk of conv_mfma (32, or 16 for stride 2 / CIN not a multiple of 32)
+    int ntb = 2;    // 32-wide output tiles per workgroup
 };
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
@@ -383,7 +385,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf;
     a.Hi = Hi; a.Wi = Wi;
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
-    a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 63) / 64;
+    a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 32 * L.ntb - 1) / (32 * L.ntb);
     const dim3 grid(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk), block(256);
     hipStream_t st = ctx->stream;
     const bool x = xf != nullptr;
@@ -393,7 +395,8 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<1, 1, 32, false, false, false>), grid, block, 0, st, a);
     else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 2, 16, false, false, false>), grid, block, 0, st, a);
     else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma<5, 1, 32, false, false, true>), grid, block, 0, st, a);
-    else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma<5, 1, 16, false, false, true>), grid, block, 0, st, a);
+    else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma<5, 1, 16, false, false, true>), grid, block, 0, st, a);
+    else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) KPB_LAUNCH(ctx, name, (conv_mfma<5, 1, 16, false, false, true, 5>), grid, block, 0, st, a);
     else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma: no instance for ks=%d stride=%d cc=%d pool_in=%d pool_out=%d xf=%d", L.ks, S, CC, pool_in, pool_out, x);
     return KPB_OK;
 }
@@ -413,8 +416,8 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
 void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b)
 {
     if (L.mfma) {
-        ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.cc));
-        ws.put(L.name + ".b", pad_bias(b, L.cout, 64));
+        ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.cc, L.ntb));
+        ws.put(L.name + ".b", pad_bias(b, L.cout, 32 * L.ntb));
     } else {
         ws.put(L.name + ".w", pack_valu(w, L.cout, L.cin, L.ks));
         ws.put(L.name + ".b", pad_bias(b, L.cout, 8));
@@ -694,21 +697,21 @@ __global__ void make_xf(const double* sums, const float* slope, float* xf, size_
     xf[4 * i] = rstd; xf[4 * i + 1] = -(float)mean * rstd; xf[4 * i + 2] = slope[i % C]; xf[4 * i + 3] = 0.0f;
 }
 
-// disk.py:311-312: desc = F.normalize(feature[:, :128], dim=1) in place, score = sigmoid(feature[:, 128])
-__global__ __launch_bounds__(256) void disk_head(float* desc, const float* logit, float* score, size_t npix)
+// disk.py:311-312: desc = F.normalize(feature[:, :128], dim=1), score = sigmoid(feature[:, 128]); feature is [.., 129]
+__global__ __launch_bounds__(256) void disk_head(const float* feat, float* desc, float* score, size_t npix)
 {
     const int lane = threadIdx.x & 63;
     const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= npix) return;
-    float2* d = reinterpret_cast<float2*>(desc + pix * 128) + lane;
-    float2 v = *d;
-    float ss = fmaf(v.x, v.x, v.y * v.y);
+    const float* f = feat + pix * 129;
+    const float a = f[lane], b = f[lane + 64];
+    float ss = fmaf(a, a, b * b);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float n = fmaxf(sqrtf(ss), 1e-12f);
-    v.x = __fdiv_rn(v.x, n); v.y = __fdiv_rn(v.y, n);
-    *d = v;
-    if (lane == 0) score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-logit[pix]));   // conv_valu output: 1 channel, stride 1
+    desc[pix * 128 + lane] = __fdiv_rn(a, n);
+    desc[pix * 128 + lane + 64] = __fdiv_rn(b, n);
+    if (lane == 0) score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-f[128]));
 }
 
 struct DiskNet : kpb_net {
@@ -731,7 +734,7 @@ struct DiskNet : kpb_net {
         // floats per image
         const size_t n_in = P * 4, n_f1 = P * 16, n_p1 = P / 4 * 16, n_f2 = P / 4 * 32, n_p2 = P / 16 * 32, n_f3 = P / 16 * 64, n_p3 = P / 64 * 64,
                      n_f4 = P / 64 * 64, n_p4 = P / 256 * 64, n_f5 = P / 256 * 64, n_c0 = P / 64 * 128, n_u0 = P / 64 * 64, n_c1 = P / 16 * 128,
-                     n_u1 = P / 16 * 64, n_c2 = P / 4 * 96, n_u2 = P / 4 * 64, n_c3 = P * 80, n_lg = P;
+                     n_u1 = P / 16 * 64, n_c2 = P / 4 * 96, n_u2 = P / 4 * 64, n_c3 = P * 80, n_lg = P * 129;
         const size_t total = B * (n_in + n_f1 + n_p1 + n_f2 + n_p2 + n_f3 + n_p3 + n_f4 + n_p4 + n_f5 + n_c0 + n_u0 + n_c1 + n_u1 + n_c2 + n_u2 + n_c3 + n_lg)
                              + B * 128 * 4 + B * 128 * 4 + 64;
         if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
@@ -783,9 +786,8 @@ struct DiskNet : kpb_net {
         if ((rc = launch_mfma(ctx, "disk_up2", this, L["up2"], c2, u2, batch, H / 2, W / 2, false, false, false, xf))) return rc;
         upcat(u2, f1, c3, H / 2, W / 2, 64, 16);
         if ((rc = stats_xf(c3, P, 80, "up3.slope", sums, xf, batch))) return rc;
-        if ((rc = launch_mfma(ctx, "disk_up3_desc", this, L["up3d"], c3, desc_out, batch, H, W, false, false, false, xf))) return rc;
-        if ((rc = launch_valu(ctx, "disk_up3_score", this, L["up3s"], c3, lg, batch, H, W, false, xf))) return rc;
-        KPB_LAUNCH(ctx, "disk_head", disk_head, dim3((unsigned)((B * P + 3) / 4)), dim3(256), 0, st, desc_out, lg, score_out, B * P);
+        if ((rc = launch_mfma(ctx, "disk_up3", this, L["up3"], c3, lg, batch, H, W, false, false, false, xf))) return rc;
+        KPB_LAUNCH(ctx, "disk_head", disk_head, dim3((unsigned)((B * P + 3) / 4)), dim3(256), 0, st, lg, desc_out, score_out, B * P);
         KPB_HIP(ctx, hipGetLastError());
         return KPB_OK;
     }
@@ -856,17 +858,15 @@ int disk_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         ws.put_raw(L.name + ".slope", sl, q.cin);
         net->L[L.name] = L;
     }
-    {   // up_3: 80 -> 129 split into the 128 descriptor channels (MFMA) and the score logit (VALU)
+    {   // up_3: 80 -> 129 = 128 descriptor channels + the score logit, five 32-wide tiles in one workgroup
         const float* w = bl.get("up3.w", {129, 80, 5, 5});
         const float* b = bl.get("up3.b", {129});
         const float* sl = bl.get("up3.slope", {80});
         if (!w || !b || !sl) return fail("up3");
-        Layer Ld{"up3d", 80, 128, 5, 1, true}; Ld.cc = 16;
-        Layer Ls{"up3s", 80, 1, 5, 1, false};
-        stage_layer(ws, Ld, w, b);
-        stage_layer(ws, Ls, w + (size_t)128 * 80 * 25, b + 128);
+        Layer L3{"up3", 80, 129, 5, 1, true}; L3.cc = 16; L3.ntb = 5;
+        stage_layer(ws, L3, w, b);
         ws.put_raw("up3.slope", sl, 80);
-        net->L["up3d"] = Ld; net->L["up3s"] = Ls;
+        net->L["up3"] = L3;
     }
     if (int rc = ws.upload(net)) { delete net; return rc; }
     *out = net;

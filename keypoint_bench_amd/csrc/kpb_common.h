@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,7 @@ struct kpb_ctx {
     bool prof = false;
     std::vector<kpb_prof_rec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
+    std::set<std::string> prof_names;   // interned: record names outlive the (possibly temporary) strings of the callers
     hipStream_t stream = nullptr;
     bool own_stream = false;
     char err[512] = {0};
@@ -94,7 +96,7 @@ struct ProfScope {
             if (!c->prof_pool.empty()) { ev[i] = c->prof_pool.back(); c->prof_pool.pop_back(); }
             else if (hipEventCreate(&ev[i]) != hipSuccess) return;
         }
-        c->prof_recs.push_back({name, ev[0], ev[1]});
+        c->prof_recs.push_back({c->prof_names.insert(name).first->c_str(), ev[0], ev[1]});
         e1 = ev[1];
         (void)hipEventRecord(ev[0], c->stream);
     }
