@@ -192,6 +192,44 @@ __global__ __launch_bounds__(256) void conv_valu(ConvV a)
         if (cg * 8 + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
 }
 
+// SuperPoint conv1a (1 -> 64, 3x3, ReLU; SuperPoint.py:44): 16 lanes share a pixel, each lane keeps the 9 taps of its
+// 4 output channels in registers and walks down a column of pixels, so a wave store is 4 whole 256-byte pixels.
+__global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block)
+{
+    const int b = blockIdx.z, lane16 = threadIdx.x & 15, c4 = lane16 * 4;
+    const int x = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (x >= W) return;
+    float wr[9][4], bv[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[t][j] = w[t * 64 + c4 + j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = bias[c4 + j];
+    const float* g = gray + (size_t)b * H * W;
+    const int y0 = blockIdx.y * rows_per_block, y1 = min(y0 + rows_per_block, H);
+    auto ld = [&](int yy, int xx) { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? g[(size_t)yy * W + xx] : 0.0f; };
+    float r0[3], r1[3], r2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { r0[k] = ld(y0 - 1, x - 1 + k); r1[k] = ld(y0, x - 1 + k); }
+    for (int y = y0; y < y1; ++y) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r2[k] = ld(y + 1, x - 1 + k);
+        float acc[4] = {bv[0], bv[1], bv[2], bv[3]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[j] = fmaf(r0[k], wr[k][j], acc[j]);
+                acc[j] = fmaf(r1[k], wr[3 + k][j], acc[j]);
+                acc[j] = fmaf(r2[k], wr[6 + k][j], acc[j]);
+            }
+        *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * 64 + c4) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ small kernels
 // SuperPoint.py:42  x = torch.sum(x, dim=1, keepdim=True)
 __global__ void rgb_sum(const float* img, float* gray, size_t P)
@@ -273,7 +311,7 @@ __global__ void instnorm_apply(float* gray, const double* stats, size_t P)
 }
 
 // XFeat.py:27-28: skip1 = AvgPool2d(4) -> Conv2d(1, 24, 1); added to block1's output (XFeat.py:127): out += w*avg + b
-__global__ void skip_add(const float* gray, float* x1, const float* w, const float* bias, int H, int W)
+__global__ void skip_add(const float* gray, float* x1, const float* w, const float* bias, int H, int W, int cstride)
 {
     const int H4 = H / 4, W4 = W / 4;
     const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
@@ -286,7 +324,7 @@ __global__ void skip_add(const float* gray, float* x1, const float* w, const flo
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) sacc += g[(size_t)dy * W + dx];
     const float avg = sacc * (1.0f / 16.0f);
-    float* o = x1 + ((size_t)b * H4 * W4 + i) * 24;
+    float* o = x1 + ((size_t)b * H4 * W4 + i) * cstride;
 #pragma unroll
     for (int c = 0; c < 24; ++c) o[c] += fmaf(avg, w[c], bias[c]);
 }
@@ -455,7 +493,7 @@ struct SuperPointNet : kpb_net {
         hipStream_t st = ctx->stream;
         KPB_LAUNCH(ctx, "sp_rgb_sum", rgb_sum, dim3((unsigned)((P + 255) / 256), batch), dim3(256), 0, st, img, gray, P);
         int rc;
-        if ((rc = launch_valu(ctx, "sp_conv1a", this, L["conv1a"], gray, x1a, batch, H, W, true))) return rc;          // :44
+        KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32);   // :44
         if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], x1a, x1b, batch, H, W, false, true, true))) return rc;      // :45-46 (+pool)
         if ((rc = launch_mfma(ctx, "sp_conv2a", this, L["conv2a"], x1b, x2a, batch, H / 2, W / 2, false, false, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv2b", this, L["conv2b"], x2a, x2b, batch, H / 2, W / 2, false, true, true))) return rc;
@@ -532,7 +570,7 @@ struct XFeatNet : kpb_net {
         const size_t P = (size_t)H * W, B = batch;
         const int H2 = H / 2, W2 = W / 2, H4 = H / 4, W4 = W / 4, H8 = H / 8, W8 = W / 8, H16 = H / 16, W16 = W / 16, H32 = H / 32, W32 = W / 32;
         // floats per image of each activation
-        const size_t n_gray = P, n_a = P * 4, n_b = P / 4 * 8, n_c = P / 4 * 8, n_x1 = P / 16 * 24, n_t = P / 16 * 24, n_x2 = P / 16 * 24,
+        const size_t n_gray = P, n_a = P * 4, n_b = P / 4 * 8, n_c = P / 4 * 8, n_x1 = P / 16 * 32, n_t = P / 16 * 32, n_x2 = P / 16 * 32,
                      n_8 = P / 64 * 64, n_16 = P / 256 * 64, n_32a = P / 1024 * 128, n_semi = P / 64 * 65;
         const size_t total = B * (n_gray + n_a + n_b + n_c + n_x1 + n_t + n_x2 + 6 * n_8 + 3 * n_16 + 3 * n_32a + n_semi) + 64;
         if (int rc = kpb_reserve(ctx, act, total * sizeof(float) + 16 * B)) return rc;
@@ -556,7 +594,7 @@ struct XFeatNet : kpb_net {
         if ((rc = conv("block1.1", a1, b1, batch, H, W))) return rc;
         if ((rc = conv("block1.2", b1, c1, batch, H2, W2))) return rc;
         if ((rc = conv("block1.3", c1, x1, batch, H2, W2))) return rc;
-        KPB_LAUNCH(ctx, "xf_skip_add", skip_add, dim3(cdiv(H4 * W4, 256), batch), dim3(256), 0, st, gray, x1, wp("skip1.w"), wp("skip1.b"), H, W);
+        KPB_LAUNCH(ctx, "xf_skip_add", skip_add, dim3(cdiv(H4 * W4, 256), batch), dim3(256), 0, st, gray, x1, wp("skip1.w"), wp("skip1.b"), H, W, 32);
         if ((rc = conv("block2.0", x1, t2, batch, H4, W4))) return rc;
         if ((rc = conv("block2.1", t2, x2, batch, H4, W4))) return rc;
         if ((rc = conv("block3.0", x2, u8[0], batch, H4, W4))) return rc;
@@ -596,14 +634,24 @@ int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
     net->ctx = ctx; net->arch = KPB_ARCH_XFEAT; net->dim = 64; net->desc_div = 8;
     WeightStage ws;
     for (const XFeatPlan& q : XF) {
-        Layer L{q.name, q.cin, q.cout, q.ks, q.stride, (q.cin % 32 == 0) && !(q.stride == 2 && q.cin % 16 != 0)};
-        L.cc = q.stride == 2 ? 16 : 32;
-        const float* w = bl.get((L.name + ".w").c_str(), {(uint32_t)L.cout, (uint32_t)L.cin, (uint32_t)L.ks, (uint32_t)L.ks});
-        const float* b = bl.get((L.name + ".b").c_str(), {(uint32_t)L.cout});
+        const float* w = bl.get((std::string(q.name) + ".w").c_str(), {(uint32_t)q.cout, (uint32_t)q.cin, (uint32_t)q.ks, (uint32_t)q.ks});
+        const float* b = bl.get((std::string(q.name) + ".b").c_str(), {(uint32_t)q.cout});
         if (!w || !b) {
             delete net;
-            return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: XFeat tensor %s.w/.b missing or mis-shaped", L.name.c_str());
+            return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: XFeat tensor %s.w/.b missing or mis-shaped", q.name);
         }
+        // the 24-channel stage (block1.3 out, block2, block3.0 in) is stored with 32 channels, the extra 8 are
+        // exact zeros (zero weights, zero bias, ReLU), which puts block2 and block3.0 on the MFMA kernel
+        const int cin = q.cin == 24 ? 32 : q.cin, cout = q.cout == 24 ? 32 : q.cout, T = q.ks * q.ks;
+        std::vector<float> wpad((size_t)cout * cin * T, 0.0f), bpad(cout, 0.0f);
+        for (int o = 0; o < q.cout; ++o) {
+            bpad[o] = b[o];
+            for (int c = 0; c < q.cin; ++c)
+                for (int t = 0; t < T; ++t) wpad[((size_t)o * cin + c) * T + t] = w[((size_t)o * q.cin + c) * T + t];
+        }
+        w = wpad.data(); b = bpad.data();
+        Layer L{q.name, cin, cout, q.ks, q.stride, (cin % 32 == 0)};
+        L.cc = q.stride == 2 ? 16 : 32;
         stage_layer(ws, L, w, b);
         net->L[L.name] = L;
         net->relu_of[L.name] = q.relu;
