@@ -143,6 +143,32 @@ int kpb_net_forward(kpb_net* net, const float* img_dev, int batch, int H, int W,
 int kpb_net_desc_at(kpb_net* net, const float* pts_dev, int pts_cols, int max_n,
                     const int32_t* n_dev, float* out_dev);
 
+/* ---- N5: models/lightglue.py LightGlue.match (447-477) / _forward (506-652) ----------------------------
+ * blob: .kpbw container (arch KPB_ARCH_LIGHTGLUE) with the tensors of the reference state_dict under their
+ * own names (transformers.{i}.self_attn.Wqkv.weight ... log_assignment.{i}.final_proj.weight,
+ * token_confidence.{i}.token.0.weight, posenc.Wr.weight, optional input_proj.*).
+ * desc_scale: the reference's self.desc_scale (8 for SuperPoint maps, 1 for DISK). */
+#define KPB_ARCH_LIGHTGLUE 5
+typedef struct kpb_lg kpb_lg;
+typedef struct kpb_lg_params {      /* LightGlue.default_conf, lightglue.py:335-348 */
+    float depth_confidence;         /* 0.95; <= 0 disables early stopping */
+    float width_confidence;         /* 0.99; <= 0 disables point pruning */
+    float filter_threshold;         /* 0.1 */
+    int32_t prune_min_kpts;         /* pruning_keypoint_thresholds: -1 on the reference's CPU path, 1024 / 1536 on CUDA */
+} kpb_lg_params;
+int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc_scale, kpb_lg** out);
+void kpb_lg_destroy(kpb_lg* lg);
+int kpb_lg_input_dim(const kpb_lg* lg);
+/* pts*_dev [batch][max_k][3] normalised (x, y, score) as detection returns them; n*_dev [batch] or NULL;
+ * desc*_dev: descriptor maps of the two sides, [batch] x (C, Hd, Wd) with element strides (sb, sc, sh, sw);
+ * img_w / img_h: params['w'], params['h'] of the reference call.
+ * out_pairs_dev [batch][max_k][2] (index into pts0, index into pts1) ascending in the first index,
+ * out_scores_dev [batch][max_k], out_k_dev [batch], out_stop_dev [batch] (layers run; may be NULL).  Asynchronous. */
+int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_dev, const int32_t* n0_dev, const int32_t* n1_dev,
+                 int batch, int max_k, const float* desc0_dev, const float* desc1_dev, int C, int Hd, int Wd,
+                 int64_t sb, int64_t sc, int64_t sh, int64_t sw, int img_w, int img_h, const kpb_lg_params* params,
+                 int32_t* out_pairs_dev, float* out_scores_dev, int32_t* out_k_dev, int32_t* out_stop_dev);
+
 #ifdef __cplusplus
 }
 #endif

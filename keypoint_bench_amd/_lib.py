@@ -15,6 +15,11 @@ class DetectParams(ctypes.Structure):
                 ("top_k", ctypes.c_int32), ("min_score", c_float)]
 
 
+class LgParams(ctypes.Structure):
+    _fields_ = [("depth_confidence", c_float), ("width_confidence", c_float), ("filter_threshold", c_float),
+                ("prune_min_kpts", ctypes.c_int32)]
+
+
 class MatchParams(ctypes.Structure):
     _fields_ = [("max_distance", c_double), ("cross_check", ctypes.c_int32)]
 
@@ -44,6 +49,12 @@ SIGNATURES = {
     "kpb_net_desc_div": (c_int, [c_void_p]),
     "kpb_net_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "kpb_net_desc_at": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "kpb_lg_create": (c_int, [c_void_p, c_void_p, c_size_t, c_float, ctypes.POINTER(c_void_p)]),
+    "kpb_lg_destroy": (None, [c_void_p]),
+    "kpb_lg_input_dim": (c_int, [c_void_p]),
+    "kpb_lg_match": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                             c_int64, c_int64, c_int64, c_int64, c_int, c_int, ctypes.POINTER(LgParams), c_void_p, c_void_p,
+                             c_void_p, c_void_p]),
 }
 
 _lib = None

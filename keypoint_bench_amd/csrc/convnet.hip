@@ -9,143 +9,9 @@
 // weights are pre-packed in exactly that fragment order so B is CC/8 global float4 loads per 32-wide tile.
 // The 2x2 max-pools of the VGG trunk are fused: on the input read (POOL_IN) or lane-locally on the
 // accumulators (POOL_OUT: the four pixels of a pool window live in registers r, r+1, r+8, r+9 of one lane).
-#include "net.h"
+#include "conv_mfma.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float relu(float v) { return fmaxf(v, 0.0f); }
-
-struct ConvM {
-    const float* in;    // [B][Hi][Wi][CIN]
-    float* out;         // [B][Ho][Wo][COUT]   (Ho, Wo) = (H, W) or (H/2, W/2) with POOL_OUT
-    const float* wp;    // packed: [ntile][tap][chunk][h][32][KC]
-    const float* bias;  // [COUTP] (zero padded)
-    const float* xf;    // XF: [B][CIN][4] = (scale, shift, prelu slope, -) applied to the input before zero padding
-    int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
-};
-
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2>
-__global__ __launch_bounds__(256) void conv_mfma(ConvM a)
-{
-    constexpr int KC = CC / 2, PITCH = CC + 4, T = KS * KS, PAD = KS / 2;
-    constexpr int IH = 7 * S + KS, IW = 15 * S + KS, Q = CC / 4;
-    constexpr int NLD = (IH * IW * Q + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float tile[IH * IW * PITCH];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
-    const int ty0 = blockIdx.y * 8, tx0 = blockIdx.x * 16;
-    const int Hc = POOL_IN ? a.Hi / 2 : a.Hi, Wc = POOL_IN ? a.Wi / 2 : a.Wi;   // conv input extent
-    const int iy0 = ty0 * S - PAD, ix0 = tx0 * S - PAD;
-    const float* in = a.in + (size_t)b * a.Hi * a.Wi * a.CIN;
-    const int orow = 2 * wv + (p >> 4), ocol = p & 15;
-    const size_t ntile_stride = (size_t)T * a.NCH * 2 * 32 * KC;
-
-    f32x16 acc[NTB];
-#pragma unroll
-    for (int n = 0; n < NTB; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
-    for (int ch = 0; ch < a.NCH; ++ch) {
-        __syncthreads();
-        {   // stage one CC-channel slab of the input tile; every load of a thread is in flight before the first LDS store
-            float4 buf[NLD];
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int idx = tid + k * 256;
-                const int pix = idx / Q, q = idx - pix * Q;
-                const int y = pix / IW, x = pix - y * IW;
-                const int gy = iy0 + y, gx = ix0 + x;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < IH * IW * Q && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
-                    if (POOL_IN) {
-                        const float* s = in + ((size_t)(2 * gy) * a.Wi + 2 * gx) * a.CIN + ch * CC + 4 * q;
-                        const float4 v00 = *reinterpret_cast<const float4*>(s), v01 = *reinterpret_cast<const float4*>(s + a.CIN);
-                        const float4 v10 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.CIN);
-                        const float4 v11 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.CIN + a.CIN);
-                        v.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)); v.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
-                        v.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); v.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
-                    } else {
-                        v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.CIN + ch * CC + 4 * q);
-                    }
-                    if (XF) {   // InstanceNorm (scale, shift) + PReLU of the pre-activation Conv block (disk.py:76-97)
-                        const float4* t4 = reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + ch * CC + 4 * q) * 4);
-                        const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
-                        v.x = fmaf(v.x, t0.x, t0.y); v.x = v.x >= 0.0f ? v.x : v.x * t0.z;
-                        v.y = fmaf(v.y, t1.x, t1.y); v.y = v.y >= 0.0f ? v.y : v.y * t1.z;
-                        v.z = fmaf(v.z, t2.x, t2.y); v.z = v.z >= 0.0f ? v.z : v.z * t2.z;
-                        v.w = fmaf(v.w, t3.x, t3.y); v.w = v.w >= 0.0f ? v.w : v.w * t3.z;
-                    }
-                }
-                buf[k] = v;
-            }
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int idx = tid + k * 256;
-                const int pix = idx / Q, q = idx - pix * Q;
-                if (idx < IH * IW * Q) *reinterpret_cast<float4*>(&tile[pix * PITCH + 4 * q]) = buf[k];
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int tap = 0; tap < T; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const float* ap = &tile[((orow * S + ky) * IW + ocol * S + kx) * PITCH + h * KC];
-            const float* bp = a.wp + ((((size_t)nt0 * T + tap) * a.NCH + ch) * 2 + h) * 32 * KC + p * KC;
-            float A[KC], Bw[NTB][KC];
-#pragma unroll
-            for (int q = 0; q < KC / 4; ++q) {
-                const float4 va = *reinterpret_cast<const float4*>(ap + 4 * q);
-                A[4 * q] = va.x; A[4 * q + 1] = va.y; A[4 * q + 2] = va.z; A[4 * q + 3] = va.w;
-#pragma unroll
-                for (int n = 0; n < NTB; ++n) {
-                    const float4 v = *reinterpret_cast<const float4*>(bp + n * ntile_stride + 4 * q);
-                    Bw[n][4 * q] = v.x; Bw[n][4 * q + 1] = v.y; Bw[n][4 * q + 2] = v.z; Bw[n][4 * q + 3] = v.w;
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < KC; ++s)
-#pragma unroll
-                for (int n = 0; n < NTB; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s], Bw[n][s], acc[n], 0, 0, 0);
-        }
-    }
-
-    // epilogue: D[row = pixel i][col = channel]; lane holds channel p of each 32-wide tile, pixels (r&3) + 8*(r>>2) + 4h
-#pragma unroll
-    for (int n = 0; n < NTB; ++n) {
-        const int co = (nt0 + n) * 32 + p;
-        const float bias = a.bias[co];
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            v[r] = acc[n][r] + bias;
-            if (a.relu) v[r] = relu(v[r]);
-        }
-        if (co >= a.COUT) continue;
-        if (!POOL_OUT) {
-            float* out = a.out + (size_t)b * a.H * a.W * a.COUT;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int gy = ty0 + 2 * wv + (i >> 4), gx = tx0 + (i & 15);
-                if (gy < a.H && gx < a.W) out[((size_t)gy * a.W + gx) * a.COUT + co] = v[r];
-            }
-        } else {
-            const int Ho = a.H / 2, Wo = a.W / 2;
-            float* out = a.out + (size_t)b * Ho * Wo * a.COUT;
-            const int gy = ty0 / 2 + wv;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int c = 2 * h + (cc & 1) + 4 * (cc >> 1);       // pooled column inside the tile
-                const int rA = 2 * (cc & 1) + 4 * (cc >> 1);          // = 2*(c&1) + 4*(c>>2)
-                const int gx = tx0 / 2 + c;
-                if (gy < Ho && gx < Wo)
-                    out[((size_t)gy * Wo + gx) * a.COUT + co] = fmaxf(fmaxf(v[rA], v[rA + 1]), fmaxf(v[rA + 8], v[rA + 9]));
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // VALU convolution for thin layers (CIN or COUT not MFMA shaped): one pixel x 8 output channels per thread,
@@ -370,31 +236,6 @@ __global__ void unfold8(const float* gray, float* out, int H, int W)
 }
 
 // ------------------------------------------------------------------------------------------------ host helpers
-// OIHW [COUT][CIN][KS][KS] -> conv_mfma fragment order [ntile][tap][chunk][h][32][KC]
-std::vector<float> pack_mfma(const float* w, int COUT, int CIN, int KS, int CC, int NTB)
-{
-    const int KC = CC / 2, T = KS * KS, NCH = CIN / CC, NT = ((COUT + 32 * NTB - 1) / (32 * NTB)) * NTB;
-    std::vector<float> out((size_t)NT * T * NCH * 2 * 32 * KC, 0.0f);
-    for (int nt = 0; nt < NT; ++nt)
-        for (int tap = 0; tap < T; ++tap)
-            for (int ch = 0; ch < NCH; ++ch)
-                for (int h = 0; h < 2; ++h)
-                    for (int j = 0; j < 32; ++j)
-                        for (int s = 0; s < KC; ++s) {
-                            const int o = nt * 32 + j, c = ch * CC + h * KC + s;
-                            if (o < COUT)
-                                out[(((((size_t)nt * T + tap) * NCH + ch) * 2 + h) * 32 + j) * KC + s] = w[((size_t)o * CIN + c) * T + tap];
-                        }
-    return out;
-}
-
-std::vector<float> pad_bias(const float* b, int COUT, int mult)
-{
-    std::vector<float> out(((COUT + mult - 1) / mult) * mult, 0.0f);
-    if (b) for (int i = 0; i < COUT; ++i) out[i] = b[i];
-    return out;
-}
-
 // OIHW -> [tap][cin][COUT8]
 std::vector<float> pack_valu(const float* w, int COUT, int CIN, int KS)
 {
@@ -421,6 +262,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
     ConvM a;
     a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf;
+    a.active = nullptr; a.istride = L.cin; a.ostride = L.cout; a.ooff = 0;
     a.Hi = Hi; a.Wi = Wi;
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
     a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 32 * L.ntb - 1) / (32 * L.ntb);

@@ -1,0 +1,729 @@
+// lightglue.hip -- N5: the LightGlue matcher (models/lightglue.py: LightGlue.match 447-477, _forward 506-652 and the
+// blocks it calls) on gfx950, fp32 throughout, following the reference's CPU path: exact-fp32 attention, early
+// stopping (check_if_stop 670-681) and point pruning (get_pruning_mask 659-668) decided ON THE DEVICE, so a batch of
+// pairs runs through all nine layers without a host round trip; pairs that stopped are skipped by every later kernel.
+//
+//   Linear layers   = conv_mfma<1,...> over tokens laid out as a 16-wide "image" (weights pre-packed once)
+//   attention       = lg_flash: per wave 32 queries, K tile as the MFMA A operand and Q as B (S^T = K.Q^T), so each
+//                     lane owns one query column and its softmax statistics; the probability tile then feeds the
+//                     P.V MFMA straight from its accumulator registers (k order permuted, V rows loaded to match)
+//   assignment      = NT GEMM of the projected descriptors, row/column log-sum-exp, mutual arg-max, threshold
+#include "conv_mfma.h"
+
+namespace {
+
+constexpr int D = 256, NH = 4, HD = 64, NF = 32, NL = 9;
+
+// ------------------------------------------------------------------------------------------------ preparation
+struct PrepArgs {
+    const float* pts0; const float* pts1;   // [B][K][3] normalised (x, y, score)
+    const int* n0; const int* n1;           // [B] or null
+    const float* Wr;                        // posenc.Wr.weight [32][2]
+    float* kpx;                             // [S][MP][2] pixel keypoints
+    float* cosb; float* sinb;               // [S][MP][32]
+    int* ind; int* cnt; int* cnt_orig;      // [S][MP], [S], [S]
+    int* active_seq; int* active_pair; int* stop;
+    int K, MP; float w1, h1;                // w - 1, h - 1
+};
+
+// lightglue.py:449-450 (pixel keypoints), 45-57 (normalize_keypoints, size=None), 93-98 (Fourier encoding)
+__global__ __launch_bounds__(256) void lg_prepare(PrepArgs a)
+{
+    __shared__ float red[4][4];
+    const int s = blockIdx.x, b = s >> 1, side = s & 1, tid = threadIdx.x;
+    const float* pts = (side ? a.pts1 : a.pts0) + (size_t)b * a.K * 3;
+    const int* np = side ? a.n1 : a.n0;
+    const int n = np ? min(np[b], a.K) : a.K;
+    float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+    for (int t = tid; t < n; t += 256) {
+        const float x = pts[3 * t] * a.w1, y = pts[3 * t + 1] * a.h1;
+        a.kpx[((size_t)s * a.MP + t) * 2] = x; a.kpx[((size_t)s * a.MP + t) * 2 + 1] = y;
+        mnx = fminf(mnx, x); mny = fminf(mny, y); mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
+    }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = mnx; red[tid >> 6][1] = mny; red[tid >> 6][2] = mxx; red[tid >> 6][3] = mxy; }
+    __syncthreads();
+    mnx = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])); mny = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1]));
+    mxx = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2])); mxy = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+    const float sx = (1.0f + mxx) - mnx, sy = (1.0f + mxy) - mny;       // size = 1 + max - min
+    const float shx = sx / 2.0f, shy = sy / 2.0f, scale = fmaxf(sx, sy) / 2.0f;
+    for (int i = tid; i < n * NF; i += 256) {
+        const int t = i / NF, f = i - t * NF;
+        const float kx = __fdiv_rn(a.kpx[((size_t)s * a.MP + t) * 2] - shx, scale), ky = __fdiv_rn(a.kpx[((size_t)s * a.MP + t) * 2 + 1] - shy, scale);
+        const float pr = __fadd_rn(__fmul_rn(kx, a.Wr[2 * f]), __fmul_rn(ky, a.Wr[2 * f + 1]));
+        a.cosb[((size_t)s * a.MP + t) * NF + f] = cosf(pr);
+        a.sinb[((size_t)s * a.MP + t) * NF + f] = sinf(pr);
+    }
+    for (int t = tid; t < a.MP; t += 256) a.ind[(size_t)s * a.MP + t] = t;
+    if (tid == 0) {
+        a.cnt[s] = n; a.cnt_orig[s] = n;
+        const int n_other = (side ? a.n0 : a.n1) ? min((side ? a.n0 : a.n1)[b], a.K) : a.K;
+        const int act = (n > 0 && n_other > 0) ? 1 : 0;       // lightglue.py:553-554: nothing to do without keypoints
+        a.active_seq[s] = act;
+        if (side == 0) { a.active_pair[b] = act; a.stop[b] = act ? 0 : 1; }
+    }
+}
+
+struct SampleArgs {
+    const float* d0; const float* d1;       // descriptor maps of side 0 / 1: [B] x (C, Hd, Wd) with element strides
+    long long sb, sc, sh, sw;
+    const float* kpx; const int* cnt; float* out;   // out [S][MP][C]
+    int C, Hd, Wd, MP; float ds;            // ds = desc_scale
+};
+
+// lightglue.py:24-41 sample_descriptors: grid_sample(align_corners=True) at the LightGlue pixel convention, then L2 norm
+__global__ __launch_bounds__(256) void lg_sample(SampleArgs a)
+{
+    const int s = blockIdx.y, b = s >> 1, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= a.cnt[s]) return;
+    const float* map = ((s & 1) ? a.d1 : a.d0) + (size_t)b * a.sb;
+    const float half = a.ds / 2.0f;
+    float kx = (a.kpx[((size_t)s * a.MP + t) * 2] - half) + 0.5f, ky = (a.kpx[((size_t)s * a.MP + t) * 2 + 1] - half) + 0.5f;
+    kx = __fdiv_rn(kx, (float)((double)a.Wd * a.ds - a.ds / 2.0 - 0.5)); ky = __fdiv_rn(ky, (float)((double)a.Hd * a.ds - a.ds / 2.0 - 0.5));
+    const float gx = kx * 2.0f - 1.0f, gy = ky * 2.0f - 1.0f;
+    const float x = (gx + 1.0f) * ((float)(a.Wd - 1) / 2.0f), y = (gy + 1.0f) * ((float)(a.Hd - 1) / 2.0f);
+    const float xw = floorf(x), yn = floorf(y);
+    const float w = x - xw, e = 1.0f - w, nn = y - yn, so = 1.0f - nn;
+    const float c_nw = so * e, c_ne = so * w, c_sw = nn * e, c_se = nn * w;
+    const long long x0 = (long long)xw, y0 = (long long)yn, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < a.Wd, vx1 = x1 >= 0 && x1 < a.Wd, vy0 = y0 >= 0 && y0 < a.Hd, vy1 = y1 >= 0 && y1 < a.Hd;
+    float v[4];
+    float ss = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ch = lane + 64 * q;
+        v[q] = 0.0f;
+        if (ch < a.C) {
+            const float* p = map + (size_t)ch * a.sc;
+            const float nw = (vx0 && vy0) ? p[y0 * a.sh + x0 * a.sw] : 0.0f, ne = (vx1 && vy0) ? p[y0 * a.sh + x1 * a.sw] : 0.0f;
+            const float sw = (vx0 && vy1) ? p[y1 * a.sh + x0 * a.sw] : 0.0f, se = (vx1 && vy1) ? p[y1 * a.sh + x1 * a.sw] : 0.0f;
+            v[q] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(nw, c_nw), __fmul_rn(ne, c_ne)), __fmul_rn(sw, c_sw)), __fmul_rn(se, c_se));
+            ss = fmaf(v[q], v[q], ss);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);                      // F.normalize
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (lane + 64 * q < a.C) a.out[((size_t)s * a.MP + t) * a.C + lane + 64 * q] = __fdiv_rn(v[q], nrm);
+}
+
+// ------------------------------------------------------------------------------------------------ transformer pieces
+// lightglue.py:179-183: qkv.unflatten(-1, (heads, -1, 3)) then rotary embedding of q and k (71-78)
+__global__ __launch_bounds__(256) void lg_rotary(const float* qkv, const float* cosb, const float* sinb, float* q, float* k, float* v,
+                                                 const int* cnt, const int* active, int MP)
+{
+    const int s = blockIdx.y;
+    if (!active[s]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;        // (token, head, pair f)
+    const int t = i >> 7, hf = i & 127, head = hf >> 5, f = hf & 31;
+    if (t >= cnt[s]) return;
+    const float* src = qkv + ((size_t)s * MP + t) * 768 + head * 192 + (2 * f) * 3;
+    const float q0 = src[0], k0 = src[1], v0 = src[2], q1 = src[3], k1 = src[4], v1 = src[5];
+    const float c = cosb[((size_t)s * MP + t) * NF + f], sn = sinb[((size_t)s * MP + t) * NF + f];
+    const size_t o = ((size_t)s * MP + t) * D + head * HD + 2 * f;
+    q[o] = __fadd_rn(__fmul_rn(q0, c), __fmul_rn(-q1, sn)); q[o + 1] = __fadd_rn(__fmul_rn(q1, c), __fmul_rn(q0, sn));
+    k[o] = __fadd_rn(__fmul_rn(k0, c), __fmul_rn(-k1, sn)); k[o + 1] = __fadd_rn(__fmul_rn(k1, c), __fmul_rn(k0, sn));
+    v[o] = v0; v[o + 1] = v1;
+}
+
+struct FlashArgs {
+    const float* q; const float* k; const float* v; float* out;   // [S][MP][256] token major, head h at columns 64h..64h+63
+    const int* cnt; const int* active;
+    int MP, cross; float scale;
+};
+
+// softmax(q k^T * scale) v for one head and 32 queries per wave (lightglue.py:142-147 / 226-233), online softmax
+__global__ __launch_bounds__(256) void lg_flash(FlashArgs a)
+{
+    const int s = blockIdx.z, head = blockIdx.y;
+    if (!a.active[s]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wv) * 32;
+    const int nq = a.cnt[s];
+    if (q0 >= nq) return;
+    const int kv = a.cross ? (s ^ 1) : s;
+    const int nk = a.cnt[kv];
+    float Qr[32];
+    {
+        const float* qp = a.q + ((size_t)s * a.MP + q0 + p) * D + head * HD + 32 * h;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qp + 4 * c);
+            Qr[4 * c] = t4.x; Qr[4 * c + 1] = t4.y; Qr[4 * c + 2] = t4.z; Qr[4 * c + 3] = t4.w;
+        }
+    }
+    f32x16 O0 = {0}, O1 = {0};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float* kbase = a.k + (size_t)kv * a.MP * D + head * HD;
+    const float* vbase = a.v + (size_t)kv * a.MP * D + head * HD;
+    for (int k0 = 0; k0 < nk; k0 += 32) {
+        float Kr[32];
+        const float* kp = kbase + (size_t)(k0 + p) * D + 32 * h;      // rows past nk stay inside the padded buffer
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 t4 = *reinterpret_cast<const float4*>(kp + 4 * c);
+            Kr[4 * c] = t4.x; Kr[4 * c + 1] = t4.y; Kr[4 * c + 2] = t4.z; Kr[4 * c + 3] = t4.w;
+        }
+        f32x16 st = {0};
+#pragma unroll
+        for (int c = 0; c < 32; ++c) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Kr[c], Qr[c], st, 0, 0, 0);   // S^T: rows = keys, col = query p
+        float sc[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sc[r] = key < nk ? st[r] * a.scale : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_run == -INFINITY) ? 0.0f : expf(m_run - m_new);
+        float ps = 0.0f, pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pr[r] = (sc[r] == -INFINITY) ? 0.0f : expf(sc[r] - m_new); ps += pr[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        // rescale O: its rows are queries (r&3) + 8*(r>>2) + 4h, whose alpha lives in the lane of that query
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+            O0[r] *= ar; O1[r] *= ar;
+        }
+        // P.V: step r of the K loop consumes key (r&3) + 8*(r>>2) + 4h from this lane half -- exactly where pr[r] sits
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float* vp = vbase + (size_t)key * D + p;
+            const float v0 = key < nk ? vp[0] : 0.0f, v1 = key < nk ? vp[32] : 0.0f;
+            O0 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[r], v0, O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x2f32(pr[r], v1, O1, 0, 0, 0);
+        }
+    }
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    float* op = a.out + (size_t)s * a.MP * D + head * HD + p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float ir = __shfl(inv, qi, 64);
+        if (q0 + qi < nq) {
+            op[(size_t)(q0 + qi) * D] = O0[r] * ir;
+            op[(size_t)(q0 + qi) * D + 32] = O1[r] * ir;
+        }
+    }
+}
+
+// ffn.1 + ffn.2: LayerNorm(512, eps 1e-5, affine) then exact GELU, in place (lightglue.py:166-170)
+__global__ __launch_bounds__(256) void lg_ln_gelu(float* hbuf, const float* g, const float* bta, const int* cnt, const int* active, int MP)
+{
+    const int s = blockIdx.y, lane = threadIdx.x & 63;
+    if (!active[s]) return;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= cnt[s]) return;
+    float* x = hbuf + ((size_t)s * MP + t) * 512;
+    float v[8], sum = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { v[q] = x[lane + 64 * q]; sum += v[q]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / 512.0f;
+    float var = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float d = v[q] - mean; var = fmaf(d, d, var); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = 1.0f / sqrtf(var / 512.0f + 1e-5f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = lane + 64 * q;
+        const float y = (v[q] - mean) * rstd * g[c] + bta[c];
+        x[c] = 0.5f * y * (1.0f + erff(y * 0.70710678118654752440f));
+    }
+}
+
+// x += y on the first 256 columns of the 512-wide [x | message] rows
+__global__ void lg_residual(float* cat, const float* y, const int* cnt, const int* active, int MP)
+{
+    const int s = blockIdx.y;
+    if (!active[s]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, t = i >> 6, c4 = (i & 63) * 4;
+    if (t >= cnt[s]) return;
+    float4* x = reinterpret_cast<float4*>(cat + ((size_t)s * MP + t) * 512 + c4);
+    const float4 d = *reinterpret_cast<const float4*>(y + ((size_t)s * MP + t) * D + c4);
+    float4 v = *x;
+    v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+    *x = v;
+}
+
+// token confidence (lightglue.py:101-111) and matchability (308-309): two 256 -> 1 linears per token
+__global__ __launch_bounds__(256) void lg_conf(const float* cat, const float* wc, const float* bc, const float* wm, const float* bm,
+                                               float* conf, float* msc, float* zlog, const int* cnt, const int* active, int MP, int has_conf)
+{
+    const int s = blockIdx.y, lane = threadIdx.x & 63;
+    if (!active[s]) return;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= cnt[s]) return;
+    const float4 x = *reinterpret_cast<const float4*>(cat + ((size_t)s * MP + t) * 512 + 4 * lane);
+    const float4 m = *reinterpret_cast<const float4*>(wm + 4 * lane);
+    float zc = 0.0f, zm = fmaf(x.x, m.x, fmaf(x.y, m.y, fmaf(x.z, m.z, x.w * m.w)));
+    if (has_conf) {
+        const float4 c = *reinterpret_cast<const float4*>(wc + 4 * lane);
+        zc = fmaf(x.x, c.x, fmaf(x.y, c.y, fmaf(x.z, c.z, x.w * c.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { zc += __shfl_xor(zc, o, 64); zm += __shfl_xor(zm, o, 64); }
+    if (lane == 0) {
+        const size_t o = (size_t)s * MP + t;
+        zm += bm[0];
+        zlog[o] = zm;
+        msc[o] = 1.0f / (1.0f + expf(-zm));
+        conf[o] = has_conf ? 1.0f / (1.0f + expf(-(zc + bc[0]))) : 0.0f;
+    }
+}
+
+struct DecideArgs {
+    const float* conf; const float* msc;
+    int* cnt; const int* cnt_orig; int* newcnt; int* dst;   // dst [S][MP]: new row of a kept token, -1 if pruned
+    int* active_pair; int* active_seq; int* fin_pair; int* fin_seq; int* stop;
+    int MP, layer, prune_min; float thr, depth_conf, width_keep;   // width_keep = 1 - width_confidence
+    int do_stop, do_prune;
+};
+
+// check_if_stop (lightglue.py:670-681) and get_pruning_mask (659-668), one workgroup per pair
+__global__ __launch_bounds__(256) void lg_decide(DecideArgs a)
+{
+    __shared__ int wsum[4];
+    __shared__ int s_flag;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) { a.fin_pair[b] = 0; a.fin_seq[2 * b] = 0; a.fin_seq[2 * b + 1] = 0; }
+    if (!a.active_pair[b]) return;
+    const int s0 = 2 * b, s1 = 2 * b + 1;
+    const bool last = a.layer == NL - 1;
+    bool finish = last;
+    if (!last && a.do_stop) {
+        int unconf = 0;
+        for (int side = 0; side < 2; ++side) {
+            const int s = s0 + side, n = a.cnt[s];
+            for (int t = tid; t < n; t += 256) unconf += a.conf[(size_t)s * a.MP + t] < a.thr;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) unconf += __shfl_xor(unconf, o, 64);
+        if (lane == 0) wsum[wid] = unconf;
+        __syncthreads();
+        if (tid == 0) {
+            const float tot = (float)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+            const float ratio = 1.0f - __fdiv_rn(tot, (float)(a.cnt_orig[s0] + a.cnt_orig[s1]));
+            s_flag = ratio > a.depth_conf;
+        }
+        __syncthreads();
+        finish = s_flag != 0;
+        __syncthreads();
+    }
+    if (finish) {
+        if (tid == 0) {
+            a.fin_pair[b] = 1; a.fin_seq[s0] = 1; a.fin_seq[s1] = 1;
+            a.stop[b] = a.layer + 1;
+            a.active_pair[b] = 0; a.active_seq[s0] = 0; a.active_seq[s1] = 0;
+            a.newcnt[s0] = a.cnt[s0]; a.newcnt[s1] = a.cnt[s1];
+        }
+        return;
+    }
+    // pruning: ordered compaction of the kept tokens (index_select keeps order, lightglue.py:568-571)
+    for (int side = 0; side < 2; ++side) {
+        const int s = s0 + side, n = a.cnt[s];
+        const bool prune = a.do_prune && n > a.prune_min;
+        int base = 0;
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int t = c0 + tid;
+            bool keep = false;
+            if (t < n) {
+                const size_t o = (size_t)s * a.MP + t;
+                keep = !prune || (a.msc[o] > a.width_keep) || (a.do_stop && a.conf[o] <= a.thr);
+            }
+            const unsigned long long bal = __ballot(keep);
+            const int within = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wsum[wid] = __popcll(bal);
+            __syncthreads();
+            int wbase = 0, tot = 0;
+            for (int w = 0; w < 4; ++w) { if (w < wid) wbase += wsum[w]; tot += wsum[w]; }
+            __syncthreads();
+            if (t < n) a.dst[(size_t)s * a.MP + t] = keep ? base + wbase + within : -1;
+            base += tot;
+        }
+        if (tid == 0) a.newcnt[s] = base;
+    }
+}
+
+// moves kept tokens (x, encoding, original index) to their new rows in the other buffer set
+__global__ void lg_gather(const float* cat_in, float* cat_out, const float* cos_in, const float* sin_in, float* cos_out, float* sin_out,
+                          const int* ind_in, int* ind_out, const int* dst, const int* cnt, const int* active, int MP)
+{
+    const int s = blockIdx.y;
+    if (!active[s]) return;
+    const int i = blockIdx.x * 256 + threadIdx.x, t = i >> 6, c4 = (i & 63) * 4;
+    if (t >= cnt[s]) return;
+    const int d = dst[(size_t)s * MP + t];
+    if (d < 0) return;
+    *reinterpret_cast<float4*>(cat_out + ((size_t)s * MP + d) * 512 + c4) = *reinterpret_cast<const float4*>(cat_in + ((size_t)s * MP + t) * 512 + c4);
+    if (c4 < NF) {
+        *reinterpret_cast<float4*>(cos_out + ((size_t)s * MP + d) * NF + c4) = *reinterpret_cast<const float4*>(cos_in + ((size_t)s * MP + t) * NF + c4);
+        *reinterpret_cast<float4*>(sin_out + ((size_t)s * MP + d) * NF + c4) = *reinterpret_cast<const float4*>(sin_in + ((size_t)s * MP + t) * NF + c4);
+    }
+    if (c4 == 0) ind_out[(size_t)s * MP + d] = ind_in[(size_t)s * MP + t];
+}
+
+__global__ void lg_commit_counts(int* cnt, const int* newcnt, const int* active, int S)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < S && active[s]) cnt[s] = newcnt[s];
+}
+
+// ------------------------------------------------------------------------------------------------ assignment
+// sim[b][i][j] = (md0[i] / 4) . (md1[j] / 4), md = final_proj(desc) (lightglue.py:299-303); 32x32 tile per wave
+__global__ __launch_bounds__(256) void lg_sim(const float* md, float* sim, const int* cnt, const int* fin_pair, int MP)
+{
+    const int b = blockIdx.z;
+    if (!fin_pair[b]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
+    const int i0 = blockIdx.y * 32, j0 = (blockIdx.x * 4 + wv) * 32;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1];
+    if (i0 >= m || j0 >= n) return;
+    const float* A = md + ((size_t)(2 * b) * MP + i0 + p) * D + 32 * h;
+    const float* Bm = md + ((size_t)(2 * b + 1) * MP + j0 + p) * D + 32 * h;
+    f32x16 acc = {0};
+#pragma unroll 1
+    for (int kc = 0; kc < 4; ++kc) {
+        float ar[32], br[32];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 x = *reinterpret_cast<const float4*>(A + kc * 64 + 4 * c), y = *reinterpret_cast<const float4*>(Bm + kc * 64 + 4 * c);
+            ar[4 * c] = x.x * 0.25f; ar[4 * c + 1] = x.y * 0.25f; ar[4 * c + 2] = x.z * 0.25f; ar[4 * c + 3] = x.w * 0.25f;
+            br[4 * c] = y.x * 0.25f; br[4 * c + 1] = y.y * 0.25f; br[4 * c + 2] = y.z * 0.25f; br[4 * c + 3] = y.w * 0.25f;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[c], br[c], acc, 0, 0, 0);
+    }
+    float* o = sim + (size_t)b * MP * MP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (i < m && j0 + p < n) o[(size_t)i * MP + j0 + p] = acc[r];
+    }
+}
+
+// max and log(sum(exp(x - max))) of every row (mode 0) or column (mode 1) of sim: the two halves of log_softmax
+__global__ __launch_bounds__(256) void lg_lse(const float* sim, float* mxo, float* lgo, const int* cnt, const int* fin_pair, int MP, int mode)
+{
+    const int b = blockIdx.y;
+    if (!fin_pair[b]) return;
+    const int lane = threadIdx.x & 63;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1];
+    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nl = mode ? n : m, len = mode ? m : n;
+    if (line >= nl) return;
+    const float* base = sim + (size_t)b * MP * MP + (mode ? (size_t)line : (size_t)line * MP);
+    const size_t stride = mode ? MP : 1;
+    float mx = -INFINITY;
+    for (int k = lane; k < len; k += 64) mx = fmaxf(mx, base[k * stride]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.0f;
+    for (int k = lane; k < len; k += 64) sum += expf(base[k * stride] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (lane == 0) { mxo[(size_t)(2 * b + mode) * MP + line] = mx; lgo[(size_t)(2 * b + mode) * MP + line] = logf(sum); }
+}
+
+__device__ __forceinline__ float logsigmoid(float z) { return fminf(z, 0.0f) - log1pf(expf(-fabsf(z))); }
+
+// scores = log_softmax(sim, rows) + log_softmax(sim, cols) + logsigmoid(z0) + logsigmoid(z1)^T (lightglue.py:278-290);
+// best column of every row (mode 0) / best row of every column (mode 1), first index on ties (filter_matches 317)
+__global__ __launch_bounds__(256) void lg_best(const float* sim, const float* mxo, const float* lgo, const float* zlog, float* bestv, int* besti,
+                                               const int* cnt, const int* fin_pair, int MP, int mode)
+{
+    const int b = blockIdx.y;
+    if (!fin_pair[b]) return;
+    const int lane = threadIdx.x & 63;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1];
+    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nl = mode ? n : m, len = mode ? m : n;
+    if (line >= nl) return;
+    const float* S = sim + (size_t)b * MP * MP;
+    const size_t r0 = (size_t)(2 * b) * MP, r1 = (size_t)(2 * b + 1) * MP;
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+    for (int k = lane; k < len; k += 64) {
+        const int i = mode ? k : line, j = mode ? line : k;
+        const float x = S[(size_t)i * MP + j];
+        const float s0 = (x - mxo[r0 + i]) - lgo[r0 + i], s1 = (x - mxo[r1 + j]) - lgo[r1 + j];
+        const float v = (s0 + s1) + (logsigmoid(zlog[r0 + i]) + logsigmoid(zlog[r1 + j]));
+        if (v > bv) { bv = v; bi = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { bestv[(size_t)(2 * b + mode) * MP + line] = bv; besti[(size_t)(2 * b + mode) * MP + line] = bi; }
+}
+
+// filter_matches (lightglue.py:315-331) + the index mapping of pruned points (616-623): ordered by the row index
+__global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* besti, const int* ind, const int* cnt, const int* fin_pair,
+                                               int* out_pairs, float* out_scores, int* out_k, int MP, int K, float th)
+{
+    __shared__ int wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (!fin_pair[b]) return;
+    const int m = cnt[2 * b];
+    const size_t r0 = (size_t)(2 * b) * MP, r1 = (size_t)(2 * b + 1) * MP;
+    int base = 0;
+    for (int c0 = 0; c0 < m; c0 += 256) {
+        const int i = c0 + tid;
+        bool valid = false; int j = 0; float ms = 0.0f;
+        if (i < m) {
+            j = besti[r0 + i];
+            ms = expf(bestv[r0 + i]);
+            valid = (besti[r1 + j] == i) && (ms > th);
+        }
+        const unsigned long long bal = __ballot(valid);
+        const int within = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wid] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wid) wbase += wsum[w]; tot += wsum[w]; }
+        __syncthreads();
+        if (valid) {
+            const int pos = base + wbase + within;
+            out_pairs[((size_t)b * K + pos) * 2] = ind[r0 + i];
+            out_pairs[((size_t)b * K + pos) * 2 + 1] = ind[r1 + j];
+            out_scores[(size_t)b * K + pos] = ms;
+        }
+        base += tot;
+    }
+    if (tid == 0) out_k[b] = base;
+}
+
+__global__ void lg_init_out(int* out_k, int* out_stop, const int* stop, int B, int final_pass)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    if (!final_pass) out_k[b] = 0;
+    else out_stop[b] = stop[b];
+}
+
+}  // namespace
+
+// ================================================================================================ host side
+struct kpb_lg {
+    kpb_ctx* ctx = nullptr;
+    int input_dim = 256;
+    float desc_scale = 8.0f;
+    float* wdev = nullptr;
+    std::map<std::string, size_t> off;
+    kpb_buf ws;
+    float* wp(const std::string& n) { return wdev + off.at(n); }
+};
+
+namespace {
+
+struct LgNetShim : kpb_net {     // WeightStage::upload wants a kpb_net; only ctx / wdev / off are used
+    int forward(const float*, int, int, int, float*, float*) override { return KPB_E_INVALID; }
+};
+
+int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name, int cin, int cout, const float* in, int istride,
+              float* out, int ostride, int ooff, int S, int MP, const int* active)
+{
+    ConvM a;
+    a.in = in; a.out = out; a.wp = lg->wp(name + ".w"); a.bias = lg->wp(name + ".b"); a.xf = nullptr; a.active = active;
+    a.Hi = MP / 16; a.Wi = 16; a.H = MP / 16; a.W = 16;
+    a.CIN = cin; a.COUT = cout; a.NCH = cin / 32; a.relu = 0; a.nblk = (cout + 63) / 64;
+    a.istride = istride; a.ostride = ostride; a.ooff = ooff;
+    KPB_LAUNCH(ctx, tag, (conv_mfma<1, 1, 32, false, false, false, 2>), dim3(1, MP / 128, S * a.nblk), dim3(256), 0, ctx->stream, a);
+    return KPB_OK;
+}
+
+}  // namespace
+
+#define KPB_API extern "C" __attribute__((visibility("default")))
+
+KPB_API int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc_scale, kpb_lg** out)
+{
+    if (!ctx || !blob || !out) return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_create: null argument");
+    *out = nullptr;
+    KpbwBlob bl;
+    if (!bl.parse(blob, len) || bl.arch != KPB_ARCH_LIGHTGLUE) return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_lg_create: malformed .kpbw blob");
+    kpb_lg* lg = new kpb_lg();
+    lg->ctx = ctx; lg->desc_scale = desc_scale;
+    WeightStage ws;
+    auto fail = [&](const std::string& n) { delete lg; return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_lg_create: tensor %s missing or mis-shaped", n.c_str()); };
+    auto linear = [&](const std::string& key, const std::string& name, uint32_t cout, uint32_t cin) -> bool {
+        const float* w = bl.get((key + ".weight").c_str(), {cout, cin});
+        const float* b = bl.get((key + ".bias").c_str(), {cout});
+        if (!w || !b) return false;
+        ws.put(name + ".w", pack_mfma(w, (int)cout, (int)cin, 1, 32, 2));
+        ws.put(name + ".b", pad_bias(b, (int)cout, 64));
+        return true;
+    };
+    auto vec = [&](const std::string& key, const std::string& name, std::vector<uint32_t> dims) -> bool {
+        const float* v = bl.get(key.c_str(), dims);
+        if (!v) return false;
+        size_t n = 1; for (uint32_t d : dims) n *= d;
+        ws.put_raw(name, v, n);
+        return true;
+    };
+    {
+        auto it = bl.t.find("input_proj.weight");
+        if (it != bl.t.end()) {
+            lg->input_dim = (int)it->second.second[1];
+            if (lg->input_dim % 32 || !linear("input_proj", "input_proj", 256, (uint32_t)lg->input_dim)) return fail("input_proj");
+        }
+    }
+    if (!vec("posenc.Wr.weight", "posenc.Wr", {32, 2})) return fail("posenc.Wr.weight");
+    for (int i = 0; i < NL; ++i) {
+        const std::string sa = "transformers." + std::to_string(i) + ".self_attn", ca = "transformers." + std::to_string(i) + ".cross_attn";
+        const std::string L = "L" + std::to_string(i);
+        if (!linear(sa + ".Wqkv", L + ".Wqkv", 768, 256) || !linear(sa + ".out_proj", L + ".sout", 256, 256) ||
+            !linear(sa + ".ffn.0", L + ".sffn0", 512, 512) || !linear(sa + ".ffn.3", L + ".sffn3", 256, 512) ||
+            !vec(sa + ".ffn.1.weight", L + ".sln.g", {512}) || !vec(sa + ".ffn.1.bias", L + ".sln.b", {512}) ||
+            !linear(ca + ".to_qk", L + ".toqk", 256, 256) || !linear(ca + ".to_v", L + ".tov", 256, 256) || !linear(ca + ".to_out", L + ".toout", 256, 256) ||
+            !linear(ca + ".ffn.0", L + ".cffn0", 512, 512) || !linear(ca + ".ffn.3", L + ".cffn3", 256, 512) ||
+            !vec(ca + ".ffn.1.weight", L + ".cln.g", {512}) || !vec(ca + ".ffn.1.bias", L + ".cln.b", {512}))
+            return fail(L);
+        const std::string la = "log_assignment." + std::to_string(i);
+        if (!linear(la + ".final_proj", L + ".fproj", 256, 256) || !vec(la + ".matchability.weight", L + ".mw", {1, 256}) || !vec(la + ".matchability.bias", L + ".mb", {1}))
+            return fail(la);
+        if (i < NL - 1) {
+            const std::string tc = "token_confidence." + std::to_string(i) + ".token.0";
+            if (!vec(tc + ".weight", L + ".cw", {1, 256}) || !vec(tc + ".bias", L + ".cb", {1})) return fail(tc);
+        }
+    }
+    LgNetShim shim;
+    shim.ctx = ctx;
+    if (int rc = ws.upload(&shim)) { delete lg; return rc; }
+    lg->wdev = shim.wdev; lg->off = shim.off;
+    shim.wdev = nullptr;
+    *out = lg;
+    return KPB_OK;
+}
+
+KPB_API void kpb_lg_destroy(kpb_lg* lg)
+{
+    if (!lg) return;
+    (void)hipSetDevice(lg->ctx->device);
+    (void)hipStreamSynchronize(lg->ctx->stream);
+    if (lg->wdev) (void)hipFree(lg->wdev);
+    if (lg->ws.p) (void)hipFree(lg->ws.p);
+    delete lg;
+}
+
+KPB_API int kpb_lg_input_dim(const kpb_lg* lg) { return lg ? lg->input_dim : 0; }
+
+KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_dev, const int32_t* n0_dev, const int32_t* n1_dev,
+                         int batch, int max_k, const float* desc0_dev, const float* desc1_dev, int C, int Hd, int Wd,
+                         int64_t sb, int64_t sc, int64_t sh, int64_t sw, int img_w, int img_h, const kpb_lg_params* prm,
+                         int32_t* out_pairs_dev, float* out_scores_dev, int32_t* out_k_dev, int32_t* out_stop_dev)
+{
+    if (!lg) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_lg_match: null matcher");
+    kpb_ctx* ctx = lg->ctx;
+    if (!pts0_dev || !pts1_dev || !desc0_dev || !desc1_dev || !prm || !out_pairs_dev || !out_scores_dev || !out_k_dev || batch <= 0 || max_k <= 0)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_match: bad argument");
+    if (C != lg->input_dim) return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_match: descriptor maps have %d channels, the weights expect %d", C, lg->input_dim);
+    if (C > 256) return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_match: input_dim %d > 256", C);
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    const int B = batch, S = 2 * B, MP = ((max_k + 127) / 128) * 128;
+    const size_t T = (size_t)S * MP;
+    // workspace carve (floats unless noted)
+    size_t need = 0;
+    auto take = [&](size_t n) { const size_t o = need; need += (n + 63) / 64 * 64; return o; };
+    const size_t o_kpx = take(T * 2), o_cos0 = take(T * NF), o_sin0 = take(T * NF), o_cos1 = take(T * NF), o_sin1 = take(T * NF),
+                 o_din = take(T * C), o_cat0 = take(T * 512), o_cat1 = take(T * 512), o_qkv = take(T * 768), o_q = take(T * D), o_k = take(T * D),
+                 o_v = take(T * D), o_ctx = take(T * D), o_h1 = take(T * 512), o_y = take(T * D), o_conf = take(T), o_msc = take(T), o_z = take(T),
+                 o_md = take(T * D), o_sim = take((size_t)B * MP * MP), o_mx = take(T), o_lg = take(T), o_bv = take(T),
+                 o_ind0 = take(T), o_ind1 = take(T), o_dst = take(T), o_bi = take(T), o_ints = take((size_t)8 * S + 64);
+    const bool fresh = need * sizeof(float) > lg->ws.cap;
+    if (int rc = kpb_reserve(ctx, lg->ws, need * sizeof(float))) return rc;
+    float* base = static_cast<float*>(lg->ws.p);
+    hipStream_t st = ctx->stream;
+    if (fresh) KPB_HIP(ctx, hipMemsetAsync(base, 0, need * sizeof(float), st));   // padded rows must stay finite
+    float *kpx = base + o_kpx, *cosb[2] = {base + o_cos0, base + o_cos1}, *sinb[2] = {base + o_sin0, base + o_sin1}, *din = base + o_din,
+          *cat[2] = {base + o_cat0, base + o_cat1}, *qkv = base + o_qkv, *q = base + o_q, *k = base + o_k, *v = base + o_v, *cx = base + o_ctx,
+          *h1 = base + o_h1, *y = base + o_y, *conf = base + o_conf, *msc = base + o_msc, *zlog = base + o_z, *md = base + o_md, *sim = base + o_sim,
+          *mxo = base + o_mx, *lgo = base + o_lg, *bestv = base + o_bv;
+    int *ind[2] = {reinterpret_cast<int*>(base + o_ind0), reinterpret_cast<int*>(base + o_ind1)}, *dst = reinterpret_cast<int*>(base + o_dst),
+        *besti = reinterpret_cast<int*>(base + o_bi), *ints = reinterpret_cast<int*>(base + o_ints);
+    int *cnt = ints, *cnt_orig = ints + S, *newcnt = ints + 2 * S, *active_seq = ints + 3 * S, *fin_seq = ints + 4 * S, *active_pair = ints + 5 * S,
+        *fin_pair = ints + 5 * S + B, *stop = ints + 6 * S;
+
+    KPB_LAUNCH(ctx, "lg_init_out", lg_init_out, dim3(cdiv(B, 256)), dim3(256), 0, st, out_k_dev, out_stop_dev, stop, B, 0);
+    PrepArgs pa{pts0_dev, pts1_dev, n0_dev, n1_dev, lg->wp("posenc.Wr"), kpx, cosb[0], sinb[0], ind[0], cnt, cnt_orig, active_seq, active_pair, stop,
+                max_k, MP, (float)(img_w - 1), (float)(img_h - 1)};
+    KPB_LAUNCH(ctx, "lg_prepare", lg_prepare, dim3(S), dim3(256), 0, st, pa);
+    SampleArgs sa{desc0_dev, desc1_dev, sb, sc, sh, sw, kpx, cnt, din, C, Hd, Wd, MP, lg->desc_scale};
+    KPB_LAUNCH(ctx, "lg_sample", lg_sample, dim3(cdiv(max_k, 4), S), dim3(256), 0, st, sa);
+    int rc;
+    if (lg->off.count("input_proj.w")) {
+        if ((rc = lg_linear(ctx, lg, "lg_input_proj", "input_proj", C, 256, din, C, cat[0], 512, 0, S, MP, active_seq))) return rc;
+    } else {
+        KPB_HIP(ctx, hipMemcpy2DAsync(cat[0], 512 * sizeof(float), din, 256 * sizeof(float), 256 * sizeof(float), T, hipMemcpyDeviceToDevice, st));
+    }
+    const dim3 tokgrid4(cdiv(max_k, 4), S), tokgrid64(cdiv(max_k * 64, 256), S);
+    auto ffn = [&](const std::string& L, const char* pfx, float* c) -> int {     // x + ffn(cat([x, msg])), lightglue.py:185 / 241-242
+        int r;
+        if ((r = lg_linear(ctx, lg, "lg_ffn0", L + pfx + "ffn0", 512, 512, c, 512, h1, 512, 0, S, MP, active_seq))) return r;
+        KPB_LAUNCH(ctx, "lg_ln_gelu", lg_ln_gelu, tokgrid4, dim3(256), 0, st, h1, lg->wp(L + (pfx[1] == 's' ? ".sln.g" : ".cln.g")),
+                   lg->wp(L + (pfx[1] == 's' ? ".sln.b" : ".cln.b")), cnt, active_seq, MP);
+        if ((r = lg_linear(ctx, lg, "lg_ffn3", L + pfx + "ffn3", 512, 256, h1, 512, y, 256, 0, S, MP, active_seq))) return r;
+        KPB_LAUNCH(ctx, "lg_residual", lg_residual, tokgrid64, dim3(256), 0, st, c, y, cnt, active_seq, MP);
+        return KPB_OK;
+    };
+    for (int i = 0; i < NL; ++i) {
+        const std::string L = "L" + std::to_string(i);
+        float* c = cat[i & 1];
+        float *cs = cosb[i & 1], *sn = sinb[i & 1];
+        // self attention (lightglue.py:173-185)
+        if ((rc = lg_linear(ctx, lg, "lg_Wqkv", L + ".Wqkv", 256, 768, c, 512, qkv, 768, 0, S, MP, active_seq))) return rc;
+        KPB_LAUNCH(ctx, "lg_rotary", lg_rotary, dim3(cdiv(max_k * 128, 256), S), dim3(256), 0, st, qkv, cs, sn, q, k, v, cnt, active_seq, MP);
+        FlashArgs fa{q, k, v, cx, cnt, active_seq, MP, 0, 0.125f};
+        KPB_LAUNCH(ctx, "lg_flash_self", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
+        if ((rc = lg_linear(ctx, lg, "lg_out_proj", L + ".sout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq))) return rc;
+        if ((rc = ffn(L, ".s", c))) return rc;
+        // cross attention (lightglue.py:216-243)
+        if ((rc = lg_linear(ctx, lg, "lg_to_qk", L + ".toqk", 256, 256, c, 512, q, 256, 0, S, MP, active_seq))) return rc;
+        if ((rc = lg_linear(ctx, lg, "lg_to_v", L + ".tov", 256, 256, c, 512, v, 256, 0, S, MP, active_seq))) return rc;
+        FlashArgs fc{q, q, v, cx, cnt, active_seq, MP, 1, 0.125f};
+        KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
+        if ((rc = lg_linear(ctx, lg, "lg_to_out", L + ".toout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq))) return rc;
+        if ((rc = ffn(L, ".c", c))) return rc;
+        // confidences, stop / prune decision (lightglue.py:557-579)
+        const bool last = i == NL - 1;
+        KPB_LAUNCH(ctx, "lg_conf", lg_conf, tokgrid4, dim3(256), 0, st, c, last ? lg->wp(L + ".mw") : lg->wp(L + ".cw"), last ? lg->wp(L + ".mb") : lg->wp(L + ".cb"),
+                   lg->wp(L + ".mw"), lg->wp(L + ".mb"), conf, msc, zlog, cnt, active_seq, MP, last ? 0 : 1);
+        const double thr = std::min(std::max(0.8 + 0.1 * std::exp(-4.0 * i / NL), 0.0), 1.0);
+        DecideArgs da{conf, msc, cnt, cnt_orig, newcnt, dst, active_pair, active_seq, fin_pair, fin_seq, stop, MP, i, prm->prune_min_kpts,
+                      (float)thr, prm->depth_confidence, (float)(1.0 - (double)prm->width_confidence), prm->depth_confidence > 0 ? 1 : 0,
+                      prm->width_confidence > 0 ? 1 : 0};
+        KPB_LAUNCH(ctx, "lg_decide", lg_decide, dim3(B), dim3(256), 0, st, da);
+        // assignment for the pairs that finish at this layer (lightglue.py:606-614)
+        if ((rc = lg_linear(ctx, lg, "lg_final_proj", L + ".fproj", 256, 256, c, 512, md, 256, 0, S, MP, fin_seq))) return rc;
+        KPB_LAUNCH(ctx, "lg_sim", lg_sim, dim3(cdiv(max_k, 128), cdiv(max_k, 32), B), dim3(256), 0, st, md, sim, cnt, fin_pair, MP);
+        KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, cnt, fin_pair, MP, 0);
+        KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, cnt, fin_pair, MP, 1);
+        KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, zlog, bestv, besti, cnt, fin_pair, MP, 0);
+        KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, zlog, bestv, besti, cnt, fin_pair, MP, 1);
+        KPB_LAUNCH(ctx, "lg_emit", lg_emit, dim3(B), dim3(256), 0, st, bestv, besti, ind[i & 1], cnt, fin_pair, out_pairs_dev, out_scores_dev, out_k_dev,
+                   MP, max_k, prm->filter_threshold);
+        if (!last) {
+            KPB_LAUNCH(ctx, "lg_gather", lg_gather, tokgrid64, dim3(256), 0, st, c, cat[(i + 1) & 1], cs, sn, cosb[(i + 1) & 1], sinb[(i + 1) & 1],
+                       ind[i & 1], ind[(i + 1) & 1], dst, cnt, active_seq, MP);
+            KPB_LAUNCH(ctx, "lg_commit_counts", lg_commit_counts, dim3(cdiv(S, 256)), dim3(256), 0, st, cnt, newcnt, active_seq, S);
+        }
+    }
+    if (out_stop_dev) KPB_LAUNCH(ctx, "lg_init_out", lg_init_out, dim3(cdiv(B, 256)), dim3(256), 0, st, out_k_dev, out_stop_dev, stop, B, 1);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}

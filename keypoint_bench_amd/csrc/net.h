@@ -45,8 +45,10 @@ struct KpbwBlob {
             std::vector<uint32_t> d(r.dims, r.dims + r.ndim);
             for (uint32_t v : d) cnt *= v;
             if (base + 4 * ((size_t)r.off + cnt) > len) return false;
-            r.name[39] = 0;
-            t[r.name] = {reinterpret_cast<const float*>(p + base + 4 * (size_t)r.off), d};
+            char nm[41];                      // names may fill all 40 bytes of the field (no terminator then)
+            memcpy(nm, r.name, 40);
+            nm[40] = 0;
+            t[nm] = {reinterpret_cast<const float*>(p + base + 4 * (size_t)r.off), d};
         }
         return true;
     }

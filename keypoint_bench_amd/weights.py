@@ -16,6 +16,7 @@ ARCH_ALIKE = 1
 ARCH_SUPERPOINT = 2
 ARCH_XFEAT = 3
 ARCH_DISK = 4
+ARCH_LIGHTGLUE = 5
 _REC = struct.Struct("<40sI4II")
 
 
@@ -25,6 +26,7 @@ def pack(tensors: dict, arch: int) -> bytes:
     for n in names:
         a = np.ascontiguousarray(np.asarray(tensors[n], dtype=np.float32))
         dims = list(a.shape) + [1] * (4 - a.ndim)
+        assert len(n.encode()) <= 40, "tensor name longer than the 40-byte field: " + n
         recs.append(_REC.pack(n.encode(), a.ndim, *dims, off))
         payload.append(a.tobytes())
         off += a.size
@@ -196,4 +198,73 @@ def random_disk_state_dict(seed: int) -> dict:
     for name, key, cin, cout in DISK_BLOCKS:
         conv(key, cout, cin)
         sd[key + ".1.weight"] = rng.uniform(0.1, 0.4, size=(cin,)).astype(np.float32)
+    return sd
+
+
+LG_LAYERS = 9
+
+
+def tensors_lightglue(sd) -> dict:
+    """state_dict of LightGlue (models/lightglue.py:392-409) -> fp32 tensors under the reference's own names; old
+    checkpoints' self_attn.{i} / cross_attn.{i} keys are renamed as the reference does at load time (427-433)."""
+    t = {}
+    for k, v in sd.items():
+        for i in range(LG_LAYERS):
+            if not k.startswith("transformers."):
+                k = k.replace("self_attn.%d" % i, "transformers.%d.self_attn" % i)
+                k = k.replace("cross_attn.%d" % i, "transformers.%d.cross_attn" % i)
+        if k == "confidence_thresholds" or k.endswith("inner_attn") or not hasattr(v, "shape"):
+            continue
+        t[k] = _np(v).astype(np.float32)
+    return t
+
+
+def random_lightglue_state_dict(seed: int, input_dim: int = 256, variant: str = "plain") -> dict:
+    """Seeded stand-in for the absent superpoint_lightglue / disk_lightglue checkpoints.  The transformer is a
+    damped random network (its residual branches are scaled down so descriptors stay close to their input) and
+    final_proj is near a scaled identity, so that corresponding keypoints of a synthetic pair really match.
+      plain  : no layer is confident -> all nine layers run, nothing is pruned
+      stop   : token confidence saturates from layer 2 on -> check_if_stop fires (lightglue.py:670-681)
+      prune  : token confidence and matchability are bimodal at layers 0-3 -> get_pruning_mask drops points (659-668)"""
+    rng = np.random.default_rng(seed)
+    sd = {}
+
+    def lin(name, co, ci, scale=1.0, bias=0.02):
+        b = np.sqrt(3.0 / ci) * scale
+        sd[name + ".weight"] = rng.uniform(-b, b, size=(co, ci)).astype(np.float32)
+        sd[name + ".bias"] = rng.uniform(-bias, bias, size=(co,)).astype(np.float32)
+
+    if input_dim != 256:
+        lin("input_proj", 256, input_dim, 1.0)
+    sd["posenc.Wr.weight"] = rng.normal(0, 1.0, size=(32, 2)).astype(np.float32)
+    for i in range(LG_LAYERS):
+        for blk, names in (("self_attn", (("Wqkv", 768, 256, 1.0), ("out_proj", 256, 256, 0.3))),
+                           ("cross_attn", (("to_qk", 256, 256, 1.0), ("to_v", 256, 256, 1.0), ("to_out", 256, 256, 0.3)))):
+            p = "transformers.%d.%s" % (i, blk)
+            for n, co, ci, sc in names:
+                lin(p + "." + n, co, ci, sc)
+            lin(p + ".ffn.0", 512, 512, 1.0)
+            sd[p + ".ffn.1.weight"] = rng.uniform(0.8, 1.2, size=(512,)).astype(np.float32)
+            sd[p + ".ffn.1.bias"] = rng.uniform(-0.1, 0.1, size=(512,)).astype(np.float32)
+            lin(p + ".ffn.3", 256, 512, 0.15)
+        p = "log_assignment.%d" % i
+        sd[p + ".final_proj.weight"] = (10.0 * np.eye(256) + rng.normal(0, 0.05, size=(256, 256))).astype(np.float32)
+        sd[p + ".final_proj.bias"] = rng.uniform(-0.02, 0.02, size=(256,)).astype(np.float32)
+        sd[p + ".matchability.weight"] = rng.normal(0, 0.05, size=(1, 256)).astype(np.float32)
+        sd[p + ".matchability.bias"] = np.array([3.0], np.float32)
+        if i < LG_LAYERS - 1:
+            p = "token_confidence.%d.token.0" % i
+            sd[p + ".weight"] = rng.normal(0, 0.05, size=(1, 256)).astype(np.float32)
+            sd[p + ".bias"] = np.array([-1.0], np.float32)
+    if variant == "stop":
+        for i in range(2, LG_LAYERS - 1):
+            sd["token_confidence.%d.token.0.bias" % i] = np.array([6.0], np.float32)
+    elif variant == "prune":
+        for i in range(0, 4):
+            sd["token_confidence.%d.token.0.weight" % i] = rng.normal(0, 4.0, size=(1, 256)).astype(np.float32)
+            sd["token_confidence.%d.token.0.bias" % i] = np.array([0.0], np.float32)
+            sd["log_assignment.%d.matchability.weight" % i] = rng.normal(0, 4.0, size=(1, 256)).astype(np.float32)
+            sd["log_assignment.%d.matchability.bias" % i] = np.array([0.0], np.float32)
+    elif variant != "plain":
+        raise ValueError(variant)
     return sd
