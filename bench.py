@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
+    ap.add_argument("--matcher", default="brute_force", choices=["brute_force", "lightglue"],
+                    help="lightglue = BASELINE configs[4] (with --model disk or superpoint), seeded stand-in weights")
     ap.add_argument("--model", default="alike", choices=["alike", "superpoint", "xfeat", "disk"],
                     help="alike = BASELINE configs[1] (the headline); superpoint = configs[2] with seeded random weights")
     args = ap.parse_args()
@@ -178,7 +180,14 @@ def main():
             B = 4
     else:
         net = alike_t(dense_descriptors=not args.sparse).eval()
-    pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
+    lg = None
+    if args.matcher == "lightglue":
+        from keypoint_bench_amd import weights as kw
+        from keypoint_bench_amd.models.lightglue import LightGlue
+        dim, scale = {"disk": (128, 1), "superpoint": (256, 8)}[args.model]
+        lg = LightGlue(features=None, desc_scale=scale)
+        lg.load_state_dict(kw.random_lightglue_state_dict(31, dim, "plain"))
+    pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev, lightglue=lg)
     # synthetic pairs, different per rank, resident in HBM
     nd = min(args.distinct, B)
     v0s, v1s = zip(*[synthetic.image_pair(rank * 1000 + i, H, W) for i in range(nd)])
@@ -252,7 +261,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"alike": "ALIKE-t", "superpoint": "SuperPoint", "xfeat": "XFeat", "disk": "DISK"}[args.model] + " extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
                                    "(euclidean fp64, max_distance=5, cross_check), 640x480 pairs [BASELINE configs[1]]",
-                       "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
+                       "matcher": args.matcher, "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),

@@ -15,7 +15,7 @@ from ._lib import Context, DetectParams, MatchParams, ptr
 
 
 class PairPipeline:
-    def __init__(self, net, extractor_params, brute_force_params, batch, H, W, device="cuda:0"):
+    def __init__(self, net, extractor_params, brute_force_params, batch, H, W, device="cuda:0", lightglue=None):
         self.net, self.B, self.H, self.W = net, int(batch), int(H), int(W)
         self.device = torch.device(device)
         self.ctx = Context.get(self.device)
@@ -46,6 +46,13 @@ class PairPipeline:
         self.m1 = torch.empty((self.B, K, 3), dtype=f32, device=dev)
         self.C = C
         self.reruns = 0
+        self.lg = lightglue          # a keypoint_bench_amd.models.lightglue.LightGlue: replaces the brute-force matcher
+        if self.lg is not None:
+            if self.desc is None:
+                raise ValueError("the LightGlue matcher samples the dense descriptor map")
+            self.lg._ensure(self.device)
+            self.lg_scores = torch.empty((self.B, K), dtype=f32, device=dev)
+            self.lg_stop = torch.empty((self.B,), dtype=i32, device=dev)
         net._ensure(self.device)
 
     def enqueue(self, images):
@@ -62,6 +69,17 @@ class PairPipeline:
     def _enqueue_match(self):
         ctx, L, net = self.ctx, self.ctx.lib, self.net
         B, B2, K, C, H, W = self.B, 2 * self.B, self.top_k, self.C, self.H, self.W
+        if self.lg is not None:     # FundamentalMatrix.py:132-133 / visual_odometer.py:60-61: matcher.match(kps0, kps1, desc0, desc1, {'w','h'})
+            from ._lib import LgParams
+            lg, Hd, Wd = self.lg, self.Hd, self.Wd
+            prm = LgParams(float(lg.conf["depth_confidence"]), float(lg.conf["width_confidence"]), float(lg.conf["filter_threshold"]),
+                           lg.prune_min_kpts)
+            ctx.check(L.kpb_lg_match(lg._handle, ptr(self.kps[:B]), ptr(self.kps[B:]), ptr(self.n[:B]), ptr(self.n[B:]), B, K,
+                                     ptr(self.desc[:B]), ptr(self.desc[B:]), C, Hd, Wd, Hd * Wd * C, 1, Wd * C, C, W, H, ctypes.byref(prm),
+                                     ptr(self.pairs), ptr(self.lg_scores), ptr(self.k), ptr(self.lg_stop)))
+            ctx.check(L.kpb_gather_rows(ctx.handle, ptr(self.kps[:B]), B, K, 3, ptr(self.pairs), K, 2, 0, ptr(self.k), ptr(self.m0)))
+            ctx.check(L.kpb_gather_rows(ctx.handle, ptr(self.kps[B:]), B, K, 3, ptr(self.pairs), K, 2, 1, ptr(self.k), ptr(self.m1)))
+            return
         if self.desc is not None:   # utils/matcher.py:221-226 on the dense map (channels-last strides)
             Hd, Wd = self.Hd, self.Wd
             ctx.check(L.kpb_sample(ctx.handle, ptr(self.desc), B2, C, Hd, Wd, Hd * Wd * C, 1, Wd * C, C, ptr(self.kps), 3, K,
