@@ -16,13 +16,10 @@
 //                  v_mfma_f32_32x32x2_f32 with the A operand taken straight from the registers that
 //                  built f (K permuted so lane (p,h) owns channels 32h..32h+31) and B resident in VGPRs
 //   alike_desc_at  descriptors at keypoints only: bilinear taps on f, then one 64x64 mat-vec
-#include "net.h"
+#include "conv_mfma.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float relu(float v) { return fmaxf(v, 0.0f); }
 
 // ------------------------------------------------------------------------------------------------ block1
 constexpr int B1_TH = 32, B1_TW = 32;
@@ -115,25 +112,24 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[q][j] = a.b2[j];
 #pragma unroll 1
-    for (int ky = 0; ky < 3; ++ky) {
-        float v[6][8];
+    for (int tap = 0; tap < 9; ++tap) {   // rolled: 64 scalar-loaded weights live per trip; no runtime-indexed registers
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        float v[4][8];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const float4 lo = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + k][0]);
-            const float4 hi = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + k][4]);
-            v[k][0] = lo.x; v[k][1] = lo.y; v[k][2] = lo.z; v[k][3] = lo.w;
-            v[k][4] = hi.x; v[k][5] = hi.y; v[k][6] = hi.z; v[k][7] = hi.w;
+        for (int q = 0; q < 4; ++q) {
+            const float4 lo = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx + q][0]);
+            const float4 hi = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx + q][4]);
+            v[q][0] = lo.x; v[q][1] = lo.y; v[q][2] = lo.z; v[q][3] = lo.w;
+            v[q][4] = hi.x; v[q][5] = hi.y; v[q][6] = hi.z; v[q][7] = hi.w;
         }
-#pragma unroll 1
-        for (int kx = 0; kx < 3; ++kx)   // rolled: 64 scalar-loaded weights live per trip
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float w = a.w2[((ky * 3 + kx) * 8 + c) * 8 + j];
+            for (int j = 0; j < 8; ++j) {
+                const float w = a.w2[(tap * 8 + c) * 8 + j];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q][j] = fmaf(v[kx + q][c], w, acc[q][j]);
-                }
+                for (int q = 0; q < 4; ++q) acc[q][j] = fmaf(v[q][c], w, acc[q][j]);
+            }
     }
     // stage the 32x32x8 result through LDS (the mid tile is dead now) so that every wave store
     // instruction writes one whole 1 KiB pixel row segment instead of 64 scattered 16-byte pieces
