@@ -161,12 +161,13 @@ struct ConvArgs {
     const float* res_in; // RES: [B][H*RPOOL][W*RPOOL][CDS]
     const float* ds_w;   // [CDS][COUT]
     const float* ds_b;   // [COUT]
+    float* res_out;      // DSOUT: [B][H][W][COUT] identity branch ds(pooled input) + ds_b, written for the block's conv2
     int H, W;            // output size
 };
 
 // Each thread: one pixel x 16 output channels.  Waves split into COUT/16 channel groups and
 // 4/(COUT/16) pixel groups of 4x16 pixels; weights are wave-uniform -> scalar loads.
-template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool RELU>
+template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool RELU, bool DSOUT = false>
 __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
 {
     constexpr int G = COUT / 16, PG = 4 / G, TH = 4 * PG, TW = 16, C4 = CIN / 4;
@@ -223,6 +224,26 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
             }
         }
     if (gy >= a.H || gx >= a.W) return;
+    if (DSOUT) {   // the block's identity branch (ALike.py:76-77) from the pooled centre pixel already staged in LDS
+        float ds[16];
+        const float* db = a.ds_b + cg * 16;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) ds[j] = db[j];
+        const float* t = &tile[((row + 1) * (TW + 2) + col + 1) * CIN];
+        const float* dw = a.ds_w + cg * 16;
+#pragma unroll 2
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(t + c4 * 4);
+            const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) ds[j] = fmaf(v[c], dw[(c4 * 4 + c) * COUT + j], ds[j]);
+        }
+        float* ro = a.res_out + ((size_t)b * a.H * a.W + (size_t)gy * a.W + gx) * COUT + cg * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(ro + 4 * q) = make_float4(ds[4 * q], ds[4 * q + 1], ds[4 * q + 2], ds[4 * q + 3]);
+    }
     if (RES) {   // identity = downsample(x): 1x1 conv (with bias) on the block input (ALike.py:76-77)
         constexpr int D4 = CDS / 4;
         const int Hr = a.H * RPOOL, Wr = a.W * RPOOL;
@@ -294,6 +315,7 @@ struct HeadArgs {
     float* score;      // [B][H][W]
     float* desc;       // [B][H][W][64] or null
     int H, W;
+    int stagger;
 };
 
 constexpr int HEAD_TILES = 4;   // 32-pixel tiles per wave
@@ -350,6 +372,12 @@ __global__ __launch_bounds__(256) void alike_head(HeadArgs a)
     const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
     const int tiles_per_row = a.W / 32, ntiles = a.H * tiles_per_row;
     const int tile0 = (blockIdx.x * 4 + wv) * HEAD_TILES;
+    if (DENSE) {
+        // All workgroups do identical work, so the waves that share a SIMD would march in lockstep (all in their VALU
+        // phase, then all queueing for the matrix pipe).  A one-off start offset per workgroup de-phases them.
+        const int ph = __builtin_amdgcn_readfirstlane(a.stagger ? (int)((blockIdx.x * 5u) & 7u) : 0);
+        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     for (int t = 0; t < HEAD_TILES; ++t) {
         const int tile = tile0 + t;
@@ -476,6 +504,7 @@ struct AlikeNet : kpb_net {
         h.x1 = x1; h.a2 = a2; h.a3 = a3; h.a4 = a4;
         h.agg1 = wp("agg1.w"); h.whT = wp("head.wT"); h.wsc = wp("head.ws");
         h.score = score; h.desc = desc; h.H = H; h.W = W;
+        h.stagger = getenv("KPB_HEAD_STAGGER") ? atoi(getenv("KPB_HEAD_STAGGER")) : 1;
         return h;
     }
     int forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev) override;
@@ -498,11 +527,11 @@ void transpose(const float* w, int co, int ci, std::vector<float>& out)
         for (int c = 0; c < ci; ++c) out[(size_t)c * co + o] = w[(size_t)o * ci + c];
 }
 
-template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL>
+template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool DSOUT = false>
 void launch_conv(kpb_ctx* ctx, const char* name, hipStream_t st, const ConvArgs& a, int B)
 {
     constexpr int G = COUT / 16, TH = 4 * (4 / G), TW = 16;
-    KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
+    KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true, DSOUT>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
 }
 
 int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev)
@@ -513,13 +542,15 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     const size_t P = (size_t)H * W, B = batch;
     const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
                  n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
-    const size_t total = n_x1 + 3 * n_2 + 2 * n_3 + n_a3 + 2 * n_4 + n_a4;
+    const size_t total = n_x1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
     t2 = p; p += n_2; x2 = p; p += n_2; a2 = p; p += n_2;
     t3 = p; p += n_3; x3 = p; p += n_3; a3 = p; p += n_a3;
     t4 = p; p += n_4; x4 = p; p += n_4; a4 = p; p += n_a4;
+    float* r3 = p; p += n_3;
+    float* r4 = p; p += n_4;
     this->B = batch; this->H = H; this->W = W;
     hipStream_t st = ctx->stream;
 
@@ -528,20 +559,30 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
 
     ConvArgs c;
     // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
-    c = ConvArgs{x1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, H / 2, W / 2};
+    c = ConvArgs{x1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};
     launch_conv<8, 16, 2, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
-    c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), x1, wp("b2ds.w"), wp("b2ds.b"), H / 2, W / 2};
+    c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), x1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
     launch_conv<16, 16, 1, true, 8, 2>(ctx, "conv3x3_b2c2", st, c, batch);
     // block3 @ H/8 (141-142): pool4
-    c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, nullptr, nullptr, H / 8, W / 8};
-    launch_conv<16, 32, 4, false, 4, 1>(ctx, "conv3x3_b3c1", st, c, batch);
-    c = ConvArgs{t3, x3, wp("b3c2.w"), wp("b3c2.b"), x2, wp("b3ds.w"), wp("b3ds.b"), H / 8, W / 8};
-    launch_conv<32, 32, 1, true, 16, 4>(ctx, "conv3x3_b3c2", st, c, batch);
+    c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
+    launch_conv<16, 32, 4, false, 4, 1, true>(ctx, "conv3x3_b3c1", st, c, batch);
+    {   // conv2 of block3 on the MFMA kernel, identity branch precomputed (ALike.py:72-80)
+        ConvM m;
+        m.in = t3; m.out = x3; m.wp = wp("b3c2.wp"); m.bias = wp("b3c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r3;
+        m.Hi = H / 8; m.Wi = W / 8; m.H = H / 8; m.W = W / 8; m.CIN = 32; m.COUT = 32; m.NCH = 1; m.relu = 0; m.nblk = 1;
+        m.istride = 32; m.ostride = 32; m.ooff = 0;
+        KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+    }
     // block4 @ H/32 (143-144): pool4
-    c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, nullptr, nullptr, H / 32, W / 32};
-    launch_conv<32, 64, 4, false, 4, 1>(ctx, "conv3x3_b4c1", st, c, batch);
-    c = ConvArgs{t4, x4, wp("b4c2.w"), wp("b4c2.b"), x3, wp("b4ds.w"), wp("b4ds.b"), H / 32, W / 32};
-    launch_conv<64, 64, 1, true, 32, 4>(ctx, "conv3x3_b4c2", st, c, batch);
+    c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, wp("b4ds.w"), wp("b4ds.b"), r4, H / 32, W / 32};
+    launch_conv<32, 64, 4, false, 4, 1, true>(ctx, "conv3x3_b4c1", st, c, batch);
+    {
+        ConvM m;
+        m.in = t4; m.out = x4; m.wp = wp("b4c2.wp"); m.bias = wp("b4c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r4;
+        m.Hi = H / 32; m.Wi = W / 32; m.H = H / 32; m.W = W / 32; m.CIN = 64; m.COUT = 64; m.NCH = 2; m.relu = 0; m.nblk = 1;
+        m.istride = 64; m.ostride = 64; m.ooff = 0;
+        KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+    }
     // aggregation 1x1 + ReLU (147-150); agg1 is fused into the head
     KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), B * P / 4);
     KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), B * P / 64);
@@ -605,6 +646,10 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         snprintf(nm, 16, "b%dds.w", i); transpose(bl.get(nm, {co, ci}), co, ci, tmp); ws.put(nm, tmp);
         snprintf(nm, 16, "b%dds.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
     }
+    ws.put("b3c2.wp", pack_mfma(bl.get("b3c2.w", {c3, c3, 3, 3}), 32, 32, 3, 32, 1));
+    ws.put("b3c2.bp", pad_bias(bl.get("b3c2.b", {c3}), 32, 32));
+    ws.put("b4c2.wp", pack_mfma(bl.get("b4c2.w", {c4, c4, 3, 3}), 64, 64, 3, 32, 2));
+    ws.put("b4c2.bp", pad_bias(bl.get("b4c2.b", {c4}), 64, 64));
     for (int i = 1; i <= 4; ++i) {
         char nm[16];
         snprintf(nm, 16, "agg%d.w", i);

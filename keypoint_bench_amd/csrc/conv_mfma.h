@@ -16,6 +16,7 @@ struct ConvM {
     const float* bias;  // [COUTP] (zero padded)
     const float* xf;    // XF: [B][CIN][4] = (scale, shift, prelu slope, -) applied to the input before zero padding
     const int* active;  // optional [B]: batch items with 0 are skipped (LightGlue pairs that stopped early)
+    const float* res;   // optional [B][H][W][COUT] added before the ReLU (ALIKE ResBlock identity branch, ALike.py:76-79)
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
     int istride, ostride, ooff;   // floats between consecutive input / output pixels, channel offset of the output
 };
@@ -120,11 +121,19 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
         if (co >= a.COUT) continue;
         if (!POOL_OUT) {
             float* out = a.out + (size_t)b * a.H * a.W * a.ostride + a.ooff;
+            const float* res = a.res ? a.res + (size_t)b * a.H * a.W * a.COUT : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int gy = ty0 + 2 * wv + (i >> 4), gx = tx0 + (i & 15);
-                if (gy < a.H && gx < a.W) out[((size_t)gy * a.W + gx) * a.ostride + co] = v[r];
+                if (gy < a.H && gx < a.W) {
+                    float o = v[r];
+                    if (res) {      // residual path: v holds conv + bias (a.relu is 0), the ReLU comes after the sum
+                        o += res[((size_t)gy * a.W + gx) * a.COUT + co];
+                        o = relu(o);
+                    }
+                    out[((size_t)gy * a.W + gx) * a.ostride + co] = o;
+                }
             }
         } else {
             const int Ho = a.H / 2, Wo = a.W / 2;

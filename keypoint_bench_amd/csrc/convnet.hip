@@ -261,7 +261,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
     ConvM a;
-    a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf;
+    a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf; a.res = nullptr;
     a.active = nullptr; a.istride = L.cin; a.ostride = L.cout; a.ooff = 0;
     a.Hi = Hi; a.Wi = Wi;
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;

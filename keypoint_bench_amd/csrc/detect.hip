@@ -601,7 +601,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.tchg_cur = p.tchg[s & 1];
         a.lastchg = p.lastchg; a.negflag = p.negflag;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
-        a.sweep = s; a.max_local = 64;
+        a.sweep = s; a.max_local = env_int("KPB_NMS_MAXLOCAL", 64);
         const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
         switch (r) {
         case 1: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<1>, grid, block, 0, ctx->stream, a); break;
@@ -651,7 +651,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx,
     NmsPlan p;
     if (int rc = nms_plan(ctx, batch, H, W, nms_dist, p)) return rc;
     KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
-    const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+    const int chunk = env_int("KPB_NMS_SWEEPS", 6);
     int run = 0, pending = 1, neg = 0;
     while (pending) {
         if (int rc = nms_launch(ctx, p, score_dev, out_map_dev, batch, H, W, nms_dist, run, chunk)) return rc;
@@ -715,7 +715,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
         if (int rc = kpb_reserve(ctx, ctx->ws_nms_map, (size_t)batch * P * sizeof(float))) return rc;
         d.cur = static_cast<float*>(ctx->ws_nms_map.p);
         KPB_HIP(ctx, hipMemsetAsync(d.plan.lastchg, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
-        const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+        const int chunk = env_int("KPB_NMS_SWEEPS", 6);
         if (int rc = nms_launch(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, 0, chunk)) return rc;
         d.sweeps_run = chunk;
     }
@@ -737,7 +737,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
         ctx->det_pending = 0;
         return KPB_OK;
     }
-    const int chunk = env_int("KPB_NMS_SWEEPS", 8);
+    const int chunk = env_int("KPB_NMS_SWEEPS", 6);
     int rerun = 0;
     for (;;) {
         int pending = 0, neg = 0;

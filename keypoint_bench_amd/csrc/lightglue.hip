@@ -539,7 +539,7 @@ int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name
               float* out, int ostride, int ooff, int S, int MP, const int* active)
 {
     ConvM a;
-    a.in = in; a.out = out; a.wp = lg->wp(name + ".w"); a.bias = lg->wp(name + ".b"); a.xf = nullptr; a.active = active;
+    a.in = in; a.out = out; a.wp = lg->wp(name + ".w"); a.bias = lg->wp(name + ".b"); a.xf = nullptr; a.res = nullptr; a.active = active;
     a.Hi = MP / 16; a.Wi = 16; a.H = MP / 16; a.W = 16;
     a.CIN = cin; a.COUT = cout; a.NCH = cin / 32; a.relu = 0; a.nblk = (cout + 63) / 64;
     a.istride = istride; a.ostride = ostride; a.ooff = ooff;
