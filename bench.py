@@ -160,8 +160,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X GPU; keypoint_bench_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ        # under torchrun the RCCL path is exercised even at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.pairs_per_step
@@ -196,7 +198,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -208,7 +210,7 @@ def main():
         pipe.run(images)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -216,7 +218,7 @@ def main():
 
     # end-of-run exchange: fixed-width per-pair rows [n0, n1, matches], one RCCL all-gather
     rows = torch.stack([pipe.n[:B].float(), pipe.n[B:].float(), pipe.k.float()], dim=1).contiguous()
-    if world > 1:
+    if use_dist:
         allrows = torch.empty((world * B, 3), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allrows, rows)
     else:
@@ -269,7 +271,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
