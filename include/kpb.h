@@ -64,6 +64,8 @@ const char* kpb_last_error(const kpb_ctx* ctx);
 /* device = HIP device ordinal; stream = hipStream_t to enqueue on (NULL = the default stream).
  * Pass torch.cuda.current_stream().cuda_stream to order against torch work. */
 int kpb_ctx_create(int device, void* stream, kpb_ctx** out);
+/* Re-targets the context (after synchronising the old stream), e.g. when torch's current stream changed. */
+int kpb_ctx_set_stream(kpb_ctx* ctx, void* stream);
 void kpb_ctx_destroy(kpb_ctx* ctx);
 int kpb_sync(kpb_ctx* ctx);
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "kpb_version": (c_int, []),
     "kpb_last_error": (ctypes.c_char_p, [c_void_p]),
     "kpb_ctx_create": (c_int, [c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "kpb_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "kpb_ctx_destroy": (None, [c_void_p]),
     "kpb_sync": (c_int, [c_void_p]),
     "kpb_prof_enable": (c_int, [c_void_p, c_int]),
@@ -97,6 +98,7 @@ class Context:
         self.lib = load()
         self.device_index = device_index
         stream = torch.cuda.current_stream(device_index).cuda_stream
+        self.stream = stream
         h = c_void_p()
         rc = self.lib.kpb_ctx_create(device_index, c_void_p(stream), ctypes.byref(h))
         if rc != 0:
@@ -111,7 +113,12 @@ class Context:
             idx = torch.cuda.current_device()
         if idx not in cls._instances:
             cls._instances[idx] = cls(idx)
-        return cls._instances[idx]
+        inst = cls._instances[idx]
+        stream = torch.cuda.current_stream(idx).cuda_stream      # follow torch's current stream (with torch.cuda.stream(...))
+        if stream != inst.stream:
+            inst.check(inst.lib.kpb_ctx_set_stream(inst.handle, c_void_p(stream)))
+            inst.stream = stream
+        return inst
 
     def check(self, rc):
         if rc != 0:

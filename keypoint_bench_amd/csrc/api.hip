@@ -37,7 +37,17 @@ extern "C" __attribute__((visibility("default"))) void kpb_ctx_destroy(kpb_ctx* 
     for (kpb_buf* b : {&ctx->ws_nms_state, &ctx->ws_nms_map, &ctx->ws_cand, &ctx->ws_match, &ctx->ws_misc})
         if (b->p) (void)hipFree(b->p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->det_state && ctx->det_state_free) ctx->det_state_free(ctx->det_state);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_ctx_set_stream(kpb_ctx* ctx, void* stream)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_ctx_set_stream: null context");
+    KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = static_cast<hipStream_t>(stream);
+    return KPB_OK;
 }
 
 extern "C" __attribute__((visibility("default"))) int kpb_sync(kpb_ctx* ctx)

@@ -184,16 +184,19 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     constexpr int LH = TH + 4 * R, LW = TW + 4 * R;
     constexpr int IW = LW - 2 * R, IH = LH - 2 * R;            // inset region: whole window inside the tile
     constexpr int NHS = (IW + 7) / 8, NVS = (IH + 7) / 8;       // strips per row / per column
-    constexpr int PITCH = ((8 * NHS + 2 * R) + 3) / 4 * 4;      // floats per LDS row (16-byte aligned rows)
+    constexpr int PITCH = ((8 * NHS + 2 * R) + 3) / 4 * 4;      // floats per LDS row of t (16-byte aligned rows)
+    constexpr int EP = 8 * NHS;                                 // floats per row of e; e[y][x'] belongs to tile column x' + R
     constexpr int ROWS = 8 * NVS + 2 * R;                       // rows incl. zero padding read by the last strip
     constexpr int HIN = 8 + 2 * R, HQ = (HIN + 3) / 4;          // floats / float4s one horizontal strip reads
     constexpr int KS = 2 * R + 1, KS2 = KS * KS;
-    __shared__ __attribute__((aligned(16))) float t[ROWS * PITCH];   // >0 alive, 0 dead, <0 confirmed maximum
-    __shared__ __attribute__((aligned(16))) float e[ROWS * PITCH];   // row maxima over [x-R, x+R]
+    // the working map carries the state in the sign: > 0 alive, 0 dead, < 0 confirmed maximum (its value negated);
+    // confirmed maxima are never re-derived, a tile only has to clear what they still cover
+    __shared__ __attribute__((aligned(16))) float t[ROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float e[ROWS * EP];      // row maxima over [x-R, x+R]
     __shared__ int maxlist[MAXLIST];
-    __shared__ int s_n[2], s_kill[2], s_owned, s_over;
+    __shared__ int s_n[2], s_changed, s_over;
 
-    const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int ntiles = a.tiles_x * a.tiles_y;
     int* tcur = a.tchg_cur + (size_t)img * ntiles;
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     const float* in = (a.sweep == 0 ? a.src : a.cur) + (size_t)img * P;
     float* out = a.cur + (size_t)img * P;
     const int gy0 = ty * TH - 2 * R, gx0 = tx * TW - 2 * R;
+    const bool first = a.sweep == 0;
 
     int neg = 0;
     // zero padding outside the image (extracter.py:54-60) and in the pad rows/columns
@@ -236,7 +240,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
             if (i < NQ) {
                 neg |= (buf[k].x < 0.0f) | (buf[k].y < 0.0f) | (buf[k].z < 0.0f) | (buf[k].w < 0.0f);
                 *reinterpret_cast<float4*>(t + 4 * i) = buf[k];
-                *reinterpret_cast<float4*>(e + 4 * i) = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     } else {
@@ -248,12 +251,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
             if (ly < LH && lx < LW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = in[(size_t)gy * a.W + gx];
             neg |= (v < 0.0f);
             t[i] = v;
-            e[i] = 0.0f;
         }
     }
-    if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_kill[0] = 0; s_kill[1] = 0; s_owned = 0; s_over = 0; }
+    for (int i = tid; i < ROWS * EP; i += NMS_THREADS) e[i] = 0.0f;
+    if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_changed = 0; s_over = 0; }
     __syncthreads();
-    if (neg) a.negflag[img] = 1;
+    if (neg && first) a.negflag[img] = 1;    // only the input map may not be negative; later sweeps use the sign themselves
 
     float orig[TH * TW / NMS_THREADS];
 #pragma unroll
@@ -262,86 +265,125 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
         orig[k] = t[(oy + 2 * R) * PITCH + ox + 2 * R];
     }
 
+    // appends the positions flagged by `hit` to maxlist with one LDS atomic per wave
+    auto append = [&](bool hit, int pos, int par) {
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {
+            int base = 0;
+            if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&s_n[par], __popcll(bal));
+            base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+            if (hit) {
+                const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < MAXLIST) maxlist[slot] = pos;
+                else s_over = 1;
+            }
+        }
+    };
+    // zeroes the window of every listed maximum; no two maxima lie within R of each other, so nothing but dead or
+    // doomed pixels is overwritten and no read is needed (extracter.py:81-96)
+    auto kill = [&](int nmax, bool mark_centre) {
+        for (int i = tid; i < nmax * KS2; i += NMS_THREADS) {
+            const int m = i / KS2, c = i - m * KS2;
+            const int dy = c / KS - R, dx = c - (dy + R) * KS - R;
+            const int pos = maxlist[m] + dy * PITCH + dx;
+            if (dy == 0 && dx == 0) { if (mark_centre) t[pos] = -t[pos]; }
+            else t[pos] = 0.0f;
+        }
+    };
+
+    if (!first) {   // maxima confirmed in earlier sweeps (possibly by a neighbour tile): clear what they cover here
+        for (int i = tid; i < IH * IW + (NMS_THREADS - 1); i += NMS_THREADS) {
+            const bool in_range = i < IH * IW;
+            const int y = in_range ? i / IW + R : 0, x = in_range ? i - (y - R) * IW + R : 0;
+            append(in_range && t[y * PITCH + x] < 0.0f, y * PITCH + x, 0);
+        }
+        __syncthreads();
+        kill(min(s_n[0], MAXLIST), false);
+        __syncthreads();
+        if (tid == 0) { s_n[0] = 0; if (s_over) { s_over = 0; s_changed = 1; } }
+        __syncthreads();
+    }
+
     int unconverged = 1;
     for (int iter = 0; iter < a.max_local; ++iter) {
         const int par = iter & 1;
-        // horizontal pass: e[y][x] = max t[y][x-R .. x+R] for x in [R, R + 8*NHS)
+        // horizontal pass: e[y][x - R] = max t[y][x-R .. x+R] for x in [R, R + 8*NHS)
         for (int i = tid; i < LH * NHS; i += NMS_THREADS) {
             const int y = i / NHS, s8 = i - y * NHS;
             const float* row = t + y * PITCH + 8 * s8;
             float v[HQ * 4];
 #pragma unroll
-            for (int q = 0; q < HQ; ++q) {
+            for (int q = 0; q < HQ; ++q) {      // |t|: a confirmed maximum (stored negated) still outranks everything near it
                 const float4 f = *reinterpret_cast<const float4*>(row + 4 * q);
-                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+                v[4 * q] = fabsf(f.x); v[4 * q + 1] = fabsf(f.y); v[4 * q + 2] = fabsf(f.z); v[4 * q + 3] = fabsf(f.w);
             }
             float o[8];
             window_max<KS, 8, HQ * 4>(v, o);
-            float* er = e + y * PITCH + R + 8 * s8;   // (R + 8*s8) is not 16-byte aligned for odd R: scalar stores
-#pragma unroll
-            for (int k = 0; k < 8; ++k) er[k] = o[k];
+            float* er = e + y * EP + 8 * s8;
+            *reinterpret_cast<float4*>(er) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(er + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
         __syncthreads();
         // vertical pass on 8-row strips: a pixel is a maximum iff it is alive, equals its row maximum,
         // is > every row maximum above and >= every one below (argmax = first index, extracter.py:69-70),
         // and is > the R cells to its left.
-        for (int i = tid; i < NVS * IW; i += NMS_THREADS) {
-            const int s8 = i / IW, x = i - s8 * IW + R;
+        for (int i0 = 0; i0 < NVS * IW; i0 += NMS_THREADS) {
+            const int i = i0 + tid;
+            const bool in_range = i < NVS * IW;
+            const int s8 = in_range ? i / IW : 0, x = in_range ? i - s8 * IW + R : R;
             const int y0 = R + 8 * s8;
-            float col[8 + 2 * R];
+            float tv[8];
+            bool any_alive = false;
 #pragma unroll
-            for (int k = 0; k < 8 + 2 * R; ++k) col[k] = e[(y0 - R + k) * PITCH + x];
-            float wr[8 + R + 1];
-            window_max<R, 8 + R + 1, 8 + 2 * R>(col, wr);    // wr[j] = max col[j .. j+R-1]
+            for (int k = 0; k < 8; ++k) { tv[k] = t[(y0 + k) * PITCH + x]; any_alive |= tv[k] > 0.0f; }
+            any_alive &= in_range;
+            unsigned hits = 0;
+            if (any_alive) {
+                float col[8 + 2 * R];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int y = y0 + k;
-                const float v = t[y * PITCH + x];
-                if (y < LH - R && v > 0.0f && v == col[k + R] && v > wr[k] && v >= wr[k + R + 1]) {
-                    bool ok = true;
+                for (int k = 0; k < 8 + 2 * R; ++k) col[k] = e[(y0 - R + k) * EP + x - R];
+                float wr[8 + R + 1];
+                window_max<R, 8 + R + 1, 8 + 2 * R>(col, wr);    // wr[j] = max col[j .. j+R-1]
 #pragma unroll
-                    for (int d = 1; d <= R; ++d) ok = ok && (v > t[y * PITCH + x - d]);
-                    if (ok) {
-                        const int slot = atomicAdd(&s_n[par], 1);
-                        if (slot < MAXLIST) maxlist[slot] = y * PITCH + x;
-                        else s_over = 1;
+                for (int k = 0; k < 8; ++k) {
+                    const int y = y0 + k;
+                    const float v = tv[k];
+                    if (y < LH - R && v > 0.0f && v == col[k + R] && v > wr[k] && v >= wr[k + R + 1]) {
+                        bool ok = true;
+#pragma unroll
+                        for (int d = 1; d <= R; ++d) ok = ok && (v > fabsf(t[y * PITCH + x - d]));
+                        if (ok) hits |= 1u << k;
                     }
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) append((hits >> k) & 1u, (y0 + k) * PITCH + x, par);
         }
         __syncthreads();
         const int nmax = min(s_n[par], MAXLIST);
-        if (tid == 0) { s_n[par ^ 1] = 0; s_kill[par ^ 1] = 0; }
-        for (int i = tid; i < nmax * KS2; i += NMS_THREADS) {
-            const int m = i / KS2, c = i - m * KS2;
-            const int dy = c / KS - R, dx = c - (dy + R) * KS - R;
-            const int pos = maxlist[m] + dy * PITCH + dx;
-            if (dy == 0 && dx == 0) {
-                t[pos] = -t[pos];
-            } else if (t[pos] != 0.0f) {
-                t[pos] = 0.0f;
-                s_kill[par] = 1;
-                const int py = pos / PITCH - 2 * R, px = pos - (py + 2 * R) * PITCH - 2 * R;
-                if (py >= 0 && py < TH && px >= 0 && px < TW) s_owned = 1;
-            }
-        }
+        if (tid == 0) s_n[par ^ 1] = 0;
+        if (nmax == 0 && !s_over) { unconverged = 0; break; }    // nothing new: the tile is at its local fixed point
+        kill(nmax, true);
         __syncthreads();
-        if (!s_kill[par] && !s_over) { unconverged = 0; break; }
-        if (s_over && tid == 0) s_over = 0;   // next round re-finds what did not fit
+        if (s_over && tid == 0) s_over = 0;   // the next round re-finds what did not fit
     }
 
     const int by = ty * TH, bx = tx * TW;
+    int changed = 0;
 #pragma unroll
     for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
         const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
         const int gy = by + oy, gx = bx + ox;
         if (gy < a.H && gx < a.W) {
-            const float v = fabsf(t[(oy + 2 * R) * PITCH + ox + 2 * R]);
-            if (a.sweep == 0 || v != orig[k]) out[(size_t)gy * a.W + gx] = v;
+            const float v = t[(oy + 2 * R) * PITCH + ox + 2 * R];
+            if (v != orig[k]) changed = 1;
+            if (first || v != orig[k]) out[(size_t)gy * a.W + gx] = v;
         }
     }
+    if (changed) s_changed = 1;
+    __syncthreads();
     if (tid == 0) {
-        const int flag = (s_owned || unconverged) ? 1 : 0;
+        const int flag = (s_changed || unconverged) ? 1 : 0;
         tcur[tile] = flag;
         if (flag) atomicMax(&a.lastchg[img], a.sweep + 1);
     }
@@ -394,6 +436,7 @@ struct SelArgs {
     int* out_n;                  // [B]
     int H, W, border, top_k, kpad;
     float threshold, min_score;
+    int signed_map;              // the NMS working map keeps confirmed maxima negated
 };
 
 __device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned long long* src, int n,
@@ -454,6 +497,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (i0 + j < P) v[j] = map[i0 + j];
+        }
+        if (a.signed_map) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fabsf(v[j]);
         }
         bool pred[4];
         int cnt = 0;
@@ -635,6 +682,14 @@ int nms_status(kpb_ctx* ctx, const NmsPlan& p, int batch, int sweeps_run, int& p
 
 }  // namespace
 
+namespace {
+__global__ void abs_inplace(float* m, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) m[i] = fabsf(m[i]);
+}
+}  // namespace
+
 extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W, int nms_dist,
                             float* out_map_dev)
 {
@@ -660,6 +715,11 @@ extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx,
         if (neg) return kpb_fail(ctx, KPB_E_NEGATIVE, "kpb_fast_nms: negative scores are outside this path's contract");
         if (run > 100000) return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_fast_nms: no fixed point after %d sweeps", run);
     }
+    if (nms_dist <= 8) {   // the specialised sweep keeps confirmed maxima negated in its working map
+        const size_t n = (size_t)batch * H * W;
+        KPB_LAUNCH(ctx, "abs_inplace", abs_inplace, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out_map_dev, n);
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     return KPB_OK;
 }
 
@@ -670,7 +730,16 @@ struct DetState {
     int batch, H, W; kpb_detect_params prm;
     float* out_kps; int* out_idx; int* out_n;
     int sweeps_run;
-} g_det;
+};
+
+DetState& det_state(kpb_ctx* ctx)
+{
+    if (!ctx->det_state) {
+        ctx->det_state = new DetState();
+        ctx->det_state_free = [](void* p) { delete static_cast<DetState*>(p); };
+    }
+    return *static_cast<DetState*>(ctx->det_state);
+}
 
 int det_select(kpb_ctx* ctx, const DetState& d)
 {
@@ -681,6 +750,7 @@ int det_select(kpb_ctx* ctx, const DetState& d)
     s.H = d.H; s.W = d.W; s.border = d.prm.border_dist; s.top_k = d.prm.top_k;
     s.kpad = d.prm.top_k >= d.H * d.W ? 0 : next_pow2(d.prm.top_k);
     s.threshold = d.prm.threshold; s.min_score = d.prm.min_score;
+    s.signed_map = (d.prm.nms_dist >= 1 && d.prm.nms_dist <= 8) ? 1 : 0;
     KPB_LAUNCH(ctx, "select_topk", select_topk, dim3(d.batch), dim3(SEL_THREADS), (size_t)s.kpad * sizeof(unsigned long long),
                        ctx->stream, s);
     KPB_HIP(ctx, hipGetLastError());
@@ -702,7 +772,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: top_k %d outside 1..%d (or >= H*W)", prm->top_k, KPB_MAX_TOPK);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)H * W;
-    DetState& d = g_det;
+    DetState& d = det_state(ctx);
     d.score = score_dev; d.batch = batch; d.H = H; d.W = W; d.prm = *prm;
     if (d.prm.top_k > H * W) d.prm.top_k = H * W;   // N can never exceed H*W: same rows, smaller buffers
     d.out_kps = out_kps_dev; d.out_idx = out_idx_dev; d.out_n = out_n_dev;
@@ -730,7 +800,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_detect_check: null context");
     if (!ctx->det_pending) return KPB_OK;
-    DetState& d = g_det;
+    DetState& d = det_state(ctx);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     if (d.prm.nms_dist == 0) {
         KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));

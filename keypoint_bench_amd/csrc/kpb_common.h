@@ -39,8 +39,9 @@ struct kpb_ctx {
     kpb_buf ws_match;       // per-tile row/column minima
     kpb_buf ws_misc;
     int* host_flags = nullptr;  // pinned, for status read-back
-    // state of the last kpb_detect(sync=0)
-    int det_batch = 0, det_sweeps = 0;
+    // state of the last kpb_detect(sync=0), owned by detect.hip
+    void* det_state = nullptr;
+    void (*det_state_free)(void*) = nullptr;
     int det_pending = 0;
 };
 
