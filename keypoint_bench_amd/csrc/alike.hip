@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
 
 // ------------------------------------------------------------------------------------------------ 1x1 + ReLU
 template <int CIN>
-__global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out, const float* w /*[CIN][16]*/, size_t npix)
+__global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out, const float* w /*[CIN][16]*/, const float* wsg /*[16]*/,
+                                                    float* smap, size_t npix)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= npix) return;
@@ -298,9 +299,13 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out,
             for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[c], w[(c4 * 4 + c) * 16 + j], acc[j]);
     }
     float* o = out + p * 16;
+    float sg = 0.0f;     // this group's share of the score logit: the 1x1 head commutes with the bilinear upsampling
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[j] = relu(acc[j]); sg = fmaf(acc[j], wsg[j], sg); }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(o + 4 * q) = make_float4(relu(acc[4 * q]), relu(acc[4 * q + 1]), relu(acc[4 * q + 2]), relu(acc[4 * q + 3]));
+        *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    smap[p] = sg;
 }
 
 // ------------------------------------------------------------------------------------------------ head
@@ -315,7 +320,6 @@ struct HeadArgs {
     float* score;      // [B][H][W]
     float* desc;       // [B][H][W][64] or null
     int H, W;
-    int stagger;
 };
 
 constexpr int HEAD_TILES = 4;   // 32-pixel tiles per wave
@@ -372,13 +376,6 @@ __global__ __launch_bounds__(256) void alike_head(HeadArgs a)
     const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
     const int tiles_per_row = a.W / 32, ntiles = a.H * tiles_per_row;
     const int tile0 = (blockIdx.x * 4 + wv) * HEAD_TILES;
-    if (DENSE) {
-        // All workgroups do identical work, so the waves that share a SIMD would march in lockstep (all in their VALU
-        // phase, then all queueing for the matrix pipe).  A one-off start offset per workgroup de-phases them.
-        const int ph = __builtin_amdgcn_readfirstlane(a.stagger ? (int)((blockIdx.x * 5u) & 7u) : 0);
-        for (int i = 0; i < ph; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-
     for (int t = 0; t < HEAD_TILES; ++t) {
         const int tile = tile0 + t;
         if (tile >= ntiles) break;
@@ -429,6 +426,60 @@ __global__ __launch_bounds__(256) void alike_head(HeadArgs a)
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ score, linear form
+// convhead2 is a bias-free 1x1 convolution and nn.Upsample(bilinear) is linear, so the score row of the head commutes
+// with the three upsamplings (ALike.py:151-162):
+//     w . [f1 | up2(a2) | up8(a3) | up32(a4)]  =  w1 . f1  +  up2(w2 . a2)  +  up8(w3 . a3)  +  up32(w4 . a4)
+// The scalar maps S_g = w_g . a_g come out of the aggregation kernels at 1/4, 1/64 and 1/1024 of the pixels; when no
+// dense descriptor map is wanted the full-resolution work is one 8 -> 16 product and twelve scalar taps per pixel.
+// (The same rewrite of the 64 descriptor rows was measured and lost to alike_head: interpolating three projected
+// 64-channel maps costs more vector/LDS work than the 64-deep MFMA it saves.)
+struct LinArgs {
+    const float* x1;                       // [B][H][W][8]
+    const float* S2; const float* S3; const float* S4;   // [B][H/2][W/2], ...
+    const float* agg1;                     // [8][16]
+    const float* wsc;                      // [64]      score row; entries 0..15 belong to f1
+    float* score;
+    int H, W;
+};
+
+__device__ __forceinline__ float lerp_scalar(const float* m, int Hs, int Ws, float sy, float sx, int y, int x)
+{
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+    return hy * (hx * m[(size_t)y0 * Ws + x0] + lx * m[(size_t)y0 * Ws + x1]) + ly * (hx * m[(size_t)y1 * Ws + x0] + lx * m[(size_t)y1 * Ws + x1]);
+}
+
+// one thread per pixel
+__global__ __launch_bounds__(256) void alike_score_lin(LinArgs a)
+{
+    const int b = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    const int P = a.H * a.W;
+    if (pix >= P) return;
+    const int y = pix / a.W, x = pix - y * a.W;
+    const float* px = a.x1 + ((size_t)b * P + pix) * 8;
+    const float4 lo = *reinterpret_cast<const float4*>(px), hi = *reinterpret_cast<const float4*>(px + 4);
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    float f[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) f[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = fmaf(v[c], a.agg1[c * 16 + j], f[j]);
+    float sc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sc = fmaf(relu(f[j]), a.wsc[j], sc);
+    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
+    sc += lerp_scalar(a.S2 + (size_t)b * H2 * W2, H2, W2, (float)(H2 - 1) / (float)(a.H - 1), (float)(W2 - 1) / (float)(a.W - 1), y, x);
+    sc += lerp_scalar(a.S3 + (size_t)b * H8 * W8, H8, W8, (float)(H8 - 1) / (float)(a.H - 1), (float)(W8 - 1) / (float)(a.W - 1), y, x);
+    sc += lerp_scalar(a.S4 + (size_t)b * H32 * W32, H32, W32, (float)(H32 - 1) / (float)(a.H - 1), (float)(W32 - 1) / (float)(a.W - 1), y, x);
+    a.score[(size_t)b * P + pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
 }
 
 // ------------------------------------------------------------------------------------------------ desc_at
@@ -497,14 +548,13 @@ namespace {
 
 struct AlikeNet : kpb_net {
     float *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
-          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr;
+          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr, *S2 = nullptr, *S3 = nullptr, *S4 = nullptr;
     HeadArgs head_args(float* score, float* desc)
     {
         HeadArgs h;
         h.x1 = x1; h.a2 = a2; h.a3 = a3; h.a4 = a4;
         h.agg1 = wp("agg1.w"); h.whT = wp("head.wT"); h.wsc = wp("head.ws");
         h.score = score; h.desc = desc; h.H = H; h.W = W;
-        h.stagger = getenv("KPB_HEAD_STAGGER") ? atoi(getenv("KPB_HEAD_STAGGER")) : 1;
         return h;
     }
     int forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev) override;
@@ -542,7 +592,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     const size_t P = (size_t)H * W, B = batch;
     const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
                  n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
-    const size_t total = n_x1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4;
+    const size_t n_s = B * (P / 4 + P / 64 + P / 1024) + 64;
+    const size_t total = n_x1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4 + n_s;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
@@ -551,6 +602,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     t4 = p; p += n_4; x4 = p; p += n_4; a4 = p; p += n_a4;
     float* r3 = p; p += n_3;
     float* r4 = p; p += n_4;
+    S2 = p; p += B * (P / 4); S3 = p; p += B * (P / 64); S4 = p; p += B * (P / 1024) + 64;
     this->B = batch; this->H = H; this->W = W;
     hipStream_t st = ctx->stream;
 
@@ -583,15 +635,18 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         m.istride = 64; m.ostride = 64; m.ooff = 0;
         KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
     }
-    // aggregation 1x1 + ReLU (147-150); agg1 is fused into the head
-    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), B * P / 4);
-    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), B * P / 64);
-    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), B * P / 1024);
+    // aggregation 1x1 + ReLU (147-150), each with its share of the score logit; agg1 is fused into the head
+    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4);
+    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64);
+    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024);
     // upsample + concat + head (151-162)
-    HeadArgs h = head_args(score_out_dev, desc_out_dev);
-    const dim3 hg(cdiv(H * (W / 32), 4 * HEAD_TILES), batch);
-    if (desc_out_dev) KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, hg, dim3(256), 0, st, h);
-    else KPB_LAUNCH(ctx, "alike_head_score", alike_head<false>, hg, dim3(256), 0, st, h);
+    if (desc_out_dev) {
+        HeadArgs h = head_args(score_out_dev, desc_out_dev);
+        KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, dim3(cdiv(H * (W / 32), 4 * HEAD_TILES), batch), dim3(256), 0, st, h);
+    } else {
+        LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W};
+        KPB_LAUNCH(ctx, "alike_head_score", alike_score_lin, dim3(cdiv(H * W, 256), batch), dim3(256), 0, st, la);
+    }
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }

@@ -88,7 +88,8 @@ def test_lazy_descriptors_equal_dense_sampling():
     img = torch.from_numpy(v0)[None].to(DEV)
     s_d, d_d = dense(img)
     s_l, d_l = lazy(img)
-    assert torch.equal(s_d, s_l)
+    # the score-only path evaluates the head's score row in its linear form (different summation order)
+    np.testing.assert_allclose(s_l.cpu().numpy(), s_d.cpu().numpy(), rtol=0, atol=2e-6)
     assert tuple(d_l.shape) == tuple(d_d.shape)
     kps = detection(s_d, p)
     want = sample_descriptors(kps, d_d).cpu().numpy()
