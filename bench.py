@@ -103,6 +103,17 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     return c
 
 
+def pmc_traffic(kernel, pairs, dense):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE
+    in separate rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 correction).  Counters
+    cannot be collected from inside a timed run, so this is the figure of the profile named in profiles/README.md."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_b%d_%s.json" % (pairs, "dense" if dense else "sparse"))
+    try:
+        return json.load(open(path))[kernel]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def superpoint_costs(B2):
     """(FLOPs, bytes) per launch of the SuperPoint conv kernels (2*MAC; NHWC fp32 in + out, weights negligible)."""
     P = H * W
@@ -129,7 +140,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=64, help="pairs per GPU per step")
+    ap.add_argument("--pairs-per-step", type=int, default=None, help="pairs per GPU per step (default: 256 ALIKE [SURVEY 8d], 64 XFeat, 16 SuperPoint, 4 DISK)")
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
@@ -166,20 +177,16 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B = args.pairs_per_step
+    B = args.pairs_per_step or {"alike": 256, "xfeat": 64, "superpoint": 16, "disk": 4}[args.model]
     if args.model == "superpoint":
         from keypoint_bench_amd.models.SuperPoint import superpoint_random
         net = superpoint_random(7).eval()
-        if args.pairs_per_step == 64:
-            B = 16
     elif args.model == "xfeat":
         from keypoint_bench_amd.models.XFeat import xfeat_random
         net = xfeat_random(9).eval()
     elif args.model == "disk":
         from keypoint_bench_amd.models.disk import disk_random
         net = disk_random(5).eval()
-        if args.pairs_per_step == 64:
-            B = 4
     else:
         net = alike_t(dense_descriptors=not args.sparse).eval()
     lg = None
@@ -250,8 +257,9 @@ def main():
         else:
             bound, achieved, peak, unit = "hbm", gbs, PEAK_HBM_GBS, "GB/s"
         tot = sum(v[1] for v in prof.values())
+        traffic = pmc_traffic(name, B, not args.sparse) if args.model == "alike" else None
         roof = dict(bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit, frac=round(achieved / peak, 4),
-                    traffic=None, kernel=name, avg_ms=round(avg_ms, 4), launches_per_step=calls / prof_steps,
+                    traffic=traffic, kernel=name, avg_ms=round(avg_ms, 4), launches_per_step=calls / prof_steps,
                     share_of_step=round(total_ms / tot, 3),
                     kernels_ms_per_step={k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
 

@@ -32,3 +32,17 @@ for k in names:
         n = calls[k].get(c, 0)
         row.append("%.4g" % (agg[k][c] / n) if n else "")
     print(",".join(row))
+
+# HBM traffic per launch for the kernels bench.py can name (MI355X_MICROARCH.md, "HBM": FETCH_SIZE and
+# WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled; WRITE_SIZE exact).
+import json
+PROF = {"alike_head<true>": "alike_head_dense", "alike_head<false>": "alike_head_score", "alike_score_lin": "alike_head_score",
+        "alike_block1": "alike_block1", "nms_sweep_r<6>": "nms_sweep", "match_tile": "match_tile",
+        "select_topk": "select_topk", "sample_bilinear": "sample_bilinear", "alike_desc_at": "alike_desc_at"}
+traffic = {}
+for k in names:
+    if k in PROF and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        f = agg[k]["FETCH_SIZE"] / calls[k]["FETCH_SIZE"]; w = agg[k]["WRITE_SIZE"] / calls[k]["WRITE_SIZE"]
+        traffic[PROF[k]] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024), "avg_us": dur[k] / max(ncall[k], 1)}
+if len(sys.argv) > 2:
+    json.dump(traffic, open(sys.argv[2], "w"), indent=1)

@@ -14,5 +14,5 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_W
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python $ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/p$i.log; }
 done
-python scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
+python scripts/pmc_summary.py $OUT $OUT/traffic.json > $OUT/summary.txt 2>&1
 tail -60 $OUT/summary.txt
