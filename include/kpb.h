@@ -122,6 +122,33 @@ int kpb_gather_rows(kpb_ctx* ctx, const float* src_dev, int batch, int src_rows,
                     const int32_t* idx_dev, int idx_rows, int idx_stride, int idx_col,
                     const int32_t* k_dev, float* out_dev);
 
+/* ---- 8(f)1: covisibility warp, utils/projection.py:137-167 warp_homography -----------------------
+ * kps_dev [batch][max_n][stride] fp32 rows (x, y, ...) normalised; n_dev [batch] or NULL (= max_n);
+ * hmat_dev [batch][9] row-major fp32 homography; wh_dev [batch][2] int32 (width, height) of the target
+ * image.  Keeps the points whose warp lands in [0, w-1] x [0, h-1]:
+ * out_kps0_dev / out_kps01_dev [batch][max_n][2] = the kept points and their warps (both normalised),
+ * out_ids_dev [batch][max_n] = kept row numbers ascending, then the rejected ones ascending,
+ * out_n_dev [batch] = number kept. */
+int kpb_warp_homography(kpb_ctx* ctx, const float* kps_dev, int batch, int max_n, int stride,
+                        const int32_t* n_dev, const float* hmat_dev, const int32_t* wh_dev,
+                        float* out_kps0_dev, float* out_kps01_dev, int32_t* out_ids_dev,
+                        int32_t* out_n_dev);
+
+/* ---- 8(f)1: ground-truth mutual nearest neighbours, tasks/repeatability.py:69-85 (val_key_points;
+ * mutual_argmax 9-32, compute_keypoints_distance 39-51) -------------------------------------------
+ * k0_dev, k01_dev [batch][max_m][2]: covisible keypoints of image 0 and their warps; k1_dev, k10_dev
+ * [batch][max_n][2] likewise for image 1; m_dev / n_dev [batch] or NULL.  scale_dev [batch][2] =
+ * (warp01 resize-or-width, warp10 resize-or-width).  dm = (|k0-k10| + |k1-k01|)/2 with the leading
+ * diagonal set to 99999; a cell is mutual when `-dm - min(-dm)` equals its row and its column maximum
+ * (every tie kept).  out_pairs_dev [batch][cap][2] (i, j) row-major, out_dist_dev [batch][cap] =
+ * dm*scale01, out_errors_dev [batch][max_m] = row minimum*scale10, out_counts_dev [batch][2] =
+ * (mutual cells -- may exceed cap, in which case only the first cap were written --, cells with
+ * dist <= th). */
+int kpb_val_keypoints(kpb_ctx* ctx, const float* k0_dev, const float* k01_dev, const float* k1_dev,
+                      const float* k10_dev, int batch, int max_m, int max_n, const int32_t* m_dev,
+                      const int32_t* n_dev, const float* scale_dev, float th, int32_t* out_pairs_dev,
+                      float* out_dist_dev, int cap, float* out_errors_dev, int32_t* out_counts_dev);
+
 /* ---- N1..: extractor networks (models/ALike.py:136-164 ALNet.forward, ...) ---------------------
  * arch: KPB_ARCH_*.  blob: a .kpbw container (keypoint_bench_amd/weights.py) holding the folded
  * tensors; copied, the caller may free it. */

@@ -44,6 +44,10 @@ SIGNATURES = {
                           ctypes.POINTER(MatchParams), c_void_p, c_void_p, c_void_p]),
     "kpb_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                                 c_void_p]),
+    "kpb_warp_homography": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p]),
+    "kpb_val_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "kpb_net_create": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "kpb_net_destroy": (None, [c_void_p]),
     "kpb_net_desc_dim": (c_int, [c_void_p]),

@@ -226,6 +226,24 @@ def install():
         for k, v in names.items():
             setattr(mod, k, v)
             swapped.append(modname + "." + k)
+    # the homography warp and the repeatability core.  `warp` keeps dispatching on params['mode'] inside
+    # the reference (its depth-based 'se3' branch is not built here and stays the reference's own).
+    from .tasks import repeatability as rp
+    from .utils import projection as pj
+    try:
+        mod = importlib.import_module("utils.projection")
+        mod.warp_homography = pj.warp_homography
+        swapped.append("utils.projection.warp_homography")
+        mod = importlib.import_module("tasks.repeatability")
+        theirs = mod.val_key_points
+
+        def val_key_points(kps0, kps1, warp01, warp10, th=3):
+            both_homo = warp01["mode"] == "homo" and warp10["mode"] == "homo"
+            return (rp.val_key_points if both_homo else theirs)(kps0, kps1, warp01, warp10, th)
+        mod.val_key_points = val_key_points
+        swapped.append("tasks.repeatability.val_key_points")
+    except Exception:
+        pass
     for name, mod in list(sys.modules.items()):
         if mod is None or not (name.startswith("tasks.") or name == "models.model_interface"):
             continue

@@ -1,0 +1,56 @@
+"""Drop-in for the metric core of the reference's tasks/repeatability.py: `val_key_points` (54-92) with
+`compute_keypoints_distance` (39-51) and `mutual_argmax/argmin` (9-36), computed by csrc/covis.hip.
+
+The reference materialises three M x N matrices per pair; here the pair never leaves the GPU until the handful of
+numbers the metric needs are read back."""
+import torch
+
+from .._lib import Context, ptr
+from ..utils.projection import _scalar, warp_homography_device, warp
+
+
+def _scale(w):
+    return float(_scalar(w["resize"] if "resize" in w else w["width"]))       # repeatability.py:76-81
+
+
+def gt_mutual(k0, k01, k1, k10, scale01, scale10, th=3.0, m_dev=None, n_dev=None, cap=None):
+    """Lines 69-85 for covisible sets already on the device.  k0/k01 [M,2], k1/k10 [N,2]; m_dev/n_dev optional
+    int32[1] device counts (rows beyond them ignored).  Returns (pairs[K,2] int64, dist[K], errors[M], gt_num)."""
+    dev = k0.device
+    M, N = k0.shape[0], k1.shape[0]
+    ctx = Context.get(dev)
+    scale = torch.tensor([scale01, scale10], dtype=torch.float32, device=dev)
+    errors = torch.empty((M,), dtype=torch.float32, device=dev)
+    counts = torch.zeros((2,), dtype=torch.int32, device=dev)
+    cap = cap or (M + N + 1024)
+    while True:
+        pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        dist = torch.empty((cap,), dtype=torch.float32, device=dev)
+        ctx.check(ctx.lib.kpb_val_keypoints(ctx.handle, ptr(k0), ptr(k01), ptr(k1), ptr(k10), 1, M, N, ptr(m_dev),
+                                            ptr(n_dev), ptr(scale), float(th), ptr(pairs), ptr(dist), cap, ptr(errors),
+                                            ptr(counts)))
+        total, gt = (int(v) for v in counts.tolist())
+        if total <= cap:
+            break
+        cap = total                     # every tie is a mutual cell (mutual_argmax keeps them all): grow and redo
+    return pairs[:total].to(torch.int64), dist[:total], errors, gt
+
+
+def val_key_points(kps0, kps1, warp01, warp10, th: int = 3):
+    """tasks/repeatability.py:54-92 (homography warps)."""
+    num_feat = min(kps0.shape[0], kps1.shape[0])
+    if warp01["mode"] != "homo" or warp10["mode"] != "homo":
+        warp(kps0, warp01)              # raises for the modes that are not built
+    a, b, _, na = warp_homography_device(kps0[:, 0:2], warp01)
+    a1, b1, _, nb = warp_homography_device(kps1[:, 0:2], warp10)
+    M, N = int(na.item()), int(nb.item())
+    if M == 0 or N == 0:
+        return {"num_feat": 0, "repeatability": 0, "mean_error": 0, "errors": None}
+    pairs, dist, errors, gt = gt_mutual(a[:M], b[:M], a1[:N], b1[:N], _scale(warp01), _scale(warp10), th)
+    error = dist[dist <= th].cpu().numpy()                                   # 83
+    return {
+        "num_feat": num_feat,
+        "repeatability": torch.tensor(gt) / num_feat,                          # 82, 89 (int64 / int -> float32)
+        "mean_error": error.mean(),                                            # 84 (nan when nothing is within th)
+        "errors": errors,
+    }

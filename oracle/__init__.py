@@ -48,6 +48,11 @@ def lib():
         L.kpbo_match.argtypes = [fp, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int,
                                  ip, dp]
         L.kpbo_match.restype = ctypes.c_int
+        L.kpbo_warp_homography.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, ip]
+        L.kpbo_warp_homography.restype = ctypes.c_int
+        L.kpbo_val_keypoints.argtypes = [fp, fp, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                         ip, fp, ctypes.c_long, fp]
+        L.kpbo_val_keypoints.restype = ctypes.c_long
         _lib = L
     return _lib
 
@@ -121,3 +126,40 @@ def brute_force_matcher(pts0, pts1, desc0_chw, desc1_chw, params):
     d1 = sample(desc1_chw, pts1)
     pairs, _ = match(d0, d1, params["max_distance"], params["cross_check"])
     return np.asarray(pts0)[pairs[:, 0]], np.asarray(pts1)[pairs[:, 1]]
+
+
+def warp_homography(kps, hm, width, height, fused=-1):
+    """utils/projection.py:137-167.  Returns (kps0_valid[K,2], kps01_valid[K,2], ids[K], ids_out[n-K]).
+    fused=-1 follows the reference's torch build (BLAS/fused for n >= 45, unfused below); 1 = the form libkpb uses."""
+    p = _f32(kps)
+    n = p.shape[0]
+    h = _f32(hm).reshape(9)
+    a = np.empty((max(n, 1), 2), np.float32)
+    b = np.empty((max(n, 1), 2), np.float32)
+    ids = np.empty((max(n, 1),), np.int32)
+    k = lib().kpbo_warp_homography(_fp(p), n, p.shape[1] if n else 2, _fp(h), int(width), int(height), int(fused), _fp(a), _fp(b),
+                                   ids.ctypes.data_as(ctypes.POINTER(ctypes.c_int))) if n else 0
+    return a[:k].copy(), b[:k].copy(), ids[:k].astype(np.int64), ids[k:n].astype(np.int64)
+
+
+def val_key_points(kps0, kps1, warp01, warp10, th=3, fused=-1):
+    """tasks/repeatability.py:54-92 on numpy inputs (mode 'homo').  Returns the reference's dict, plus the mutual
+    pairs and their scaled distances for the tests."""
+    num_feat = min(len(kps0), len(kps1))
+    k0, k01, _, _ = warp_homography(np.asarray(kps0)[:, :2], warp01["homography_matrix"], warp01["width"], warp01["height"], fused)
+    k1, k10, _, _ = warp_homography(np.asarray(kps1)[:, :2], warp10["homography_matrix"], warp10["width"], warp10["height"], fused)
+    if len(k0) == 0 or len(k1) == 0:
+        return dict(num_feat=0, repeatability=0, mean_error=0, errors=None)
+    s01 = float(warp01["resize"] if "resize" in warp01 else warp01["width"])
+    s10 = float(warp10["resize"] if "resize" in warp10 else warp10["width"])
+    M, N = len(k0), len(k1)
+    cap = M * N
+    pairs = np.empty((cap, 2), np.int32)
+    dist = np.empty((cap,), np.float32)
+    errors = np.empty((M,), np.float32)
+    K = lib().kpbo_val_keypoints(_fp(k0), _fp(k01), M, _fp(k1), _fp(k10), N, s01, s10,
+                                 pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _fp(dist), cap, _fp(errors))
+    dist = dist[:K]
+    sel = dist[dist <= th]
+    return dict(num_feat=num_feat, repeatability=np.float32(len(sel)) / np.float32(num_feat), mean_error=sel.mean() if len(sel) else np.float32("nan"),
+                errors=errors, pairs=pairs[:K].astype(np.int64), dist=dist.copy())

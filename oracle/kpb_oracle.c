@@ -224,3 +224,94 @@ int kpbo_match(const float* d0, int n, const float* d1, int m, int C, double max
     free(rowmin); free(rowarg); free(colmin); free(colarg);
     return K;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * covisibility warp + ground-truth mutual nearest neighbours.
+ *
+ * warp_homography, utils/projection.py:137-167.  kps rows are (x, y[, ...]) normalised; hm is the 3x3
+ * homography, row-major fp32.  Arithmetic as torch 2.10 CPU evaluates the reference's lines here
+ * (pinned by tests/golden/covis.npz): x*(w-1), y*(h-1) in fp32 (144); the einsum row (146) is
+ * h0*x, then fused-multiply-add of h1*y, then + h2; divide by the third row (147); keep points with
+ * 0 <= u <= w-1 and 0 <= v <= h-1 (153); both outputs divided by (w-1, h-1) (163-164).
+ * ids receives the kept row numbers ascending (156) followed by the rejected ones ascending (157).
+ * Returns the number kept. */
+int kpbo_warp_homography(const float* kps, int n, int stride, const float* hm, int width, int height, int fused,
+                         float* kps0_valid, float* kps01_valid, int* ids)
+{
+    if (fused < 0) fused = 9 * n > 400;
+    const float sx = (float)(width - 1), sy = (float)(height - 1);
+    int k = 0, nout = 0;
+    int* rejected = (int*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    for (int i = 0; i < n; ++i) {
+        const float x = kps[(size_t)i * stride] * sx, y = kps[(size_t)i * stride + 1] * sy;
+        float r[3];
+        for (int q = 0; q < 3; ++q)
+            r[q] = (fused ? fmaf(hm[3 * q + 1], y, hm[3 * q] * x) : hm[3 * q] * x + hm[3 * q + 1] * y) + hm[3 * q + 2];
+        const float u = r[0] / r[2], v = r[1] / r[2];
+        if (u >= 0.f && u <= sx && v >= 0.f && v <= sy) {
+            kps0_valid[2 * k] = x / sx;  kps0_valid[2 * k + 1] = y / sy;
+            kps01_valid[2 * k] = u / sx; kps01_valid[2 * k + 1] = v / sy;
+            ids[k++] = i;
+        } else {
+            rejected[nout++] = i;
+        }
+    }
+    for (int i = 0; i < nout; ++i) ids[k + i] = rejected[i];
+    free(rejected);
+    return k;
+}
+
+/* compute_keypoints_distance, tasks/repeatability.py:39-51: torch.norm(p=2) over the pair (dx, dy) evaluates
+ * sqrt(fma(dy, dy, dx*dx)) on this CPU build (pinned by the fixture). */
+static float kp_dist(const float* a, const float* b)
+{
+    const float dx = a[0] - b[0], dy = a[1] - b[1];
+    return sqrtf(fmaf(dy, dy, dx * dx));
+}
+
+/* val_key_points after the two warps, tasks/repeatability.py:69-92 (mutual_argmax 9-32).
+ * k0[M,2], k01[M,2] = covisible keypoints of image 0 and their warps; k1[N,2], k10[N,2] likewise for image 1.
+ *   dm[i][j] = (|k0_i - k10_j| + |k1_j - k01_i|) / 2   (69-71);  dm[i][i] = 99999 for i < min(M,N)   (72-73)
+ *   value = -dm;  value -= value.min()  (18, 36);  mutual where value equals its row max and its column max,
+ *   ALL ties kept, listed row-major (20-32)
+ *   dist = dm[pairs] * scale01   (75-81);  errors[i] = min_j dm[i][j] * scale10   (77, 81, 85)
+ * pairs/dist get at most cap entries; returns the number of mutual cells (may exceed cap: caller checks). */
+long kpbo_val_keypoints(const float* k0, const float* k01, int M, const float* k1, const float* k10, int N,
+                        float scale01, float scale10, int* pairs, float* dist, long cap, float* errors)
+{
+    float* dm = (float*)malloc((size_t)M * N * sizeof(float));
+    float* rmin = (float*)malloc((size_t)M * sizeof(float));
+    float* cmin = (float*)malloc((size_t)N * sizeof(float));
+    float dmax = -INFINITY;
+    const int nd = M < N ? M : N;
+    for (int j = 0; j < N; ++j) cmin[j] = INFINITY;
+    for (int i = 0; i < M; ++i) {
+        float best = INFINITY;
+        for (int j = 0; j < N; ++j) {
+            float d = (kp_dist(k0 + 2 * i, k10 + 2 * j) + kp_dist(k1 + 2 * j, k01 + 2 * i)) / 2.f;
+            if (i == j && i < nd) d = 99999.f;
+            dm[(size_t)i * N + j] = d;
+            if (d < best) best = d;
+            if (d < cmin[j]) cmin[j] = d;
+            if (d > dmax) dmax = d;
+        }
+        rmin[i] = best;
+        errors[i] = best * scale10;
+    }
+    /* value = (-dm) - min(-dm) = (-dm) - (-dmax); rounding is monotone, so the row/column maxima of value are the
+     * images of the row/column minima of dm */
+    long K = 0;
+    for (int i = 0; i < M; ++i) {
+        const float vr = (-rmin[i]) - (-dmax);
+        for (int j = 0; j < N; ++j) {
+            const float v = (-dm[(size_t)i * N + j]) - (-dmax);
+            const float vc = (-cmin[j]) - (-dmax);
+            if (v == vr && v == vc) {
+                if (K < cap) { pairs[2 * K] = i; pairs[2 * K + 1] = j; dist[K] = dm[(size_t)i * N + j] * scale01; }
+                ++K;
+            }
+        }
+    }
+    free(dm); free(rmin); free(cmin);
+    return K;
+}
