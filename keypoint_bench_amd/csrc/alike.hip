@@ -10,11 +10,11 @@
 //   alike_block1   3->8->8 3x3 (+folded BN, ReLU) fused through LDS; VALU fp32 (K=27/72, N=8 is
 //                  too thin for a 32x32 MFMA tile; fp32 MFMA peak equals the VALU peak on gfx950)
 //   conv3x3_k      generic pooled-input 3x3 conv (+bias, +1x1 residual branch, ReLU): block2..4
-//   conv1x1_relu   the four aggregation 1x1 convs
-//   alike_head     per pixel: [relu(agg1 x1) | up2 a2 | up8 a3 | up32 a4] (align_corners bilinear),
-//                  score = sigmoid(w64 . f); dense mode adds the 64->64 descriptor GEMM on
-//                  v_mfma_f32_32x32x2_f32 with the A operand taken straight from the registers that
-//                  built f (K permuted so lane (p,h) owns channels 32h..32h+31) and B resident in VGPRs
+//   conv1x1_relu   the aggregation 1x1 convs 2..4 (+ each group's share of the head rows, projected at low resolution)
+//   alike_head_hyb dense mode: head = [relu(agg1 x1) | up2 a2] x W on v_mfma_f32_32x32x2_f32 (A operand straight
+//                  from the registers that built the features) + the x interpolation of the projected coarse groups
+//                  as extra K steps; score = sigmoid of row 64
+//   alike_score_lin score-only mode: the score row in its fully linear form
 //   alike_desc_at  descriptors at keypoints only: bilinear taps on f, then one 64x64 mat-vec
 #include "conv_mfma.h"
 
@@ -279,9 +279,13 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ 1x1 + ReLU
+constexpr int ESTRIDE = 68;             // channels of a projected map: 64 descriptor rows + score row + pad (float4 aligned)
+
+// out = relu(w . in) (ALike.py:147-150); smap = this group's share of the score logit; with E != null also the group's
+// share of every head row, E[p][o] = sum_c wproj[c][o] out[p][c] (see alike_head: the head commutes with upsampling)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out, const float* w /*[CIN][16]*/, const float* wsg /*[16]*/,
-                                                    float* smap, size_t npix)
+                                                    float* smap, size_t npix, const float* wproj /*[16][64]*/, float* E /*[npix][ESTRIDE]*/)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= npix) return;
@@ -306,6 +310,19 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out,
     for (int q = 0; q < 4; ++q)
         *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     smap[p] = sg;
+    if (E) {
+        float* e = E + p * ESTRIDE;
+        for (int q = 0; q < 16; ++q) {
+            float4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const float* wr = wproj + c * 64 + 4 * q;
+                r.x = fmaf(acc[c], wr[0], r.x); r.y = fmaf(acc[c], wr[1], r.y); r.z = fmaf(acc[c], wr[2], r.z); r.w = fmaf(acc[c], wr[3], r.w);
+            }
+            *reinterpret_cast<float4*>(e + 4 * q) = r;
+        }
+        *reinterpret_cast<float4*>(e + 64) = make_float4(sg, 0.f, 0.f, 0.f);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ head
@@ -322,7 +339,6 @@ struct HeadArgs {
     int H, W;
 };
 
-constexpr int HEAD_TILES = 4;   // 32-pixel tiles per wave
 
 // 8 channels [c0, c0+8) of an align_corners=True bilinear upsample (nn.Upsample, ALike.py:126-129) at (y, x)
 __device__ __forceinline__ void up8ch(const float* m, int Hs, int Ws, float sy, float sx, int y, int x, int c0, float* f)
@@ -346,42 +362,101 @@ __device__ __forceinline__ void up8ch(const float* m, int Hs, int Ws, float sy, 
     }
 }
 
-// Lane (p, h) of a wave owns pixel p of the tile and, of each 16-channel group of x1234, channels
-// 8h..8h+7: every lane runs the same instruction stream (no divergence between the wave halves) and
-// step s of the MFMA K loop consumes channel chan(s, h) = 16*(s/8) + 8h + (s%8) from A and B alike.
-template <bool DENSE>
-__global__ __launch_bounds__(256) void alike_head(HeadArgs a)
+// ------------------------------------------------------------------------------------------------ head, hybrid form
+// convhead2 has no bias and bilinear upsampling is linear, so  W.up(a_g) = up(W.a_g)  (ALike.py:151-159).  For the two
+// coarse groups that is a large saving: E3 = W3.a3 and E4 = W4.a4 are projected once at 1/64 and 1/1024 of the pixels
+// (inside the aggregation kernels; channel 64 of E carries the score row), and at full resolution their bilinear interpolation becomes
+// a handful of extra K steps of the same MFMA accumulation: along a 32-pixel tile of one image row an up8 map touches
+// at most 6 source columns and an up32 map at most 3, so
+//     desc[pixel][:] = sum_c f[pixel][c] W[c][:]  (c < 32: agg1 and up2(a2), as before)
+//                    + sum_t hat3_t(pixel) V3[t][:] + sum_t hat4_t(pixel) V4[t][:]
+// where V3/V4 are the rows of E3/E4 already interpolated in y (one strip per 128-pixel row segment, in LDS) and hat_t
+// are the x interpolation weights, computed per lane and fed as the A operand.  K drops from 64 to 32 + 6 + 4 and the
+// per-pixel bilinear feature work of the two coarse groups disappears.  (Doing the same to up2(a2) was measured and
+// loses: 18 source columns per tile and a 64-channel strip cost more than its K = 16.)
+struct HybArgs {
+    const float* x1;   // [B][H][W][8]
+    const float* a2;   // [B][H/2][W/2][16]
+    const float* E3;   // [B][H/8][W/8][ESTRIDE]    W3.a3, channel 64 = score share
+    const float* E4;   // [B][H/32][W/32][ESTRIDE]  W4.a4
+    const float* agg1; // [8][16]
+    const float* whT;  // [64][64]  whT[c][o]; rows 0..31 used here
+    const float* wsc;  // [64]
+    float* score; float* desc;
+    int H, W;
+};
+
+constexpr int SEG_TILES = 4;            // a wave owns one 128-pixel row segment
+constexpr int NT3 = 18, NT4 = 7;        // strip rows a segment can touch: floor(127/8)+... see the bounds below
+
+// rows [tb, tb + NT) of map E (clamped to the last column), interpolated in y, into a wave's LDS strip
+template <int NT>
+__device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, int Ws, float sy, int y, int tb, int lane)
 {
-    __shared__ __attribute__((aligned(16))) float Bl[32 * 2 * 64];   // [s][h][out]: head weight of chan(s,h)
+    const float fy = sy * (float)y;
+    const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.0f - ly;
+    for (int i = lane; i < NT * (ESTRIDE / 4); i += 64) {
+        const int t = i / (ESTRIDE / 4), q = i - t * (ESTRIDE / 4);
+        const int xt = min(tb + t, Ws - 1);
+        const float4 u = *reinterpret_cast<const float4*>(E + ((size_t)y0 * Ws + xt) * ESTRIDE + 4 * q);
+        const float4 d = *reinterpret_cast<const float4*>(E + ((size_t)y1 * Ws + xt) * ESTRIDE + 4 * q);
+        float4 o;
+        o.x = hy * u.x + ly * d.x; o.y = hy * u.y + ly * d.y; o.z = hy * u.z + ly * d.z; o.w = hy * u.w + ly * d.w;
+        *reinterpret_cast<float4*>(V + t * ESTRIDE + 4 * q) = o;
+    }
+}
+
+// Lane (p, h) of a wave owns pixel p of the tile and, of each of the two fine 16-channel groups, channels 8h..8h+7:
+// every lane runs the same instruction stream (no divergence between the wave halves), the A operand comes straight
+// from the registers that built the features, and step s of the K loop consumes channel 16*(s/8) + 8h + (s%8) from A
+// and B alike (the MFMA does not care which k a lane calls its own, as long as A and B agree).  In the tap steps the
+// lane supplies the weight of pixel p for source column 2s + h.
+__global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float Bl[16 * 2 * 64];   // [s][h][out]: head weight of chan(s,h), s < 16
     __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j
-    __shared__ __attribute__((aligned(16))) float Ws[2 * 32];         // [h][s]:       score weight of chan(s,h)
+    __shared__ __attribute__((aligned(16))) float Ws[2 * 16];         // [h][s]:       score weight of chan(s,h)
+    __shared__ __attribute__((aligned(16))) float V3[4][NT3 * ESTRIDE];
+    __shared__ __attribute__((aligned(16))) float V4[4][NT4 * ESTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    if (DENSE)
-        for (int i = tid; i < 32 * 2 * 64; i += 256) {
-            const int o = i & 63, hh = (i >> 6) & 1, s = i >> 7;
-            Bl[i] = a.whT[(16 * (s >> 3) + 8 * hh + (s & 7)) * 64 + o];
-        }
+    for (int i = tid; i < 16 * 2 * 64; i += 256) {
+        const int o = i & 63, hh = (i >> 6) & 1, s = i >> 7;
+        Bl[i] = a.whT[(16 * (s >> 3) + 8 * hh + (s & 7)) * 64 + o];
+    }
     if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j]; }
-    if (tid < 64) { const int s = tid & 31, hh = tid >> 5; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)]; }
-    __syncthreads();
+    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)]; }
 
     const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
     const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
-    const float* a3 = a.a3 + (size_t)b * H8 * W8 * 16;
-    const float* a4 = a.a4 + (size_t)b * H32 * W32 * 16;
+    const float* E3 = a.E3 + (size_t)b * H8 * W8 * ESTRIDE;
+    const float* E4 = a.E4 + (size_t)b * H32 * W32 * ESTRIDE;
     const float sy2 = (float)(H2 - 1) / (float)(a.H - 1), sx2 = (float)(W2 - 1) / (float)(a.W - 1);
     const float sy8 = (float)(H8 - 1) / (float)(a.H - 1), sx8 = (float)(W8 - 1) / (float)(a.W - 1);
     const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
-    const int tiles_per_row = a.W / 32, ntiles = a.H * tiles_per_row;
-    const int tile0 = (blockIdx.x * 4 + wv) * HEAD_TILES;
-    for (int t = 0; t < HEAD_TILES; ++t) {
-        const int tile = tile0 + t;
-        if (tile >= ntiles) break;
-        const int y = tile / tiles_per_row, x0 = (tile - y * tiles_per_row) * 32, x = x0 + p;
+    const int tiles_per_row = a.W / 32, segs_per_row = (tiles_per_row + SEG_TILES - 1) / SEG_TILES;
+    const int seg = blockIdx.x * 4 + wv;
+    const bool live = seg < a.H * segs_per_row;
+    const int y = live ? seg / segs_per_row : 0, xs = live ? (seg - y * segs_per_row) * (32 * SEG_TILES) : 0;
+    const int ntile = live ? min(SEG_TILES, tiles_per_row - xs / 32) : 0;
+    // a 128-pixel segment spans < 16 source columns of the up8 map and < 4 of the up32 map (scale < 1/8, 1/32), a tile
+    // starts at most 12 (3) columns into the strip and uses 6 (4) rows from there: NT3 = 12 + 6, NT4 = 3 + 4
+    const int tb3 = (int)(sx8 * (float)xs), tb4 = (int)(sx32 * (float)xs);
+    if (live) {
+        build_strip<NT3>(V3[wv], E3, H8, W8, sy8, y, tb3, lane);
+        build_strip<NT4>(V4[wv], E4, H32, W32, sy32, y, tb4, lane);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntile; ++t) {
+        const int x0 = xs + 32 * t, x = x0 + p;
         const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
-        float f[32];
+        int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
+        asm volatile("" : "+v"(z));             // (hoisted, they would pin ~50 registers across it)
+        const float* Blz = Bl + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
+        float f[16];
         {   // group 0: relu(agg1 . x1), outputs 8h..8h+7 (ALike.py:147)
             const float4 lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8), hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
             const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -389,41 +464,64 @@ __global__ __launch_bounds__(256) void alike_head(HeadArgs a)
             for (int j = 0; j < 8; ++j) f[j] = 0.0f;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float4 w0 = *reinterpret_cast<const float4*>(&A1[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1[(h * 8 + c) * 8 + 4]);
+                const float4 w0 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8 + 4]);
                 f[0] = fmaf(v[c], w0.x, f[0]); f[1] = fmaf(v[c], w0.y, f[1]); f[2] = fmaf(v[c], w0.z, f[2]); f[3] = fmaf(v[c], w0.w, f[3]);
                 f[4] = fmaf(v[c], w1.x, f[4]); f[5] = fmaf(v[c], w1.y, f[5]); f[6] = fmaf(v[c], w1.z, f[6]); f[7] = fmaf(v[c], w1.w, f[7]);
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
         }
-        up8ch(a2, H2, W2, sy2, sx2, y, x, 8 * h, f + 8);      // ALike.py:151-153
-        up8ch(a3, H8, W8, sy8, sx8, y, x, 8 * h, f + 16);
-        up8ch(a4, H32, W32, sy32, sx32, y, x, 8 * h, f + 24);
+        up8ch(a2, H2, W2, sy2, sx2, y, x, 8 * h, f + 8);      // ALike.py:151
+
+        // x interpolation of the two coarse groups: source column and weight of this lane's pixel, relative to the tile
+        const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
+        const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;     // tile's first strip row
+        const int t3 = (int)fx3 - tb3 - rb3, t4 = (int)fx4 - tb4 - rb4;
+        const float lx3 = fx3 - (float)(int)fx3, lx4 = fx4 - (float)(int)fx4;
+        const float* v3 = V3[wv] + rb3 * ESTRIDE;
+        const float* v4 = V4[wv] + rb4 * ESTRIDE;
 
         float sc = 0.0f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float4 w = *reinterpret_cast<const float4*>(&Ws[h * 32 + 4 * q]);
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(&Wsz[h * 16 + 4 * q]);
             sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
         }
         sc += __shfl_xor(sc, 32, 64);
+        sc += (1.0f - lx3) * v3[t3 * ESTRIDE + 64] + lx3 * v3[(t3 + 1) * ESTRIDE + 64];
+        sc += (1.0f - lx4) * v4[t4 * ESTRIDE + 64] + lx4 * v4[(t4 + 1) * ESTRIDE + 64];
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
-        if (DENSE) {
-            f32x16 acc0 = {0}, acc1 = {0};
+
+        f32x16 acc0 = {0}, acc1 = {0};
 #pragma unroll
-            for (int s = 0; s < 32; ++s) {
-                const float b0 = Bl[(s * 2 + h) * 64 + p], b1 = Bl[(s * 2 + h) * 64 + 32 + p];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b1, acc1, 0, 0, 0);
-            }
-            // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
-            float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
+        for (int s = 0; s < 16; ++s) {
+            const float b0 = Blz[(s * 2 + h) * 64 + p], b1 = Blz[(s * 2 + h) * 64 + 32 + p];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b1, acc1, 0, 0, 0);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
-                d[(size_t)rowp * 64 + p] = acc0[r];
-                d[(size_t)rowp * 64 + 32 + p] = acc1[r];
-            }
+        for (int s = 0; s < 3; ++s) {
+            const int k = 2 * s + h;
+            const float w = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f);
+            const float b0 = v3[k * ESTRIDE + p], b1 = v3[k * ESTRIDE + 32 + p];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int k = 2 * s + h;
+            const float w = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f);
+            const float b0 = v4[k * ESTRIDE + p], b1 = v4[k * ESTRIDE + 32 + p];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
+        }
+        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
+        float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
+            d[(size_t)rowp * 64 + p] = acc0[r];
+            d[(size_t)rowp * 64 + 32 + p] = acc1[r];
         }
     }
 }
@@ -548,7 +646,7 @@ namespace {
 
 struct AlikeNet : kpb_net {
     float *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
-          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr, *S2 = nullptr, *S3 = nullptr, *S4 = nullptr;
+          *t4 = nullptr, *x4 = nullptr, *a4 = nullptr, *S2 = nullptr, *S3 = nullptr, *S4 = nullptr, *E3 = nullptr, *E4 = nullptr;
     HeadArgs head_args(float* score, float* desc)
     {
         HeadArgs h;
@@ -593,7 +691,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
                  n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
     const size_t n_s = B * (P / 4 + P / 64 + P / 1024) + 64;
-    const size_t total = n_x1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4 + n_s;
+    const size_t n_e = desc_out_dev ? B * (P / 64 + P / 1024) * ESTRIDE : 0;
+    const size_t total = n_x1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4 + n_s + n_e;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
@@ -603,6 +702,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     float* r3 = p; p += n_3;
     float* r4 = p; p += n_4;
     S2 = p; p += B * (P / 4); S3 = p; p += B * (P / 64); S4 = p; p += B * (P / 1024) + 64;
+    E3 = E4 = nullptr;
+    if (desc_out_dev) { E3 = p; p += B * (P / 64) * ESTRIDE; E4 = p; p += B * (P / 1024) * ESTRIDE; }
     this->B = batch; this->H = H; this->W = W;
     hipStream_t st = ctx->stream;
 
@@ -636,13 +737,14 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
     }
     // aggregation 1x1 + ReLU (147-150), each with its share of the score logit; agg1 is fused into the head
-    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4);
-    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64);
-    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024);
+    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4, nullptr, nullptr);
+    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64, wp("head.wT") + 32 * 64, E3);
+    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
     // upsample + concat + head (151-162)
     if (desc_out_dev) {
-        HeadArgs h = head_args(score_out_dev, desc_out_dev);
-        KPB_LAUNCH(ctx, "alike_head_dense", alike_head<true>, dim3(cdiv(H * (W / 32), 4 * HEAD_TILES), batch), dim3(256), 0, st, h);
+        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W};
+        const int segs = H * cdiv(W / 32, SEG_TILES);
+        KPB_LAUNCH(ctx, "alike_head_dense", alike_head_hyb, dim3(cdiv(segs, 4), batch), dim3(256), 0, st, hy);
     } else {
         LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W};
         KPB_LAUNCH(ctx, "alike_head_score", alike_score_lin, dim3(cdiv(H * W, 256), batch), dim3(256), 0, st, la);
