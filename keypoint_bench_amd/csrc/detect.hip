@@ -9,6 +9,8 @@
 // on stale neighbour state; every schedule ends in the same map.  nms_sweep therefore iterates whole
 // rounds inside LDS on a 32x64 tile with a 2r halo (no 207 MB unfold buffers, the 1.2 MB map stays in
 // L2), updates the map in place, and is re-launched until no tile changed.
+#include <algorithm>
+
 #include "kpb_common.h"
 
 namespace {
@@ -22,6 +24,9 @@ struct NmsArgs {
     int* tchg_cur;      // [B][ntiles] flags written by this sweep
     int* lastchg;       // [B] 1 + index of the last sweep that changed anything
     int* negflag;       // [B] set when a negative score is seen
+    int* ucount;        // [B] sweep 0 of nms_sweep_r: number of pixels it left undecided (alive, not confirmed) ...
+    int2* ulist;        // [B][2][ucap] ... as (raster index, -1) (null: not collected)
+    int ucap;
     int H, W, r, tiles_y, tiles_x, sweep, max_local;
 };
 
@@ -370,15 +375,32 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 
     const int by = ty * TH, bx = tx * TW;
     int changed = 0;
+    if (first && a.ulist) {     // the local rounds are over: maxlist and its counter are reused for the undecided pixels
+        __syncthreads();
+        if (tid == 0) { s_n[0] = 0; s_over = 0; }
+        __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
         const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
         const int gy = by + oy, gx = bx + ox;
+        bool undecided = false;
         if (gy < a.H && gx < a.W) {
             const float v = t[(oy + 2 * R) * PITCH + ox + 2 * R];
             if (v != orig[k]) changed = 1;
             if (first || v != orig[k]) out[(size_t)gy * a.W + gx] = v;
+            undecided = v > 0.0f;
         }
+        if (first && a.ulist) append(undecided, gy * a.W + gx, 0);     // what this tile could not settle goes to nms_tail
+    }
+    if (first && a.ulist) {
+        __syncthreads();
+        const int cnt = min(s_n[0], MAXLIST);
+        if (tid == 0) s_n[1] = cnt ? atomicAdd(&a.ucount[img], s_over ? a.ucap + cnt : cnt) : 0;   // overflow of the tile's list: poison the count
+        __syncthreads();
+        const int base = s_n[1];
+        for (int i = tid; i < cnt; i += NMS_THREADS)
+            if (base + i < a.ucap) a.ulist[(size_t)img * 2 * a.ucap + base + i] = make_int2(maxlist[i], -1);
     }
     if (changed) s_changed = 1;
     __syncthreads();
@@ -391,6 +413,108 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // A2 + A3 + A4: one 1024-thread workgroup per image.
+// ------------------------------------------------------------------------------------------------ sparse tail
+// After sweep 0 a few percent of the pixels are still undecided: alive, but with a rival in a neighbouring tile whose
+// fate the tile could not know.  They are settled here straight on the signed map in L2, one workgroup per image, by
+// the same two monotone rules: an undecided pixel dies when a confirmed maximum lies within r, and is confirmed once
+// nothing alive in its window is ahead of it (greater, or equal and earlier in raster order).  A pixel found blocked
+// remembers one blocker and is not rescanned while that blocker is alive (one load instead of a window per round).
+// The best undecided pixel always has a settled blocker, so every round settles something; reads of a neighbour's
+// stale state only delay a decision.  If the round limit is hit, status = 1 sends the image back to the tiled sweeps.
+struct TailArgs {
+    float* cur; int2* wlist; int* slist; int* ucount; int* status;
+    int ucap, H, W, r, max_rounds;
+};
+
+constexpr int TAIL_THREADS = 1024;
+
+template <int R>
+__global__ __launch_bounds__(TAIL_THREADS) void nms_tail(TailArgs a)
+{
+    constexpr int NGRP = TAIL_THREADS / 16, U = 4;      // 16 lanes scan one window; U windows per group in flight
+    static_assert(2 * R + 1 <= 17, "one 16-lane pass plus the centre-right column");
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, l = lane & 15, grp = tid >> 4;
+    float* cur = a.cur + (size_t)img * a.H * a.W;
+    int2* wl[2] = {a.wlist + (size_t)img * 2 * a.ucap, a.wlist + (size_t)img * 2 * a.ucap + a.ucap};
+    int* sl = a.slist + (size_t)img * a.ucap;
+    __shared__ int s_nw, s_ns;
+    const int total = a.ucount[img];
+    int nw = total <= a.ucap ? total : 0;       // an overflowed list is incomplete (and partly unwritten): leave the image to the tiled sweeps
+    const unsigned long long gmask = 0xFFFFull << (lane & 48);
+    int round = 0;
+    for (; round < a.max_rounds && nw > 0; ++round) {
+        if (tid == 0) { s_nw = 0; s_ns = 0; }
+        __syncthreads();
+        const int2* src = wl[round & 1];
+        int2* dst = wl[(round & 1) ^ 1];
+        // phase A: watchers whose blocker is still alive stay parked, the rest are due for a scan
+        for (int e = tid; e < nw; e += TAIL_THREADS) {
+            const int2 w = src[e];
+            if (w.y >= 0 && cur[w.y] > 0.0f) dst[atomicAdd(&s_nw, 1)] = w;
+            else sl[atomicAdd(&s_ns, 1)] = w.x;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int ns = s_ns;
+        // phase B: window scans (plain loads: the whole workgroup sits on one CU and shares its write-through L1, so the
+        // other groups' decisions are visible after the barrier that ends a round)
+        for (int e0 = 0; e0 < ns; e0 += NGRP * U) {
+            int idx[U], y[U], x[U], blk[U];
+            float v[U];
+            bool have[U], dead[U], blocked[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * NGRP + grp;
+                have[u] = e < ns;
+                idx[u] = have[u] ? sl[e] : 0;
+                y[u] = idx[u] / a.W; x[u] = idx[u] - y[u] * a.W;
+                dead[u] = false; blocked[u] = false; blk[u] = -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = cur[idx[u]];          // written only by this group: never stale
+            // lane l looks down column x - R + l of each window; for R = 8 lane 0 also takes the 17th column
+#pragma unroll
+            for (int c = 0; c < (2 * R + 1 + 15) / 16; ++c) {
+                const int dx = -R + l + 16 * c;
+                const bool col_ok = dx <= R && (c == 0 || l == 0);
+#pragma unroll
+                for (int dy = -R; dy <= R; ++dy) {
+                    float q[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int yy = y[u] + dy, xx = x[u] + dx;
+                        const bool in = have[u] && col_ok && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+                        q[u] = in ? cur[(size_t)yy * a.W + xx] : 0.0f;
+                    }
+                    const bool earlier = dy < 0 || (dy == 0 && dx < 0);
+                    const bool self = dy == 0 && dx == 0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        dead[u] |= q[u] < 0.0f;
+                        if (q[u] > 0.0f && !self && (earlier ? q[u] >= v[u] : q[u] > v[u])) { blocked[u] = true; blk[u] = idx[u] + dy * a.W + dx; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned long long bb = __ballot(blocked[u]) & gmask;
+                const bool any_dead = (__ballot(dead[u]) & gmask) != 0;
+                const int blocker = __shfl(blk[u], bb ? __ffsll((long long)bb) - 1 : 0, 64);
+                if (have[u] && l == 0) {
+                    if (any_dead) cur[idx[u]] = 0.0f;
+                    else if (!bb) cur[idx[u]] = -v[u];
+                    else dst[atomicAdd(&s_nw, 1)] = make_int2(idx[u], blocker);
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        nw = s_nw;
+        __syncthreads();
+    }
+    if (tid == 0) a.status[img] = (nw > 0 || total > a.ucap) ? 1 : 0;
+}
+
 __device__ __forceinline__ unsigned f2key(float v)
 {
     const unsigned u = __float_as_uint(v);
@@ -610,6 +734,10 @@ struct NmsPlan {
     int* tchg[2];
     int* lastchg;
     int* negflag;
+    int* ucount;        // sparse tail (r <= 8): undecided pixels of sweep 0
+    int2* ulist;        // [B][2][ucap] watch lists (ping-pong)
+    int* slist;         // [B][ucap] pixels due for a window scan
+    int ucap;
 };
 
 int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p)
@@ -620,13 +748,22 @@ int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p)
     const int LH = TH + 4 * r, LW = TW + 4 * r;
     p.lds = (size_t)2 * LH * LW * sizeof(float) + (MAXLIST + 4) * sizeof(int);
     const size_t nflag = (size_t)batch * p.ntiles;
-    const size_t bytes = (2 * nflag + 2 * (size_t)batch) * sizeof(int);
+    const size_t bytes = (2 * nflag + 3 * (size_t)batch) * sizeof(int);
     if (int rc = kpb_reserve(ctx, ctx->ws_nms_state, bytes)) return rc;
     int* base = static_cast<int*>(ctx->ws_nms_state.p);
     p.lastchg = base;
     p.negflag = base + batch;
-    p.tchg[0] = base + 2 * batch;
+    p.ucount = base + 2 * batch;
+    p.tchg[0] = base + 3 * batch;
     p.tchg[1] = p.tchg[0] + nflag;
+    p.ulist = nullptr;
+    p.ucap = 0;
+    if (r >= 1 && r <= 8 && !env_int("KPB_NMS_TILED", 0)) {
+        p.ucap = std::max(4096, H * W / 8);
+        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * 5 * p.ucap * sizeof(int))) return rc;
+        p.ulist = static_cast<int2*>(ctx->ws_nms_list.p);
+        p.slist = reinterpret_cast<int*>(p.ulist + (size_t)batch * 2 * p.ucap);
+    }
     static bool attr_set = false;
     if (!attr_set) {
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep),
@@ -647,6 +784,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.tchg_prev = p.tchg[(s + 1) & 1];
         a.tchg_cur = p.tchg[s & 1];
         a.lastchg = p.lastchg; a.negflag = p.negflag;
+        a.ucount = p.ucount; a.ulist = p.ulist; a.ucap = p.ucap;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s; a.max_local = env_int("KPB_NMS_MAXLOCAL", 64);
         const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
@@ -663,6 +801,34 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         }
     }
     KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+// The opening of every NMS run: clear the per-image state, sweep 0 and -- for the specialised radii -- the sparse tail,
+// which leaves lastchg[img] = 0 (settled) or 1 (round limit or list overflow: the caller's loop of tiled sweeps takes
+// over, with every tile marked as changed).  Returns the number of sweeps the status check has to account for.
+int nms_open(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int batch, int H, int W, int r, int chunk, int& sweeps_run)
+{
+    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 3 * (size_t)batch * sizeof(int), ctx->stream));
+    if (!p.ulist) {
+        sweeps_run = chunk;
+        return nms_launch(ctx, p, src, cur, batch, H, W, r, 0, chunk);
+    }
+    if (int rc = nms_launch(ctx, p, src, cur, batch, H, W, r, 0, 1)) return rc;
+    TailArgs t{cur, p.ulist, p.slist, p.ucount, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256)};
+    switch (r) {
+    case 1: KPB_LAUNCH(ctx, "nms_tail", nms_tail<1>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    case 2: KPB_LAUNCH(ctx, "nms_tail", nms_tail<2>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    case 3: KPB_LAUNCH(ctx, "nms_tail", nms_tail<3>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    case 4: KPB_LAUNCH(ctx, "nms_tail", nms_tail<4>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    case 5: KPB_LAUNCH(ctx, "nms_tail", nms_tail<5>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    case 6: KPB_LAUNCH(ctx, "nms_tail", nms_tail<6>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    case 7: KPB_LAUNCH(ctx, "nms_tail", nms_tail<7>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    default: KPB_LAUNCH(ctx, "nms_tail", nms_tail<8>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
+    }
+    KPB_HIP(ctx, hipMemsetAsync(p.tchg[0], 1, (size_t)batch * p.ntiles * sizeof(int), ctx->stream));   // "previous" flags of sweep 1
+    KPB_HIP(ctx, hipGetLastError());
+    sweeps_run = 1;
     return KPB_OK;
 }
 
@@ -705,12 +871,15 @@ extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx,
     }
     NmsPlan p;
     if (int rc = nms_plan(ctx, batch, H, W, nms_dist, p)) return rc;
-    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
     const int chunk = env_int("KPB_NMS_SWEEPS", 6);
     int run = 0, pending = 1, neg = 0;
     while (pending) {
-        if (int rc = nms_launch(ctx, p, score_dev, out_map_dev, batch, H, W, nms_dist, run, chunk)) return rc;
-        run += chunk;
+        if (run == 0) {
+            if (int rc = nms_open(ctx, p, score_dev, out_map_dev, batch, H, W, nms_dist, chunk, run)) return rc;
+        } else {
+            if (int rc = nms_launch(ctx, p, score_dev, out_map_dev, batch, H, W, nms_dist, run, chunk)) return rc;
+            run += chunk;
+        }
         if (int rc = nms_status(ctx, p, batch, run, pending, neg)) return rc;
         if (neg) return kpb_fail(ctx, KPB_E_NEGATIVE, "kpb_fast_nms: negative scores are outside this path's contract");
         if (run > 100000) return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_fast_nms: no fixed point after %d sweeps", run);
@@ -784,10 +953,8 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     if (prm->nms_dist > 0) {
         if (int rc = kpb_reserve(ctx, ctx->ws_nms_map, (size_t)batch * P * sizeof(float))) return rc;
         d.cur = static_cast<float*>(ctx->ws_nms_map.p);
-        KPB_HIP(ctx, hipMemsetAsync(d.plan.lastchg, 0, 2 * (size_t)batch * sizeof(int), ctx->stream));
         const int chunk = env_int("KPB_NMS_SWEEPS", 6);
-        if (int rc = nms_launch(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, 0, chunk)) return rc;
-        d.sweeps_run = chunk;
+        if (int rc = nms_open(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, chunk, d.sweeps_run)) return rc;
     }
     if (int rc = det_select(ctx, d)) return rc;
     ctx->det_pending = 1;

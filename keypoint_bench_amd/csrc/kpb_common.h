@@ -35,6 +35,7 @@ struct kpb_ctx {
     // named workspaces, grown on demand (first call of a shape = warm-up), never freed before destroy
     kpb_buf ws_nms_state;   // per-image / per-tile sweep flags
     kpb_buf ws_nms_map;     // [batch][H*W] working map
+    kpb_buf ws_nms_list;    // [batch][2][cap] undecided pixels handed from sweep 0 to the sparse tail
     kpb_buf ws_cand;        // [batch][H*W] uint64 candidate list (key<<32 | ~idx)
     kpb_buf ws_match;       // per-tile row/column minima
     kpb_buf ws_misc;
