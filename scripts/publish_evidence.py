@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Copy the summaries of scripts/collect_evidence.sh from gpurun_out/ into profiles/ (tracked).  Usage: publish_evidence.py r01"""
+import glob, json, os, shutil, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
+b = json.load(open(os.path.join(src, R, "bench_default.json")))
+B = b["config"]["pairs_per_step_per_gpu"]
+shutil.copy(glob.glob(os.path.join(src, R, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "%s_bench_default_kernel_stats.csv" % R))
+shutil.copy(os.path.join(src, R, "bench_default.json"), os.path.join(dst, "%s_bench_default.json" % R))
+shutil.copy(os.path.join(src, R, "bench_sparse.json"), os.path.join(dst, "%s_bench_sparse.json" % R))
+for mode in ("dense", "sparse"):
+    shutil.copy(os.path.join(src, "pmc_%s_%s" % (R, mode), "summary.txt"), os.path.join(dst, "%s_pmc_per_kernel_b%d_%s.csv" % (R, B, mode)))
+    shutil.copy(os.path.join(src, "pmc_%s_%s" % (R, mode), "traffic.json"), os.path.join(dst, "pmc_traffic_b%d_%s.json" % (B, mode)))
+print("published", R, "value", b["value"], "roofline", {k: b["roofline"][k] for k in ("kernel", "frac", "avg_ms", "traffic")})
