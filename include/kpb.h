@@ -149,6 +149,21 @@ int kpb_val_keypoints(kpb_ctx* ctx, const float* k0_dev, const float* k01_dev, c
                       const int32_t* n_dev, const float* scale_dev, float th, int32_t* out_pairs_dev,
                       float* out_dist_dev, int cap, float* out_errors_dev, int32_t* out_counts_dev);
 
+/* ---- 8(f)4: the tensor Lucas-Kanade tracker, utils/matcher.py:7-142 OpticalFlow ------------------
+ * img1_dev, img2_dev [C][H][W] planar fp32 (the reference's [1,C,H,W]); pts1_dev / pts2_dev [n][pts_stride]
+ * normalised (x, y, ...): where the points are in image 1 and where they are expected in image 2;
+ * unit_dev [n][2] = (cos, sin) of the random start angles the reference draws (matcher.py:55-56; the
+ * caller draws them so that runs are reproducible).  Pyramid of `levels` (avg-pool 2i), `iterations`
+ * Gauss-Newton steps per level on a win_size x win_size x C window.  out_pts_dev [n][2] in PIXELS of the
+ * full image, as the reference returns them; out_err_dev [n] = min(|out - pts2|, 8). */
+typedef struct kpb_lk_params {
+    float distance;
+    int32_t win_size, levels, iterations;
+} kpb_lk_params;
+int kpb_lk_track(kpb_ctx* ctx, const float* img1_dev, const float* img2_dev, int C, int H, int W,
+                 const float* pts1_dev, const float* pts2_dev, int pts_stride, const float* unit_dev,
+                 int n, const kpb_lk_params* params, float* out_pts_dev, float* out_err_dev);
+
 /* ---- N1..: extractor networks (models/ALike.py:136-164 ALNet.forward, ...) ---------------------
  * arch: KPB_ARCH_*.  blob: a .kpbw container (keypoint_bench_amd/weights.py) holding the folded
  * tensors; copied, the caller may free it. */

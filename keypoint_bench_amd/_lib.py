@@ -20,6 +20,10 @@ class LgParams(ctypes.Structure):
                 ("prune_min_kpts", ctypes.c_int32)]
 
 
+class LkParams(ctypes.Structure):           # kpb_lk_params
+    _fields_ = [("distance", ctypes.c_float), ("win_size", ctypes.c_int32), ("levels", ctypes.c_int32), ("iterations", ctypes.c_int32)]
+
+
 class MatchParams(ctypes.Structure):
     _fields_ = [("max_distance", c_double), ("cross_check", ctypes.c_int32)]
 
@@ -48,6 +52,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p]),
     "kpb_val_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "kpb_lk_track": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                             c_void_p, c_void_p, c_void_p]),
     "kpb_net_create": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "kpb_net_destroy": (None, [c_void_p]),
     "kpb_net_desc_dim": (c_int, [c_void_p]),

@@ -216,7 +216,8 @@ def install():
     from .utils import extracter as ex, matcher as ma
     swapped = []
     for modname, names in (("utils.extracter", {"detection": ex.detection, "fast_nms": ex.fast_nms}),
-                           ("utils.matcher", {"brute_force_matcher": ma.brute_force_matcher}),
+                           ("utils.matcher", {"brute_force_matcher": ma.brute_force_matcher, "OpticalFlow": ma.OpticalFlow,
+                                              "optical_flow_tensor": ma.optical_flow_tensor}),
                            ("models.ALike", {"ALNet": ALNet}), ("models.SuperPoint", {"SuperPointNet": SuperPointNet}),
                            ("models.XFeat", {"XFeatModel": XFeatModel}), ("models.disk", {"DISK": DISK})):
         try:
@@ -247,7 +248,7 @@ def install():
     for name, mod in list(sys.modules.items()):
         if mod is None or not (name.startswith("tasks.") or name == "models.model_interface"):
             continue
-        for k, v in (("detection", ex.detection), ("brute_force_matcher", ma.brute_force_matcher), ("ALNet", ALNet),
+        for k, v in (("detection", ex.detection), ("brute_force_matcher", ma.brute_force_matcher), ("optical_flow_tensor", ma.optical_flow_tensor), ("ALNet", ALNet),
                      ("SuperPointNet", SuperPointNet), ("XFeatModel", XFeatModel), ("DISK", DISK)):
             if hasattr(mod, k):
                 setattr(mod, k, v)

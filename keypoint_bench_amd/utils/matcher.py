@@ -4,7 +4,7 @@ import ctypes
 
 import torch
 
-from .._lib import Context, MatchParams, ptr
+from .._lib import Context, LkParams, MatchParams, ptr
 
 
 def sample_descriptors(pts: torch.Tensor, desc_map, n=None) -> torch.Tensor:
@@ -75,3 +75,47 @@ def brute_force_matcher(pts0: torch.Tensor, pts1: torch.Tensor, desc_map_0, desc
                                           ptr(out)))
         outs.append(out)
     return outs[0], outs[1]
+
+
+class OpticalFlow(object):
+    """utils/matcher.py:7-142: pyramidal Lucas-Kanade on win_size x win_size x C windows, computed by csrc/lk.hip (one
+    wave per keypoint, nothing unfolded).  Same constructor keys, same call, same return: (points [1,N,2] in PIXELS of
+    the full image, error [1,N])."""
+
+    def __init__(self, params=None):
+        if params is None:
+            params = {"distance": 3, "win_size": 3, "levels": 1, "interation": 40, "gray": False}      # matcher.py:9-16
+        self.distance, self.win_size, self.levels = params["distance"], params["win_size"], params["levels"]
+        self.interation, self.gray = params["interation"], params["gray"]
+
+    def __call__(self, img1, img2, pts1, pts2, random_angle=None):
+        if not img1.is_cuda:
+            raise RuntimeError("keypoint_bench_amd needs CUDA/HIP tensors; there is no CPU path")
+        N, C, H, W = img1.shape
+        if N != 1:
+            raise ValueError("one image pair per call (the reference indexes batch element 0, matcher.py:60)")
+        if C != (1 if self.gray else 3):        # the reference's Sobel weight is [C,C,3,3] with C fixed by `gray` (26-36)
+            raise ValueError("images must have %d channel(s) for gray=%s" % (1 if self.gray else 3, self.gray))
+        dev = img1.device
+        a = img1.detach().to(torch.float32).contiguous()
+        b = img2.detach().to(torch.float32).contiguous()
+        p1 = pts1.detach().to(torch.float32).contiguous()
+        p2 = pts2.detach().to(torch.float32).contiguous()
+        n = p1.shape[0]
+        if random_angle is None:
+            random_angle = torch.randn(n, device=dev) * 6.28                                             # 55
+        unit = torch.stack([torch.cos(random_angle), torch.sin(random_angle)], dim=1).to(torch.float32).contiguous()   # 56
+        out = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        err = torch.empty((n,), dtype=torch.float32, device=dev)
+        if n:
+            ctx = Context.get(dev)
+            prm = LkParams(float(self.distance), int(self.win_size), int(self.levels), int(self.interation))
+            ctx.check(ctx.lib.kpb_lk_track(ctx.handle, ptr(a), ptr(b), C, H, W, ptr(p1), ptr(p2), p1.shape[1], ptr(unit), n,
+                                           ctypes.byref(prm), ptr(out), ptr(err)))
+        return out.unsqueeze(0), err.unsqueeze(0)
+
+
+def optical_flow_tensor(pts0, pts1, img0, img1, params=None):
+    """utils/matcher.py:186-203."""
+    pts1_, _ = OpticalFlow(params)(img0, img1, pts0, pts1)
+    return pts1_

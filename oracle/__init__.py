@@ -53,6 +53,9 @@ def lib():
         L.kpbo_val_keypoints.argtypes = [fp, fp, ctypes.c_int, fp, fp, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                          ip, fp, ctypes.c_long, fp]
         L.kpbo_val_keypoints.restype = ctypes.c_long
+        L.kpbo_lk_track.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, ctypes.c_int, ctypes.c_float,
+                                    ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
+        L.kpbo_lk_track.restype = None
         _lib = L
     return _lib
 
@@ -163,3 +166,18 @@ def val_key_points(kps0, kps1, warp01, warp10, th=3, fused=-1):
     sel = dist[dist <= th]
     return dict(num_feat=num_feat, repeatability=np.float32(len(sel)) / np.float32(num_feat), mean_error=sel.mean() if len(sel) else np.float32("nan"),
                 errors=errors, pairs=pairs[:K].astype(np.int64), dist=dist.copy())
+
+
+def lk_track(img1_chw, img2_chw, pts1, pts2, unit, distance=3, win_size=3, levels=1, interation=40):
+    """utils/matcher.py:7-142 OpticalFlow(params)(img1, img2, pts1, pts2) for one pair; `unit` [n,2] are the (cos, sin)
+    of the reference's random angles.  Returns (pts [n,2] in pixels, error [n])."""
+    a, b = _f32(img1_chw), _f32(img2_chw)
+    C, H, W = a.shape
+    p1, p2, u = _f32(pts1)[:, :2].copy(), _f32(pts2)[:, :2].copy(), _f32(unit)
+    n = p1.shape[0]
+    out = np.empty((n, 2), np.float32)
+    err = np.empty((n,), np.float32)
+    if n:
+        lib().kpbo_lk_track(_fp(a), _fp(b), C, H, W, _fp(p1), _fp(p2), _fp(u), n, float(distance), int(win_size), int(levels),
+                            int(interation), _fp(out), _fp(err))
+    return out, err

@@ -315,3 +315,162 @@ long kpbo_val_keypoints(const float* k0, const float* k01, int M, const float* k
     free(dm); free(rmin); free(cmin);
     return K;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * the tensor Lucas-Kanade tracker, utils/matcher.py:7-142 (OpticalFlow).
+ *
+ * The reference unfolds six win*win*C-channel patch maps per level (93-107) and grid_samples them at the
+ * keypoints (110, 116-119).  Sampling the unfolded map at (px, py) equals, for window cell (ky, kx),
+ *     sum over the four bilinear taps (xt, yt) of (px, py) that lie inside the image (grid_sample's zero padding)
+ *         w_t * img[c][yt + ky - r][xt + kx - r]        (0 outside the image: unfold's zero padding, 93)
+ * which is what sample_cell() computes, so nothing is materialised.  All arithmetic fp32 as in the reference.
+ * Sums over the window run in (c, ky, kx) order; torch's einsum order differs, so agreement with the reference is
+ * to rounding (see tests/test_oracle_lk.py for the tolerance), not bit for bit. */
+static float lk_pix(const float* img, int H, int W, int y, int x)
+{
+    return (y >= 0 && y < H && x >= 0 && x < W) ? img[(size_t)y * W + x] : 0.0f;
+}
+
+/* Sobel pair of matcher.py:23-24 as conv2d (cross-correlation, zero padding 1) evaluates it (87-90) */
+static void lk_sobel(const float* img, int H, int W, float* dx, float* dy)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float sx = 0.f, sy = 0.f;
+            static const float kx[3][3] = {{1, 0, -1}, {2, 0, -2}, {1, 0, -1}};
+            static const float ky[3][3] = {{1, 2, 1}, {0, 0, 0}, {-1, -2, -1}};
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    const float v = lk_pix(img, H, W, y + i - 1, x + j - 1);
+                    sx += kx[i][j] * v; sy += ky[i][j] * v;
+                }
+            dx[(size_t)y * W + x] = sx; dy[(size_t)y * W + x] = sy;
+        }
+}
+
+typedef struct { int x0, y0; float w[4]; int ok[4]; } lk_taps;
+
+/* grid_sample(align_corners=True, bilinear, zeros) tap set of pixel position (px, py), reached through the
+ * reference's normalise (109, 115) / ATen's unnormalise round trip */
+static lk_taps lk_make_taps(float px, float py, int H, int W)
+{
+    lk_taps t;
+    const float gx = px / (float)(W - 1) * 2.0f - 1.0f, gy = py / (float)(H - 1) * 2.0f - 1.0f;
+    const float ix = (gx + 1.0f) * ((float)(W - 1) / 2.0f), iy = (gy + 1.0f) * ((float)(H - 1) / 2.0f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float wx = ix - fx, wy = iy - fy, ex = 1.0f - wx, sy = 1.0f - wy;
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    t.w[0] = sy * ex; t.w[1] = sy * wx; t.w[2] = wy * ex; t.w[3] = wy * wx;       /* nw, ne, sw, se */
+    for (int k = 0; k < 4; ++k) {
+        const int xt = t.x0 + (k & 1), yt = t.y0 + (k >> 1);
+        t.ok[k] = xt >= 0 && xt < W && yt >= 0 && yt < H;
+    }
+    return t;
+}
+
+static float lk_sample_cell(const float* img, int H, int W, const lk_taps* t, int oy, int ox)
+{
+    float s = 0.0f;
+    for (int k = 0; k < 4; ++k)
+        if (t->ok[k]) s += lk_pix(img, H, W, t->y0 + (k >> 1) + oy, t->x0 + (k & 1) + ox) * t->w[k];
+    return s;
+}
+
+/* optical_flow_level, matcher.py:77-133, for one image pair.  img1/img2 [C][H][W]; pts1/pts2 [n][2] pixel positions
+ * at this level; pts2 is updated in place (pts_pre). */
+static void lk_level(const float* img1, const float* img2, int C, int H, int W, const float* pts1, float* pts2, int n,
+                     int win, int iters)
+{
+    const int r = win / 2, E = C * win * win;
+    const size_t P = (size_t)H * W;
+    float* dx2 = (float*)malloc(P * C * sizeof(float));
+    float* dy2 = (float*)malloc(P * C * sizeof(float));
+    float* p1 = (float*)malloc((size_t)E * sizeof(float));
+    for (int c = 0; c < C; ++c) lk_sobel(img2 + c * P, H, W, dx2 + c * P, dy2 + c * P);
+    for (int i = 0; i < n; ++i) {
+        const lk_taps t1 = lk_make_taps(pts1[2 * i], pts1[2 * i + 1], H, W);
+        int e = 0;
+        for (int c = 0; c < C; ++c)
+            for (int ky = 0; ky < win; ++ky)
+                for (int kx = 0; kx < win; ++kx) p1[e++] = lk_sample_cell(img1 + c * P, H, W, &t1, ky - r, kx - r);
+        float px = pts2[2 * i], py = pts2[2 * i + 1];
+        for (int it = 0; it < iters; ++it) {
+            const lk_taps t = lk_make_taps(px, py, H, W);
+            float g00 = 0.f, g01 = 0.f, g11 = 0.f, b0 = 0.f, b1 = 0.f;
+            e = 0;
+            for (int c = 0; c < C; ++c)
+                for (int ky = 0; ky < win; ++ky)
+                    for (int kx = 0; kx < win; ++kx, ++e) {
+                        const float v = lk_sample_cell(img2 + c * P, H, W, &t, ky - r, kx - r);
+                        const float jx = lk_sample_cell(dx2 + c * P, H, W, &t, ky - r, kx - r);
+                        const float jy = lk_sample_cell(dy2 + c * P, H, W, &t, ky - r, kx - r);
+                        const float dI = p1[e] - v;                                   /* 117 */
+                        g00 += jx * jx; g01 += jx * jy; g11 += jy * jy;               /* 121 */
+                        b0 += dI * jx; b1 += dI * jy;                                 /* 122 */
+                    }
+            const float det = g00 * g11 - g01 * g01;                                  /* 123 */
+            if (det > 1e-6f) {
+                /* inverse (124); the update einsum 'bik,bk->bk' (125) sums the inverse over its SECOND index and
+                 * multiplies row-wise: dx = (inv00 + inv01) * b0, dy = (inv10 + inv11) * b1 */
+                const float i00 = g11 / det, i01 = -g01 / det, i11 = g00 / det;
+                px = px - (i00 + i01) * b0;
+                py = py - (i01 + i11) * b1;
+            }
+        }
+        pts2[2 * i] = px; pts2[2 * i + 1] = py;
+    }
+    free(dx2); free(dy2); free(p1);
+}
+
+static void lk_avgpool(const float* img, int C, int H, int W, int k, float* out)
+{
+    const int Ho = H / k, Wo = W / k;
+    for (int c = 0; c < C; ++c)
+        for (int y = 0; y < Ho; ++y)
+            for (int x = 0; x < Wo; ++x) {
+                float s = 0.f;
+                for (int i = 0; i < k; ++i)
+                    for (int j = 0; j < k; ++j) s += img[(size_t)c * H * W + (size_t)(y * k + i) * W + x * k + j];
+                out[(size_t)c * Ho * Wo + (size_t)y * Wo + x] = s / (float)(k * k);
+            }
+}
+
+/* OpticalFlow.__call__, matcher.py:48-75.  pts1, pts2 [n][2] normalised; unit [n][2] = (cos, sin) of the random angles
+ * (55-56; drawn by the caller so that runs can be compared).  out_pts [n][2] in PIXELS of the full image (as the
+ * reference returns them), out_err [n] (73). */
+void kpbo_lk_track(const float* img1, const float* img2, int C, int H, int W, const float* pts1, const float* pts2,
+                   const float* unit, int n, float distance, int win, int levels, int iters, float* out_pts, float* out_err)
+{
+    float* p1 = (float*)malloc((size_t)n * 2 * sizeof(float));
+    float* p2 = (float*)malloc((size_t)n * 2 * sizeof(float));
+    float* cur = (float*)malloc((size_t)n * 2 * sizeof(float));
+    float* l1 = (float*)malloc((size_t)n * 2 * sizeof(float));
+    for (int i = 0; i < n; ++i) {
+        p1[2 * i] = pts1[2 * i] * (float)(W - 1); p1[2 * i + 1] = pts1[2 * i + 1] * (float)(H - 1);      /* 51 */
+        p2[2 * i] = pts2[2 * i] * (float)(W - 1); p2[2 * i + 1] = pts2[2 * i + 1] * (float)(H - 1);      /* 52 */
+        float x = p2[2 * i] + unit[2 * i] * distance, y = p2[2 * i + 1] + unit[2 * i + 1] * distance;    /* 59 */
+        x = fminf(fmaxf(x, 10.f), (float)(W - 10)); y = fminf(fmaxf(y, 10.f), (float)(H - 10));          /* 60-61 */
+        cur[2 * i] = x; cur[2 * i + 1] = y;
+    }
+    for (int lv = 0; lv < levels; ++lv) {                                                                /* 76-87 */
+        const int idx = levels - lv - 1;
+        const float scale = (float)(1 << idx);
+        const int k = idx == 0 ? 1 : 2 * idx;                      /* build_pyramid (45): level i>0 is avg_pool2d(img, 2i, 2i) */
+        const int Hl = H / k, Wl = W / k;
+        float *a = (float*)img1, *b = (float*)img2;
+        if (k > 1) {
+            a = (float*)malloc((size_t)C * Hl * Wl * sizeof(float)); b = (float*)malloc((size_t)C * Hl * Wl * sizeof(float));
+            lk_avgpool(img1, C, H, W, k, a); lk_avgpool(img2, C, H, W, k, b);
+        }
+        for (int i = 0; i < 2 * n; ++i) { l1[i] = p1[i] / scale; cur[i] = cur[i] / scale; }               /* 79-80 */
+        lk_level(a, b, C, Hl, Wl, l1, cur, n, win, iters);
+        for (int i = 0; i < 2 * n; ++i) cur[i] = cur[i] * scale;                                          /* 85 */
+        if (k > 1) { free(a); free(b); }
+    }
+    for (int i = 0; i < n; ++i) {
+        const float dx = cur[2 * i] - p2[2 * i], dy = cur[2 * i + 1] - p2[2 * i + 1];
+        out_pts[2 * i] = cur[2 * i]; out_pts[2 * i + 1] = cur[2 * i + 1];
+        out_err[i] = fminf(sqrtf(dx * dx + dy * dy), 8.0f);                                               /* 73 */
+    }
+    free(p1); free(p2); free(cur); free(l1);
+}
