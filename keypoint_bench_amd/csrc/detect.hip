@@ -758,7 +758,11 @@ int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p)
     p.tchg[1] = p.tchg[0] + nflag;
     p.ulist = nullptr;
     p.ucap = 0;
-    if (r >= 1 && r <= 8 && !env_int("KPB_NMS_TILED", 0)) {
+    // The tail is one workgroup per image and latency-bound (about 1.4 ms whatever the batch); four more tiled sweeps
+    // cost about 8 us per 480x640 image.  It pays once the batch fills the chip.  KPB_NMS_TILED=1 / =0 force a choice.
+    const int tiled = env_int("KPB_NMS_TILED", -1);
+    const bool big = (size_t)batch * H * W >= (size_t)192 * 480 * 640;
+    if (r >= 1 && r <= 8 && (tiled == 0 || (tiled < 0 && big))) {
         p.ucap = std::max(4096, H * W / 8);
         if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * 5 * p.ucap * sizeof(int))) return rc;
         p.ulist = static_cast<int2*>(ctx->ws_nms_list.p);

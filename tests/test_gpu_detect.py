@@ -138,6 +138,7 @@ def test_nms_schedules_agree(mode, monkeypatch):
     else:
         m = np.stack([synthetic.score_smooth(21, 480, 640), synthetic.score_uniform(22, 480, 640)])[:, None]
     s = torch.from_numpy(m).to(_dev())
+    monkeypatch.setenv("KPB_NMS_TILED", "0")            # small batches default to the tiled sweeps: force the tail
     want = fast_nms(s, 6).cpu().numpy()
     if mode == "tiled-only":
         monkeypatch.setenv("KPB_NMS_TILED", "1")
