@@ -119,6 +119,33 @@ def test_device_counts_and_batch_through_the_abi():
         np.testing.assert_array_equal(errors[b, : int(m[b])].cpu().numpy(), G[p + "errors"])
 
 
+def test_warp_batch_with_device_counts():
+    """Two images in one kpb_warp_homography call, ragged by device-side counts, against the single-image results."""
+    from keypoint_bench_amd._lib import Context, ptr
+    ctx = Context.get(torch.device(DEV))
+    cs = (2, 1)
+    n_max = max(len(G["c%d_kps0" % c]) for c in cs)
+    kps = torch.zeros((2, n_max, 3), device=DEV)
+    n = torch.zeros(2, dtype=torch.int32, device=DEV)
+    hm = torch.zeros((2, 9), device=DEV); wh = torch.zeros((2, 2), dtype=torch.int32, device=DEV)
+    for b, c in enumerate(cs):
+        p = "c%d_" % c
+        k = torch.from_numpy(G[p + "kps0"])
+        kps[b, : len(k)] = k; n[b] = len(k)
+        hm[b] = torch.from_numpy(G[p + "hm"]).reshape(9); wh[b] = torch.from_numpy(G[p + "wh1"].astype(np.int32))
+    a = torch.zeros((2, n_max, 2), device=DEV); bb = torch.zeros_like(a)
+    ids = torch.full((2, n_max), -1, dtype=torch.int32, device=DEV); nv = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ctx.check(ctx.lib.kpb_warp_homography(ctx.handle, ptr(kps), 2, n_max, 3, ptr(n), ptr(hm), ptr(wh), ptr(a), ptr(bb), ptr(ids), ptr(nv)))
+    for b, c in enumerate(cs):
+        p = "c%d_" % c
+        k = int(nv[b])
+        assert k == len(G[p + "ids"])
+        np.testing.assert_array_equal(ids[b, :k].cpu().numpy(), G[p + "ids"])
+        np.testing.assert_array_equal(ids[b, k: int(n[b])].cpu().numpy(), G[p + "ids_out"])
+        np.testing.assert_array_equal(a[b, :k].cpu().numpy(), G[p + "k0v"])
+        np.testing.assert_array_equal(bb[b, :k].cpu().numpy(), G[p + "k01v"])
+
+
 def test_full_size_properties():
     """8192 keypoints per side: identity keeps everything in order; a warp followed by its inverse returns the points;
     the number of mutual cells is symmetric under swapping the two images."""
