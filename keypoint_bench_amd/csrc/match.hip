@@ -62,7 +62,8 @@ __device__ __forceinline__ bool precedes(double s1, int i1, double s2, int i2)
     return s1 < s2;
 }
 
-constexpr int MT = 64, KC = 32, MATCH_THREADS = 256;
+constexpr int TM = 4, TN = 8;                                 // distances per thread: TM rows x TN columns
+constexpr int MTI = 16 * TM, MTJ = 16 * TN, KC = 16, MATCH_THREADS = 256;
 
 struct MatchArgs {
     const float* d0; const float* d1; const int* n; const int* m;
@@ -71,44 +72,61 @@ struct MatchArgs {
     int C, max_n, max_m, tiles_i, tiles_j;
 };
 
+// One MTI x MTJ tile of the distance matrix per workgroup, TM x TN of it per thread: every float64 operand read from LDS
+// feeds TN (TM) subtract / multiply / add triples, which keeps the LDS pipe far below the vector ALUs' rate.
 __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
 {
-    __shared__ __attribute__((aligned(16))) double A[KC][MT];
-    __shared__ __attribute__((aligned(16))) double Bt[KC][MT];
-    __shared__ double cs[16][MT];
-    __shared__ int ci[16][MT];
+    constexpr int STAGE = KC * (MTI + MTJ) * 2, RED = 16 * MTJ * 3;       // words: operand tiles / column-minimum exchange
+    __shared__ __attribute__((aligned(16))) unsigned smem[STAGE > RED ? STAGE : RED];
+    double (*A)[MTI] = reinterpret_cast<double (*)[MTI]>(smem);
+    double (*Bt)[MTJ] = reinterpret_cast<double (*)[MTJ]>(smem + KC * MTI * 2);
     const int b = blockIdx.z, tj = blockIdx.x, ti = blockIdx.y, tid = threadIdx.x;
     const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
-    const int i0 = ti * MT, j0 = tj * MT;
+    const int i0 = ti * MTI, j0 = tj * MTJ;
     if (i0 >= n || j0 >= m) return;   // partials of empty tiles are never read (finalize clips to n, m)
     const float* d0 = a.d0 + (size_t)b * a.max_n * a.C;
     const float* d1 = a.d1 + (size_t)b * a.max_m * a.C;
-    const int r = tid >> 4, c = tid & 15;        // thread owns rows i0+4r.., cols j0+4c..
-    double acc[4][4];
+    const int r = tid >> 4, c = tid & 15;        // thread owns rows i0+TM*r.., cols j0+TN*c..
+    double acc[TM][TN];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < TM; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[p][q] = 0.0;
+        for (int q = 0; q < TN; ++q) acc[p][q] = 0.0;
 
+    const bool vec = (a.C % 4) == 0;
     for (int k0 = 0; k0 < a.C; k0 += KC) {
-        // stage KC channels of 64 rows of each side as float64, channel-major
-        for (int x = tid; x < MT * KC; x += MATCH_THREADS) {
-            const int row = x & (MT - 1), k = x / MT;
-            const int kk = k0 + k;
-            const int gi = min(i0 + row, n - 1), gj = min(j0 + row, m - 1);
-            A[k][row] = (kk < a.C) ? (double)d0[(size_t)gi * a.C + kk] : 0.0;
-            Bt[k][row] = (kk < a.C) ? (double)d1[(size_t)gj * a.C + kk] : 0.0;
+        // stage KC channels of the tile's rows of each side as float64, channel-major (float4 loads when C allows)
+        if (vec) {
+            for (int x = tid; x < (MTI + MTJ) * (KC / 4); x += MATCH_THREADS) {
+                const int row = x / (KC / 4), kq = x - row * (KC / 4), kk = k0 + 4 * kq;
+                const bool second = row >= MTI;
+                const int lr = second ? row - MTI : row;
+                const float* src = second ? d1 + (size_t)min(j0 + lr, m - 1) * a.C : d0 + (size_t)min(i0 + lr, n - 1) * a.C;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kk < a.C) v = *reinterpret_cast<const float4*>(src + kk);
+                double* dst = second ? &Bt[4 * kq][lr] : &A[4 * kq][lr];
+                const int pitch = second ? MTJ : MTI;
+                dst[0] = (double)v.x; dst[pitch] = (double)v.y; dst[2 * pitch] = (double)v.z; dst[3 * pitch] = (double)v.w;
+            }
+        } else {
+            for (int x = tid; x < (MTI + MTJ) * KC; x += MATCH_THREADS) {
+                const int row = x % (MTI + MTJ), k = x / (MTI + MTJ), kk = k0 + k;
+                if (row < MTI) A[k][row] = (kk < a.C) ? (double)d0[(size_t)min(i0 + row, n - 1) * a.C + kk] : 0.0;
+                else Bt[k][row - MTI] = (kk < a.C) ? (double)d1[(size_t)min(j0 + row - MTI, m - 1) * a.C + kk] : 0.0;
+            }
         }
         __syncthreads();
         const int kend = min(KC, a.C - k0);
         for (int k = 0; k < kend; ++k) {
-            double av[4], bv[4];
+            double av[TM], bv[TN];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { av[p] = A[k][4 * r + p]; bv[p] = Bt[k][4 * c + p]; }
+            for (int p = 0; p < TM; ++p) av[p] = A[k][TM * r + p];
 #pragma unroll
-            for (int p = 0; p < 4; ++p)
+            for (int q = 0; q < TN; ++q) bv[q] = Bt[k][TN * c + q];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+            for (int p = 0; p < TM; ++p)
+#pragma unroll
+                for (int q = 0; q < TN; ++q) {
                     const double d = __dsub_rn(av[p], bv[q]);
                     acc[p][q] = __dadd_rn(acc[p][q], __dmul_rn(d, d));   // no FMA: scipy's s += d*d
                 }
@@ -116,15 +134,15 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
         __syncthreads();
     }
 
-    // row minima over this tile's columns: 4 local columns, then the 16 lanes that share r
+    // row minima over this tile's columns: TN local columns, then the 16 lanes that share r
     const int lane = tid & 63;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < TM; ++p) {
         double bs = __longlong_as_double(0x7FF0000000000000LL);
         int bj = 0x7FFFFFFF;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = j0 + 4 * c + q;
+        for (int q = 0; q < TN; ++q) {
+            const int j = j0 + TN * c + q;
             if (j < m && precedes(acc[p][q], j, bs, bj)) { bs = acc[p][q]; bj = j; }
         }
 #pragma unroll
@@ -133,26 +151,29 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
             const int oj = __shfl_xor(bj, d, 64);
             if (precedes(os, oj, bs, bj)) { bs = os; bj = oj; }
         }
-        const int i = i0 + 4 * r + p;
+        const int i = i0 + TM * r + p;
         if ((lane & 15) == 0 && i < n) {
             const size_t o = ((size_t)b * a.tiles_j + tj) * a.max_n + i;
             a.rpart_s[o] = bs; a.rpart_j[o] = bj;
         }
     }
-    // column minima over this tile's rows: 4 local rows, then across the 16 row groups through LDS
+    // column minima over this tile's rows: TM local rows, then across the 16 row groups through LDS (the operand
+    // tiles are dead: the last k loop ended with a barrier)
+    double (*cs)[MTJ] = reinterpret_cast<double (*)[MTJ]>(smem);
+    int (*ci)[MTJ] = reinterpret_cast<int (*)[MTJ]>(smem + 16 * MTJ * 2);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < TN; ++q) {
         double bs = __longlong_as_double(0x7FF0000000000000LL);
         int bi = 0x7FFFFFFF;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int i = i0 + 4 * r + p;
+        for (int p = 0; p < TM; ++p) {
+            const int i = i0 + TM * r + p;
             if (i < n && precedes(acc[p][q], i, bs, bi)) { bs = acc[p][q]; bi = i; }
         }
-        cs[r][4 * c + q] = bs; ci[r][4 * c + q] = bi;
+        cs[r][TN * c + q] = bs; ci[r][TN * c + q] = bi;
     }
     __syncthreads();
-    if (tid < MT) {
+    if (tid < MTJ) {
         double bs = cs[0][tid]; int bi = ci[0][tid];
         for (int g = 1; g < 16; ++g)
             if (precedes(cs[g][tid], ci[g][tid], bs, bi)) { bs = cs[g][tid]; bi = ci[g][tid]; }
@@ -181,7 +202,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
     __shared__ int wsum[FIN_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
-    const int tiles_i = (n + MT - 1) / MT, tiles_j = (m + MT - 1) / MT;
+    const int tiles_i = (n + MTI - 1) / MTI, tiles_j = (m + MTJ - 1) / MTJ;
     for (int j = tid; j < m; j += FIN_THREADS) {   // argmin(distances, axis=0)
         double bs = __longlong_as_double(0x7FF0000000000000LL);
         int bi = 0x7FFFFFFF;
@@ -273,7 +294,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
     }
     if (!d0_dev || !d1_dev || !out_pairs_dev) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: null buffer");
     if (max_m > 16384) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: max_m %d > 16384", max_m);
-    const int tiles_i = cdiv(max_n, MT), tiles_j = cdiv(max_m, MT);
+    const int tiles_i = cdiv(max_n, MTI), tiles_j = cdiv(max_m, MTJ);
     const size_t nr = (size_t)batch * tiles_j * max_n, nc = (size_t)batch * tiles_i * max_m;
     const size_t bytes = (nr + nc) * (sizeof(double) + sizeof(int)) + 64;
     if (int rc = kpb_reserve(ctx, ctx->ws_match, bytes)) return rc;
