@@ -790,7 +790,10 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.lastchg = p.lastchg; a.negflag = p.negflag;
         a.ucount = p.ucount; a.ulist = p.ulist; a.ucap = p.ucap;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
-        a.sweep = s; a.max_local = env_int("KPB_NMS_MAXLOCAL", 64);
+        a.sweep = s;
+        // with the sparse tail behind it, sweep 0 stops after three in-tile rounds (99.6 % of an ALIKE map is settled by
+        // then; measured: 3 rounds 2.26 + 1.49 ms, 5 rounds 2.75 + 1.39 ms, 2 rounds 1.87 + 2.52 ms per 512 images)
+        a.max_local = env_int("KPB_NMS_MAXLOCAL", (p.ulist && s == 0) ? 3 : 64);
         const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
         switch (r) {
         case 1: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<1>, grid, block, 0, ctx->stream, a); break;
