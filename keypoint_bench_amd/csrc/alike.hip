@@ -515,13 +515,14 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
         }
-        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
+        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  40 GB per launch
+        // that nothing re-reads before they have left every cache: streaming stores keep the L2 for a2 and the strips
         float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
-            d[(size_t)rowp * 64 + p] = acc0[r];
-            d[(size_t)rowp * 64 + 32 + p] = acc1[r];
+            __builtin_nontemporal_store(acc0[r], d + (size_t)rowp * 64 + p);
+            __builtin_nontemporal_store(acc1[r], d + (size_t)rowp * 64 + 32 + p);
         }
     }
 }
