@@ -24,9 +24,9 @@ class LazyDescriptors:
     """Stands where the dense descriptor map would be; only the matcher ever looks inside it
     (tasks pass desc_map through opaquely: MHA.py:38-39, AUC.py:119-120)."""
 
-    def __init__(self, net, shape, batch_index=0):
-        self._net, self.shape, self._b = net, torch.Size(shape), batch_index
-        self._stamp = net._forward_count
+    def __init__(self, net, shape, slot, batch_index=0):
+        self._net, self.shape, self._b, self._slot = net, torch.Size(shape), batch_index, slot
+        self._stamp = net._slot_stamp[slot]
 
     def detach(self):
         return self
@@ -38,14 +38,17 @@ class LazyDescriptors:
     def sample(self, pts: torch.Tensor) -> torch.Tensor:
         """Descriptors at pts [N, >=2] (x, y normalised): what grid_sample on the dense map returns."""
         net = self._net
-        if self._stamp != net._forward_count:
-            raise RuntimeError("LazyDescriptors used after a later forward of the same net; its features are gone "
-                               "(construct the net with dense_descriptors=True to keep maps alive)")
-        return net._desc_at(pts, self._b)
+        if self._stamp != net._slot_stamp[self._slot]:
+            raise RuntimeError("LazyDescriptors used after %d later forwards of the same net; its features are gone "
+                               "(construct the net with dense_descriptors=True to keep maps alive)" % net.KEEP)
+        return net._desc_at(pts, self._slot, self._b)
 
 
 class ALNet:
     """models/ALike.py:84-164."""
+
+    KEEP = 2    # dense_descriptors=False: the features of the last KEEP forwards stay alive (the reference's pattern is
+                # forward(img0), forward(img1), then the matcher: model_interface.py:205-212 -> tasks/MHA.py:38-39)
 
     def __init__(self, param=None, dense_descriptors=True):
         if param is None:
@@ -55,6 +58,8 @@ class ALNet:
             raise NotImplementedError("this build carries kernels for ALIKE-t (c1..c4 = 8,16,32,64, dim = 64) only")
         self.dense_descriptors = dense_descriptors
         self._handle = None
+        self._extra = []            # the other KEEP-1 native nets of the keypoint-only mode (own activations each)
+        self._slot_stamp = [0] * self.KEEP
         self._ctx = None
         self._device = None
         self._blob = None
@@ -95,15 +100,19 @@ class ALNet:
             raise RuntimeError("ALNet: load_state_dict() / load_packed() must be called before forward")
         self._release()
         self._ctx = Context.get(device)
-        h = c_void_p()
-        self._ctx.check(self._ctx.lib.kpb_net_create(self._ctx.handle, _weights.ARCH_ALIKE, self._blob, len(self._blob),
-                                                     ctypes.byref(h)))
-        self._handle, self._device = h, device
+        hs = []
+        for _ in range(1 if self.dense_descriptors else self.KEEP):
+            h = c_void_p()
+            self._ctx.check(self._ctx.lib.kpb_net_create(self._ctx.handle, _weights.ARCH_ALIKE, self._blob, len(self._blob),
+                                                         ctypes.byref(h)))
+            hs.append(h)
+        self._handle, self._extra, self._device = hs[0], hs[1:], device
 
     def _release(self):
         if self._handle is not None:
-            self._ctx.lib.kpb_net_destroy(self._handle)
-            self._handle = None
+            for h in [self._handle] + self._extra:
+                self._ctx.lib.kpb_net_destroy(h)
+            self._handle, self._extra = None, []
 
     def __del__(self):
         try:
@@ -123,15 +132,18 @@ class ALNet:
         desc = None
         if self.dense_descriptors:
             desc = torch.empty((B, H, W, self.param["dim"]), dtype=torch.float32, device=x.device)
-        self._ctx.check(self._ctx.lib.kpb_net_forward(self._handle, ptr(x), B, H, W, ptr(score), ptr(desc)))
+        slot = 0 if self.dense_descriptors else self._forward_count % self.KEEP
+        handle = ([self._handle] + self._extra)[slot]
+        self._ctx.check(self._ctx.lib.kpb_net_forward(handle, ptr(x), B, H, W, ptr(score), ptr(desc)))
         self._forward_count += 1
+        self._slot_stamp[slot] = self._forward_count
         if desc is not None:
             return score, desc.permute(0, 3, 1, 2)   # [B, dim, H, W] view, channels-last storage
-        return score, LazyDescriptors(self, (B, self.param["dim"], H, W))
+        return score, LazyDescriptors(self, (B, self.param["dim"], H, W), slot)
 
     __call__ = forward
 
-    def _desc_at(self, pts: torch.Tensor, batch_index: int = 0):
+    def _desc_at(self, pts: torch.Tensor, slot: int = 0, batch_index: int = 0):
         p = pts.detach().to(torch.float32).contiguous()
         n = p.shape[0]
         out = torch.empty((n, self.param["dim"]), dtype=torch.float32, device=p.device)
@@ -140,7 +152,7 @@ class ALNet:
         if batch_index != 0 or self._last_batch() != 1:
             raise NotImplementedError("LazyDescriptors.sample: batch_size 1 only (config/config_MHA.yaml:10); "
                                       "use keypoint_bench_amd.pipeline for batched pairs")
-        self._ctx.check(self._ctx.lib.kpb_net_desc_at(self._handle, ptr(p), p.shape[1], n, ptr(None), ptr(out)))
+        self._ctx.check(self._ctx.lib.kpb_net_desc_at(([self._handle] + self._extra)[slot], ptr(p), p.shape[1], n, ptr(None), ptr(out)))
         return out
 
     def _last_batch(self):

@@ -183,7 +183,7 @@ class PairRunner:
         if img0.dim() == 3:
             img0, img1 = img0[None], img1[None]
         s0, d0 = self.model(img0)     # model_interface.py:205-207
-        s1, d1 = self.model(img1) if False else self.model(img1)
+        s1, d1 = self.model(img1)
         r = self.task_fn(idx, img0, s0, d0, img1, s1, d1, batch.get("warp01_params", {}), batch.get("warp10_params", {}),
                          self.params)
         self.results.append(r)

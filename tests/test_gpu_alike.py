@@ -100,6 +100,29 @@ def test_lazy_descriptors_equal_dense_sampling():
     np.testing.assert_allclose(sample_descriptors(pts, d_l).cpu().numpy(), sample_descriptors(pts, d_d).cpu().numpy(), rtol=0, atol=2e-5)
 
 
+def test_lazy_descriptors_survive_the_reference_call_pattern():
+    """model(img0), model(img1), then the matcher (model_interface.py:205-212 -> tasks/MHA.py:38-39): both handles must
+    still be alive and give what the dense maps give; a third forward retires the oldest one, loudly."""
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.utils.extracter import detection
+    from keypoint_bench_amd.utils.matcher import brute_force_matcher
+    v0, v1 = synthetic.image_pair(6)
+    p = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
+    bf = dict(metric="euclidean", max_distance=5, cross_check=True)
+    i0, i1 = torch.from_numpy(v0)[None].to(DEV), torch.from_numpy(v1)[None].to(DEV)
+    dense, lazy = alike_t().eval(), alike_t(dense_descriptors=False).eval()
+    sd0, dd0 = dense(i0); sd1, dd1 = dense(i1)
+    sl0, dl0 = lazy(i0); sl1, dl1 = lazy(i1)
+    k0, k1 = detection(sd0, p), detection(sd1, p)
+    want0, want1 = brute_force_matcher(k0, k1, dd0, dd1, bf)
+    got0, got1 = brute_force_matcher(k0, k1, dl0, dl1, bf)
+    assert torch.equal(got0, want0) and torch.equal(got1, want1) and got0.shape[0] > 500
+    lazy(i0)
+    with pytest.raises(RuntimeError, match="later forwards"):
+        dl0.sample(k0)
+    dl1.sample(k1)      # the newer of the two is still alive
+
+
 def test_end_to_end_pair_against_reference_golden():
     """image pair -> ALIKE-t -> detection -> brute-force match, against what the reference produced.
     Keypoints are compared as sets because a score-map ulp can flip a near-tie (SURVEY 'Score-map ulps')."""
