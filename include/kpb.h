@@ -164,6 +164,13 @@ int kpb_lk_track(kpb_ctx* ctx, const float* img1_dev, const float* img2_dev, int
                  const float* pts1_dev, const float* pts2_dev, int pts_stride, const float* unit_dev,
                  int n, const kpb_lk_params* params, float* out_pts_dev, float* out_err_dev);
 
+/* ---- 8(f)2: per-image input transform after decoding, datasets/hpatches.py:47-69 --------------------
+ * src_dev [batch][Hs][Ws][3] uint8 as decoded (BGR from cv2.imread with swap_rb = 1, RGB with 0);
+ * out_dev [batch][3][Hd][Wd] fp32 = cv2.resize(src / 255, (Wd, Hd)) (INTER_LINEAR), channels first.
+ * Hd == Hs and Wd == Ws is transforms.ToTensor (datasets/megadepth.py:312-313). */
+int kpb_preprocess(kpb_ctx* ctx, const uint8_t* src_dev, int batch, int Hs, int Ws, int swap_rb,
+                   int Hd, int Wd, float* out_dev);
+
 /* ---- N1..: extractor networks (models/ALike.py:136-164 ALNet.forward, ...) ---------------------
  * arch: KPB_ARCH_*.  blob: a .kpbw container (keypoint_bench_amd/weights.py) holding the folded
  * tensors; copied, the caller may free it. */

@@ -83,3 +83,36 @@ def greedy_nms(score_hw, nms_dist):
         out[y, x] = flat[i]
         blocked[max(0, y - r):y + r + 1, max(0, x - r):x + r + 1] = True
     return out
+
+
+def preprocess(img_u8, size=None, bgr=False):
+    """datasets/hpatches.py:47-69 after decoding, on one uint8 [H, W, 3] image: BGR -> RGB (59-60), astype(float32) / 255
+    (59-60), cv2.resize(img, (w, h)) with the default INTER_LINEAR (66-67), HWC -> CHW (74-75).  PARITY UNPINNED: cv2 is
+    not installed here; the resize restates OpenCV's INTER_LINEAR arithmetic for float32 images (resize.cpp:
+    f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s, clamped; horizontal blend, then vertical blend)."""
+    a = np.asarray(img_u8)
+    assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3
+    if bgr:
+        a = a[:, :, ::-1]
+    f = a.astype(np.float32) / np.float32(255.0)
+    Hs, Ws = f.shape[:2]
+    Hd, Wd = (Hs, Ws) if size is None else ((size, size) if isinstance(size, int) else size)
+
+    def coords(n_dst, n_src):
+        d = np.arange(n_dst, dtype=np.float64)
+        fr = ((d + 0.5) * (float(n_src) / float(n_dst)) - 0.5).astype(np.float32)
+        s = np.floor(fr).astype(np.int64)
+        fr = fr - s.astype(np.float32)
+        lo = s < 0
+        s[lo] = 0; fr[lo] = 0
+        hi = s >= n_src - 1
+        s[hi] = n_src - 1; fr[hi] = 0
+        return s, np.minimum(s + 1, n_src - 1), fr.astype(np.float32)
+
+    sx, sx1, fx = coords(Wd, Ws)
+    sy, sy1, fy = coords(Hd, Hs)
+    a0, a1 = (np.float32(1) - fx)[None, :, None], fx[None, :, None]
+    rows = f[:, sx] * a0 + f[:, sx1] * a1                                   # horizontal pass, all source rows
+    b0, b1 = (np.float32(1) - fy)[:, None, None], fy[:, None, None]
+    out = rows[sy] * b0 + rows[sy1] * b1                                    # vertical pass
+    return np.ascontiguousarray(out.transpose(2, 0, 1).astype(np.float32))
