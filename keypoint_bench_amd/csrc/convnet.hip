@@ -58,6 +58,60 @@ __global__ __launch_bounds__(256) void conv_valu(ConvV a)
         if (cg * 8 + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
 }
 
+// The same layer with kernel size, input channels and stride known at compile time (XFeat's block1: 1->4, 4->8/2, 8->8,
+// 8->24/2, all 3x3): taps and channels unroll, a pixel's channels arrive as float4 loads, the weights of a tap are one
+// scalar burst.  Bounds are tested per tap (zero padding), as in conv_valu.
+template <int KS, int CIN, int S>
+__global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
+{
+    constexpr int PAD = KS / 2;
+    const int b = blockIdx.z, cg = blockIdx.y;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= a.H * a.W) return;
+    const int oy = pix / a.W, ox = pix - oy * a.W;
+    const float* in = a.in + (size_t)b * a.Hi * a.Wi * CIN;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = a.bias[cg * 8 + j];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        const int iy = oy * S + ky - PAD;
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int ix = ox * S + kx - PAD;
+            const bool inside = iy >= 0 && iy < a.Hi && ix >= 0 && ix < a.Wi;
+            const float* src = in + ((size_t)(inside ? iy : 0) * a.Wi + (inside ? ix : 0)) * CIN;
+            float v[CIN];
+            if (CIN % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < CIN / 4; ++q) {
+                    const float4 f = *reinterpret_cast<const float4*>(src + 4 * q);
+                    v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) v[c] = src[c];
+            }
+            const float* w = a.w + ((size_t)(ky * KS + kx) * CIN) * a.COUT8 + cg * 8;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float vc = inside ? v[c] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(vc, w[(size_t)c * a.COUT8 + j], acc[j]);
+            }
+        }
+    }
+    float* o = a.out + ((size_t)b * a.H * a.W + pix) * a.COUT + cg * 8;
+    if (a.COUT % 4 == 0 && cg * 8 + 8 <= a.COUT) {
+        *reinterpret_cast<float4*>(o) = a.relu ? make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3])) : make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(o + 4) = a.relu ? make_float4(relu(acc[4]), relu(acc[5]), relu(acc[6]), relu(acc[7])) : make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (cg * 8 + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
+    }
+}
+
 // SuperPoint conv1a (1 -> 64, 3x3, ReLU; SuperPoint.py:44): 16 lanes share a pixel, each lane keeps the 9 taps of its
 // 4 output channels in registers and walks down a column of pixels, so a wave store is 4 whole 256-byte pixels.
 __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block)
@@ -183,16 +237,22 @@ __global__ void skip_add(const float* gray, float* x1, const float* w, const flo
     const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (i >= H4 * W4) return;
     const int y = i / W4, x = i - y * W4;
-    const float* g = gray + (size_t)b * H * W + (size_t)(4 * y) * W + 4 * x;
+    const float* g = gray + (size_t)b * H * W + (size_t)(4 * y) * W + 4 * x;      // W is a multiple of 32: rows are 16-byte aligned
     float sacc = 0.0f;
 #pragma unroll
-    for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 4; ++dx) sacc += g[(size_t)dy * W + dx];
+    for (int dy = 0; dy < 4; ++dy) {
+        const float4 r = *reinterpret_cast<const float4*>(g + (size_t)dy * W);
+        sacc += r.x; sacc += r.y; sacc += r.z; sacc += r.w;                        // the order avg_pool2d's sum is restated in
+    }
     const float avg = sacc * (1.0f / 16.0f);
     float* o = x1 + ((size_t)b * H4 * W4 + i) * cstride;
 #pragma unroll
-    for (int c = 0; c < 24; ++c) o[c] += fmaf(avg, w[c], bias[c]);
+    for (int q = 0; q < 6; ++q) {
+        float4 v = *reinterpret_cast<float4*>(o + 4 * q);
+        v.x += fmaf(avg, w[4 * q], bias[4 * q]); v.y += fmaf(avg, w[4 * q + 1], bias[4 * q + 1]);
+        v.z += fmaf(avg, w[4 * q + 2], bias[4 * q + 2]); v.w += fmaf(avg, w[4 * q + 3], bias[4 * q + 3]);
+        *reinterpret_cast<float4*>(o + 4 * q) = v;
+    }
 }
 
 // XFeat.py:133-135: x3 + interpolate(x4, size(x3), bilinear) + interpolate(x5, ...) (align_corners=False), 64 channels
@@ -289,7 +349,14 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     a.Hi = Hi; a.Wi = Wi; a.KS = L.ks; a.S = L.stride; a.PAD = L.ks / 2;
     a.H = (Hi + 2 * a.PAD - L.ks) / L.stride + 1; a.W = (Wi + 2 * a.PAD - L.ks) / L.stride + 1;
     a.CIN = L.cin; a.COUT = L.cout; a.COUT8 = ((L.cout + 7) / 8) * 8; a.relu = relu_ ? 1 : 0;
-    KPB_LAUNCH(ctx, name, conv_valu, dim3(cdiv(a.H * a.W, 256), a.COUT8 / 8, B), dim3(256), 0, ctx->stream, a);
+    const dim3 grid(cdiv(a.H * a.W, 256), a.COUT8 / 8, B), block(256);
+    hipStream_t st = ctx->stream;
+    const bool t3 = L.ks == 3 && !xf;
+    if (t3 && L.cin == 1 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 1, 1>), grid, block, 0, st, a);
+    else if (t3 && L.cin == 4 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 4, 2>), grid, block, 0, st, a);
+    else if (t3 && L.cin == 8 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 1>), grid, block, 0, st, a);
+    else if (t3 && L.cin == 8 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2>), grid, block, 0, st, a);
+    else KPB_LAUNCH(ctx, name, conv_valu, grid, block, 0, st, a);
     return KPB_OK;
 }
 
