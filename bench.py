@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=None, help="pairs per GPU per step (default: 256 ALIKE and XFeat [SURVEY 8d], 16 SuperPoint, 4 DISK)")
+    ap.add_argument("--pairs-per-step", type=int, default=None, help="pairs per GPU per step (default: 256 ALIKE and XFeat [SURVEY 8d], 16 SuperPoint and DISK)")
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
@@ -177,7 +177,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B = args.pairs_per_step or {"alike": 256, "xfeat": 256, "superpoint": 16, "disk": 4}[args.model]
+    B = args.pairs_per_step or {"alike": 256, "xfeat": 256, "superpoint": 16, "disk": 16}[args.model]
     if args.model == "superpoint":
         from keypoint_bench_amd.models.SuperPoint import superpoint_random
         net = superpoint_random(7).eval()
