@@ -103,6 +103,20 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     return c
 
 
+def other_net_costs(B2):
+    """(FLOPs, bytes) per launch of the dominant XFeat / DISK convolutions (2*MAC on the reference's channel counts;
+    NHWC fp32 in + out)."""
+    P = H * W
+    c = {}
+    def conv(name, px, cin, cout, k):
+        c[name] = (2 * px * k * k * cin * cout * B2, px * (cin + cout) * 4 * B2)
+    conv("xf_block1.3", P // 16, 8, 24, 3)
+    conv("xf_block2.0", P // 16, 24, 24, 3); conv("xf_block2.1", P // 16, 24, 24, 3)
+    conv("xf_block3.1", P // 64, 64, 64, 3); conv("xf_block_fusion.0", P // 64, 64, 64, 3); conv("xf_block_fusion.1", P // 64, 64, 64, 3)
+    conv("disk_up3", P, 80, 129, 5); conv("disk_up2", P // 4, 96, 64, 5); conv("disk_up1", P // 16, 128, 64, 5)
+    return c
+
+
 def pmc_traffic(kernel, pairs, dense):
     """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/prof_pmc.sh: FETCH_SIZE and WRITE_SIZE
     in separate rocprofv3 --pmc runs of this same command; FETCH_SIZE doubled per the gfx950 correction).  Counters
@@ -245,6 +259,7 @@ def main():
         sweeps = prof.get("nms_sweep", (1, 0))[0] / prof_steps
         costs = kernel_costs(2 * B, B, EXTRACTOR["top_k"], net.dim, not args.sparse, sweeps)
         costs.update(superpoint_costs(2 * B))
+        costs.update(other_net_costs(2 * B))
         name = max(prof, key=lambda k: prof[k][1])
         calls, total_ms = prof[name]
         avg_ms = total_ms / calls
