@@ -246,6 +246,28 @@ def main():
         allrows = rows
     allrows = allrows.cpu().numpy()
 
+    # the same pairs with keypoint-only descriptors (ALNet(dense_descriptors=False): same keypoints and matches, the
+    # 78.6 MB/image descriptor map is never written; SURVEY 8d asks to say which was run): timed like the main loop
+    variant = None
+    if args.model == "alike" and not args.sparse and args.matcher == "brute_force":
+        pipe2 = PairPipeline(alike_t(dense_descriptors=False).eval(), EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
+        for _ in range(args.warmup):
+            pipe2.run(images)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe2.run(images)
+        barrier()
+        e2 = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([e2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        same = bool(torch.equal(pipe2.k, pipe.k) and torch.equal(pipe2.pairs[:, :16], pipe.pairs[:, :16]))
+        variant = {"descriptors": "keypoint-only", "value": round(world * B * args.steps / e2, 2), "unit": "pairs/s",
+                   "ms_per_step": round(1e3 * e2 / args.steps, 3), "same_matches_as_dense": same}
+        del pipe2
+
     # roofline leg: per-kernel durations from HIP events on the launch stream, same workload
     roof = None
     ctx = pipe.ctx
@@ -291,7 +313,7 @@ def main():
                        "nms_reruns": pipe.reruns},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
                         "pairs_gathered": int(allrows.shape[0])},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "variant": variant,
         }
         print(json.dumps(out))
     if use_dist:
