@@ -27,6 +27,7 @@ constexpr int B1_TH = 32, B1_TW = 32;
 struct Block1Args {
     const float* img;   // [B][3][H][W]
     float* x1;          // [B][H][W][8]
+    float* p1;          // [B][H/2][W/2][8] = max_pool2d(x1, 2, 2) (ALike.py:139), what block 2 reads
     const float* w1;    // [27][8]  (cin, ky, kx) major, cout minor
     const float* b1;    // [8]
     const float* w2;    // [9][8][8] (tap, cin, cout)
@@ -149,6 +150,23 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
         if (gy < a.H && gx < a.W)
             *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + tx0) * 8 + rx4 * 4) =
                 *reinterpret_cast<const float4*>(stage + i * 4);
+    }
+    // the 2x2 max-pool block 2 starts with, from the tile still in LDS: 16x16 pooled pixels x 2 float4
+    {
+        const int H2 = a.H / 2, W2 = a.W / 2;
+#pragma unroll
+        for (int k = 0; k < (B1_TH / 2) * (B1_TW / 2) * 2 / 256; ++k) {
+            const int i = tid + k * 256;
+            const int q = i & 1, px = (i >> 1) & (B1_TW / 2 - 1), py = i >> 5;
+            const float* s0 = stage + ((2 * py) * B1_TW + 2 * px) * 8 + 4 * q;
+            const float4 v00 = *reinterpret_cast<const float4*>(s0), v01 = *reinterpret_cast<const float4*>(s0 + 8);
+            const float4 v10 = *reinterpret_cast<const float4*>(s0 + B1_TW * 8), v11 = *reinterpret_cast<const float4*>(s0 + B1_TW * 8 + 8);
+            const int gy = ty0 / 2 + py, gx = tx0 / 2 + px;
+            if (gy < H2 && gx < W2)
+                *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + gy) * W2 + gx) * 8 + 4 * q) =
+                    make_float4(fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)), fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y)),
+                                fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)), fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w)));
+        }
     }
 }
 
@@ -646,7 +664,7 @@ __global__ __launch_bounds__(256) void alike_desc_at(DescAtArgs a)
 namespace {
 
 struct AlikeNet : kpb_net {
-    float *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
+    float *p1 = nullptr, *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
           *t4 = nullptr, *x4 = nullptr, *a4 = nullptr, *S2 = nullptr, *S3 = nullptr, *S4 = nullptr, *E3 = nullptr, *E4 = nullptr;
     HeadArgs head_args(float* score, float* desc)
     {
@@ -693,10 +711,12 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
                  n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
     const size_t n_s = B * (P / 4 + P / 64 + P / 1024) + 64;
     const size_t n_e = desc_out_dev ? B * (P / 64 + P / 1024) * ESTRIDE : 0;
-    const size_t total = n_x1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4 + n_s + n_e;
+    const size_t n_p1 = B * (P / 4) * 8;
+    const size_t total = n_x1 + n_p1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4 + n_s + n_e;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
+    p1 = p; p += n_p1;
     t2 = p; p += n_2; x2 = p; p += n_2; a2 = p; p += n_2;
     t3 = p; p += n_3; x3 = p; p += n_3; a3 = p; p += n_a3;
     t4 = p; p += n_4; x4 = p; p += n_4; a4 = p; p += n_a4;
@@ -708,15 +728,15 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     this->B = batch; this->H = H; this->W = W;
     hipStream_t st = ctx->stream;
 
-    Block1Args b1{img_dev, x1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
+    Block1Args b1{img_dev, x1, p1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
     KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
 
     ConvArgs c;
     // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
-    c = ConvArgs{x1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};
-    launch_conv<8, 16, 2, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
-    c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), x1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
-    launch_conv<16, 16, 1, true, 8, 2>(ctx, "conv3x3_b2c2", st, c, batch);
+    c = ConvArgs{p1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};      // pooled by block1
+    launch_conv<8, 16, 1, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
+    c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), p1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
+    launch_conv<16, 16, 1, true, 8, 1>(ctx, "conv3x3_b2c2", st, c, batch);
     // block3 @ H/8 (141-142): pool4
     c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
     launch_conv<16, 32, 4, false, 4, 1, true>(ctx, "conv3x3_b3c1", st, c, batch);
