@@ -48,6 +48,27 @@ def test_forward_full_size_against_reference_golden_and_oracle():
     np.testing.assert_allclose(desc[0].cpu().numpy(), do[0].numpy(), rtol=0, atol=ATOL_DESC)
 
 
+@pytest.mark.parametrize("shape", [(512, 512), (480, 608), (96, 32), (32, 160), (224, 736)])
+@pytest.mark.parametrize("dense", [True, False])
+def test_forward_other_shapes_against_oracle(shape, dense):
+    """HPatches runs at 512 x 512 (config_MHA.yaml:16); widths that are not multiples of 128 end a row with a short head
+    segment; 32-pixel extents are the smallest the net accepts (one pixel at 1/32 resolution)."""
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.utils.matcher import sample_descriptors
+    H, W = shape
+    img = synthetic.image_pair(7, max(H, 64), max(W, 64))[0][:, :H, :W].copy()
+    score, desc = alike_t(dense_descriptors=dense).eval()(torch.from_numpy(img)[None].to(DEV))
+    so, do = _oracle_forward(img)
+    np.testing.assert_allclose(score[0, 0].cpu().numpy(), so[0, 0].numpy(), rtol=0, atol=ATOL_SCORE)
+    if dense:
+        np.testing.assert_allclose(desc[0].cpu().numpy(), do[0].numpy(), rtol=0, atol=ATOL_DESC)
+    else:
+        rng = np.random.default_rng(H + W)
+        pts = torch.from_numpy(rng.random((200, 2)).astype(np.float32)).to(DEV)
+        want = sample_descriptors(pts, do.to(DEV)).cpu().numpy()
+        np.testing.assert_allclose(sample_descriptors(pts, desc).cpu().numpy(), want, rtol=0, atol=ATOL_DESC)
+
+
 def test_state_dict_loading_equals_packed_blob():
     """load_state_dict on an ALNet-shaped state dict (BN un-folded) gives the same network as the blob."""
     from keypoint_bench_amd.models.ALike import ALNet, alike_t
