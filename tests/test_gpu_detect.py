@@ -149,3 +149,16 @@ def test_nms_schedules_agree(mode, monkeypatch):
     for b in range(2):
         exp, _ = oracle.fast_nms(m[b, 0], 6)
         np.testing.assert_array_equal(got[b, 0], exp)
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 5, 7, 8])
+def test_nms_tail_every_radius(r, monkeypatch):
+    """The sparse tail is specialised per radius (r = 8 needs a 17th window column): force it on small batches and check
+    every radius against the oracle's literal rounds."""
+    from keypoint_bench_amd.utils.extracter import fast_nms
+    m = np.stack([synthetic.score_smooth(30 + r, 240, 320), synthetic.score_uniform(40 + r, 240, 320)])[:, None]
+    monkeypatch.setenv("KPB_NMS_TILED", "0")
+    got = fast_nms(torch.from_numpy(m).to(_dev()), r).cpu().numpy()
+    for b in range(2):
+        exp, _ = oracle.fast_nms(m[b, 0], r)
+        np.testing.assert_array_equal(got[b, 0], exp)
