@@ -189,7 +189,19 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a banner (host name, library path) on stdout when its communicator comes up; stdout must carry the
+        # one JSON line only, so the file descriptor points at stderr until the first collective has run
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     B = args.pairs_per_step or {"alike": 256, "xfeat": 256, "superpoint": 16, "disk": 16}[args.model]
     if args.model == "superpoint":
