@@ -306,11 +306,11 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out,
                                                     float* smap, size_t npix, const float* wproj /*[16][64]*/, float* E /*[npix][ESTRIDE]*/)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix) return;
+    const bool live = p < npix;        // (dead lanes of the last workgroup still help to copy the projected rows out)
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
-    const float* x = in + p * CIN;
+    const float* x = in + (live ? p : 0) * CIN;
 #pragma unroll 2
     for (int c4 = 0; c4 < CIN / 4; ++c4) {
         const float4 v4 = *reinterpret_cast<const float4*>(x + c4 * 4);
@@ -320,26 +320,47 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out,
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc[j] = fmaf(v[c], w[(c4 * 4 + c) * 16 + j], acc[j]);
     }
-    float* o = out + p * 16;
     float sg = 0.0f;     // this group's share of the score logit: the 1x1 head commutes with the bilinear upsampling
 #pragma unroll
     for (int j = 0; j < 16; ++j) { acc[j] = relu(acc[j]); sg = fmaf(acc[j], wsg[j], sg); }
+    if (live) {
+        float* o = out + p * 16;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
-    smap[p] = sg;
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        smap[p] = sg;
+    }
     if (E) {
-        float* e = E + p * ESTRIDE;
+        // 68 floats per pixel, 272 bytes apart: written per thread they would be 17 scattered 16-byte pieces per lane.
+        // Instead each wave passes its pixels through LDS 16 at a time and writes the 16 x 272 contiguous bytes with
+        // consecutive lanes on consecutive float4s (a wave's LDS operations execute in order: no barrier)
+        __shared__ __attribute__((aligned(16))) float stage[4][16 * ESTRIDE];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float* st = stage[wv];
+        const size_t p0 = (size_t)blockIdx.x * 256 + wv * 64;          // first pixel of this wave
+        float4 r[17];
+#pragma unroll
         for (int q = 0; q < 16; ++q) {
-            float4 r = {0.f, 0.f, 0.f, 0.f};
+            r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const float* wr = wproj + c * 64 + 4 * q;
-                r.x = fmaf(acc[c], wr[0], r.x); r.y = fmaf(acc[c], wr[1], r.y); r.z = fmaf(acc[c], wr[2], r.z); r.w = fmaf(acc[c], wr[3], r.w);
+                r[q].x = fmaf(acc[c], wr[0], r[q].x); r[q].y = fmaf(acc[c], wr[1], r[q].y);
+                r[q].z = fmaf(acc[c], wr[2], r[q].z); r[q].w = fmaf(acc[c], wr[3], r[q].w);
             }
-            *reinterpret_cast<float4*>(e + 4 * q) = r;
         }
-        *reinterpret_cast<float4*>(e + 64) = make_float4(sg, 0.f, 0.f, 0.f);
+        r[16] = make_float4(sg, 0.f, 0.f, 0.f);
+        for (int g = 0; g < 4; ++g) {
+            if ((lane >> 4) == g) {
+                float* e = st + (lane & 15) * ESTRIDE;
+#pragma unroll
+                for (int q = 0; q < 17; ++q) *reinterpret_cast<float4*>(e + 4 * q) = r[q];
+            }
+            const size_t base = p0 + 16 * g;                            // 16 pixels = 16 * 17 float4, contiguous in E
+            for (int j = lane; j < 16 * (ESTRIDE / 4); j += 64)
+                if (base + j / (ESTRIDE / 4) < npix)
+                    *reinterpret_cast<float4*>(E + base * ESTRIDE + 4 * j) = *reinterpret_cast<const float4*>(st + 4 * j);
+        }
     }
 }
 
