@@ -329,7 +329,8 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     const dim3 grid(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk), block(256);
     hipStream_t st = ctx->stream;
     const bool x = xf != nullptr;
-    if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, false, false>), grid, block, 0, st, a);
+    if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, false, false, 1>), grid, block, 0, st, a);
+    else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, false, false>), grid, block, 0, st, a);
     else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, true, false>), grid, block, 0, st, a);
     else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, true, false, false>), grid, block, 0, st, a);
     else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<1, 1, 32, false, false, false>), grid, block, 0, st, a);
@@ -561,6 +562,7 @@ int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         w = wpad.data(); b = bpad.data();
         Layer L{q.name, cin, cout, q.ks, q.stride, (cin % 32 == 0)};
         L.cc = q.stride == 2 ? 16 : 32;
+        if (cout <= 32 && q.ks == 3 && q.stride == 1) L.ntb = 1;      // block2: one 32-wide output tile, not a half-empty pair
         stage_layer(ws, L, w, b);
         net->L[L.name] = L;
         net->relu_of[L.name] = q.relu;
