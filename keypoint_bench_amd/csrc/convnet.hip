@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_valu(ConvV a)
 // The same layer with kernel size, input channels and stride known at compile time (XFeat's block1: 1->4, 4->8/2, 8->8,
 // 8->24/2, all 3x3): taps and channels unroll, a pixel's channels arrive as float4 loads, the weights of a tap are one
 // scalar burst.  Bounds are tested per tap (zero padding), as in conv_valu.
-template <int KS, int CIN, int S>
+template <int KS, int CIN, int S, int CPT = 8>      // CPT output channels per thread: the taps are read once per CPT
 __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
 {
     constexpr int PAD = KS / 2;
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
     if (pix >= a.H * a.W) return;
     const int oy = pix / a.W, ox = pix - oy * a.W;
     const float* in = a.in + (size_t)b * a.Hi * a.Wi * CIN;
-    float acc[8];
+    float acc[CPT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = a.bias[cg * 8 + j];
+    for (int j = 0; j < CPT; ++j) acc[j] = a.bias[cg * CPT + j];
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
         const int iy = oy * S + ky - PAD;
@@ -92,23 +92,25 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
 #pragma unroll
                 for (int c = 0; c < CIN; ++c) v[c] = src[c];
             }
-            const float* w = a.w + ((size_t)(ky * KS + kx) * CIN) * a.COUT8 + cg * 8;
+            const float* w = a.w + ((size_t)(ky * KS + kx) * CIN) * a.COUT8 + cg * CPT;
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
                 const float vc = inside ? v[c] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] = fmaf(vc, w[(size_t)c * a.COUT8 + j], acc[j]);
+                for (int j = 0; j < CPT; ++j) acc[j] = fmaf(vc, w[(size_t)c * a.COUT8 + j], acc[j]);
             }
         }
     }
-    float* o = a.out + ((size_t)b * a.H * a.W + pix) * a.COUT + cg * 8;
-    if (a.COUT % 4 == 0 && cg * 8 + 8 <= a.COUT) {
-        *reinterpret_cast<float4*>(o) = a.relu ? make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3])) : make_float4(acc[0], acc[1], acc[2], acc[3]);
-        *reinterpret_cast<float4*>(o + 4) = a.relu ? make_float4(relu(acc[4]), relu(acc[5]), relu(acc[6]), relu(acc[7])) : make_float4(acc[4], acc[5], acc[6], acc[7]);
+    float* o = a.out + ((size_t)b * a.H * a.W + pix) * a.COUT + cg * CPT;
+    if (a.COUT % 4 == 0 && cg * CPT + CPT <= a.COUT) {
+#pragma unroll
+        for (int q = 0; q < CPT / 4; ++q)
+            *reinterpret_cast<float4*>(o + 4 * q) = a.relu ? make_float4(relu(acc[4 * q]), relu(acc[4 * q + 1]), relu(acc[4 * q + 2]), relu(acc[4 * q + 3]))
+                                                           : make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (cg * 8 + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
+        for (int j = 0; j < CPT; ++j)
+            if (cg * CPT + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
     }
 }
 
@@ -356,6 +358,8 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     if (t3 && L.cin == 1 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 1, 1>), grid, block, 0, st, a);
     else if (t3 && L.cin == 4 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 4, 2>), grid, block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 1>), grid, block, 0, st, a);
+    else if (t3 && L.cin == 8 && L.stride == 2 && a.COUT8 == 32)
+        KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2, 32>), dim3(grid.x, 1, grid.z), block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2>), grid, block, 0, st, a);
     else KPB_LAUNCH(ctx, name, conv_valu, grid, block, 0, st, a);
     return KPB_OK;
