@@ -134,6 +134,16 @@ int kpb_warp_homography(kpb_ctx* ctx, const float* kps_dev, int batch, int max_n
                         float* out_kps0_dev, float* out_kps01_dev, int32_t* out_ids_dev,
                         int32_t* out_n_dev);
 
+/* ---- depth-based covisibility warp, utils/projection.py:195-268 warp_se3 (with interpolate_depth 271-373) ------
+ * One image pair per call.  kps_dev [n][stride] normalised; depth0_dev [H0][W0], depth1_dev [H1][W1] fp32 (0 = no
+ * depth); cam_dev [38] = inverse(intrinsics0)[9], intrinsics1[9], pose01[16], bbox0 (row, col), bbox1 (row, col).
+ * out_kps0_dev / out_kps01_dev [n][2]: covisible points and their warps (normalised by the depth-map sizes);
+ * out_ids_dev [n]: their row numbers; out_ids_out_dev [n]: points that leave image 1, then occluded points (each
+ * ascending); out_counts_dev [2] = (covisible, left-or-occluded). */
+int kpb_warp_se3(kpb_ctx* ctx, const float* kps_dev, int n, int stride, const float* depth0_dev, int H0, int W0,
+                 const float* depth1_dev, int H1, int W1, const float* cam_dev, float* out_kps0_dev,
+                 float* out_kps01_dev, int32_t* out_ids_dev, int32_t* out_ids_out_dev, int32_t* out_counts_dev);
+
 /* ---- 8(f)1: ground-truth mutual nearest neighbours, tasks/repeatability.py:69-85 (val_key_points;
  * mutual_argmax 9-32, compute_keypoints_distance 39-51) -------------------------------------------
  * k0_dev, k01_dev [batch][max_m][2]: covisible keypoints of image 0 and their warps; k1_dev, k10_dev

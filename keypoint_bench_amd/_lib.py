@@ -50,6 +50,8 @@ SIGNATURES = {
                                 c_void_p]),
     "kpb_warp_homography": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p]),
+    "kpb_warp_se3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "kpb_val_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "kpb_lk_track": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,

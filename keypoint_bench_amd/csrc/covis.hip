@@ -96,6 +96,116 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_homography(WarpArgs a)
     if (threadIdx.x == 0) a.n_valid[b] = nv;
 }
 
+// ------------------------------------------------------------------------------------------------ warp_se3
+// utils/projection.py:195-268 with interpolate_depth (271-373), unproject (30-53) and project (56-75): lift a keypoint of
+// image 0 through its interpolated depth, move it with pose01, project it into image 1 and accept it if the depth map
+// there agrees to 5 cm.  The three einsums are evaluated as torch's BLAS does for the point counts that matter (a
+// fused-multiply-add chain; below 400 multiply-adds torch runs an unfused loop: <= 1 ulp apart).
+struct Se3Args {
+    const float* kps; int n, stride;
+    const float* depth0; int H0, W0; const float* depth1; int H1, W1;
+    const float* cam;       // kinv0[9], k1[9], pose[16], bbox0[2], bbox1[2]
+    float* k0v; float* k01v; int32_t* ids_valid; int32_t* ids_out; int32_t* counts;
+};
+
+// 0: corner outside the bordered image, 1: a corner without depth, 2: interpolated (z valid)
+__device__ __forceinline__ int se3_interp(const float* __restrict__ depth, int h, int w, float x, float y, float& z)
+{
+    constexpr int border = 10;
+    const float i = y, j = x;
+    const long it = (long)floorf(i), jt = (long)floorf(j), ib = (long)ceilf(i), jr = (long)ceilf(j);
+    if (!(it >= border && jt >= border && jr < w - border && ib < h - border)) return 0;
+    const float dtl = depth[it * w + jt], dtr = depth[it * w + jr], dbl = depth[ib * w + jt], dbr = depth[ib * w + jr];
+    if (!(dtl > 0.f && dtr > 0.f && dbl > 0.f && dbr > 0.f)) return 1;
+    const float di = i - (float)it, dj = j - (float)jt;
+    const float wtl = (1.f - di) * (1.f - dj), wtr = (1.f - di) * dj, wbl = di * (1.f - dj), wbr = di * dj;
+    z = ((wtl * dtl + wtr * dtr) + wbl * dbl) + wbr * dbr;
+    return 2;
+}
+
+__device__ __forceinline__ float dot3f(const float* a, float b0, float b1, float b2) { return fmaf(a[2], b2, fmaf(a[1], b1, a[0] * b0)); }
+
+// class of point i: 0 dropped (no depth in image 0, or corners but no depth in image 1), 1 outside image 1, 2 occluded,
+// 3 covisible; x, y = position in image 0, u, v = position in image 1 (pixels)
+__device__ __forceinline__ int se3_point(const Se3Args& a, int i, float& x, float& y, float& u01, float& v01)
+{
+    const float* kinv0 = a.cam; const float* k1 = a.cam + 9; const float* pose = a.cam + 18;
+    const float* bbox0 = a.cam + 34; const float* bbox1 = a.cam + 36;
+    x = a.kps[(size_t)i * a.stride] * (float)a.W0; y = a.kps[(size_t)i * a.stride + 1] * (float)a.H0;      // 204
+    float z0;
+    if (se3_interp(a.depth0, a.H0, a.W0, x, y, z0) != 2) return 0;                                          // 211
+    const float bu = (x + bbox0[1]) + 0.5f, bv = (y + bbox0[0]) + 0.5f;                                     // 214
+    const float d0 = bu * z0, d1 = bv * z0;                                                                 // 42
+    float p[3], q[3], zuv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) p[r] = dot3f(kinv0 + 3 * r, d0, d1, z0);                                    // 46
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { const float* t = pose + 4 * r; q[r] = fmaf(t[2], p[2], fmaf(t[1], p[1], t[0] * p[0])) + t[3]; }   // 221
+#pragma unroll
+    for (int r = 0; r < 3; ++r) zuv[r] = dot3f(k1 + 3 * r, q[0], q[1], q[2]);                               // 68
+    const float u = zuv[0] / zuv[2], v = zuv[1] / zuv[2], z01 = zuv[2];                                     // 73-75
+    u01 = (u - bbox1[1]) - 0.5f; v01 = (v - bbox1[0]) - 0.5f;                                               // 227
+    float z1;
+    const int c = se3_interp(a.depth1, a.H1, a.W1, u01, v01, z1);                                           // 234
+    if (c == 0) return 1;                                                                                   // 236-239
+    if (c == 1) return 0;
+    return fabsf(z01 - z1) < 0.05f ? 3 : 2;                                                                 // 246-249
+}
+
+// one workgroup: count the three lists, then emit them in ascending point order (ids_out = outside, then occluded: 262)
+__global__ __launch_bounds__(WARP_THREADS) void warp_se3(Se3Args a)
+{
+    __shared__ int tot[4], base[4], wave_cnt[3][WARP_THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 4) { tot[threadIdx.x] = 0; base[threadIdx.x] = 0; }
+    __syncthreads();
+    int mine[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < a.n; i += WARP_THREADS) {
+        float x, y, u, v;
+        mine[se3_point(a, i, x, y, u, v)]++;
+    }
+#pragma unroll
+    for (int c = 1; c < 4; ++c) {
+        int m = mine[c];
+        for (int o = 32; o; o >>= 1) m += __shfl_down(m, o);
+        if (lane == 0 && m) atomicAdd(&tot[c], m);
+    }
+    __syncthreads();
+    const int n_outside = tot[1];
+    for (int i0 = 0; i0 < a.n; i0 += WARP_THREADS) {
+        const int i = i0 + threadIdx.x;
+        float x = 0, y = 0, u = 0, v = 0;
+        const int cls = i < a.n ? se3_point(a, i, x, y, u, v) : 0;
+        int before[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int c = 1; c < 4; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            before[c] = __popcll(m & ((1ull << lane) - 1));
+            if (lane == 0) wave_cnt[c - 1][wave] = __popcll(m);
+        }
+        __syncthreads();
+        if (cls) {
+            int p = base[cls] + before[cls];
+            for (int w = 0; w < wave; ++w) p += wave_cnt[cls - 1][w];
+            if (cls == 3) {
+                a.k0v[2 * p] = x / (float)a.W0; a.k0v[2 * p + 1] = y / (float)a.H0;                         // 266
+                a.k01v[2 * p] = u / (float)a.W1; a.k01v[2 * p + 1] = v / (float)a.H1;                       // 267
+                a.ids_valid[p] = i;
+            } else {
+                a.ids_out[(cls == 2 ? n_outside : 0) + p] = i;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            int c = 0;
+            for (int w = 0; w < WARP_THREADS / 64; ++w) c += wave_cnt[threadIdx.x][w];
+            base[threadIdx.x + 1] += c;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { a.counts[0] = tot[3]; a.counts[1] = tot[1] + tot[2]; }
+}
+
 // ------------------------------------------------------------------------------------------------ val_key_points
 struct ValArgs {
     const float* k0; const float* k01; const float* k1; const float* k10;
@@ -283,6 +393,22 @@ extern "C" __attribute__((visibility("default"))) int kpb_val_keypoints(
     KPB_LAUNCH(ctx, "covis_count", covis_mutual<false>, dim3(cdiv(max_m, 4), batch), dim3(256), 0, ctx->stream, a);
     KPB_LAUNCH(ctx, "covis_scan", covis_scan, dim3(batch), dim3(1024), 0, ctx->stream, a);
     KPB_LAUNCH(ctx, "covis_emit", covis_mutual<true>, dim3(cdiv(max_m, 4), batch), dim3(256), 0, ctx->stream, a);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_warp_se3(
+    kpb_ctx* ctx, const float* kps_dev, int n, int stride, const float* depth0_dev, int H0, int W0, const float* depth1_dev, int H1, int W1,
+    const float* cam_dev, float* out_kps0_dev, float* out_kps01_dev, int32_t* out_ids_dev, int32_t* out_ids_out_dev, int32_t* out_counts_dev)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_warp_se3: null context");
+    if (n < 0 || stride < 2 || !depth0_dev || !depth1_dev || !cam_dev || !out_counts_dev || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_warp_se3: bad argument");
+    if (n && (!kps_dev || !out_kps0_dev || !out_kps01_dev || !out_ids_dev || !out_ids_out_dev))
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_warp_se3: null buffer");
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    Se3Args a{kps_dev, n, stride, depth0_dev, H0, W0, depth1_dev, H1, W1, cam_dev, out_kps0_dev, out_kps01_dev, out_ids_dev, out_ids_out_dev, out_counts_dev};
+    KPB_LAUNCH(ctx, "warp_se3", warp_se3, dim3(1), dim3(WARP_THREADS), 0, ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }

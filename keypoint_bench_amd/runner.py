@@ -227,21 +227,17 @@ def install():
         for k, v in names.items():
             setattr(mod, k, v)
             swapped.append(modname + "." + k)
-    # the homography warp and the repeatability core.  `warp` keeps dispatching on params['mode'] inside
-    # the reference (its depth-based 'se3' branch is not built here and stays the reference's own).
+    # the two covisibility warps and the repeatability core (`warp` keeps dispatching on params['mode'])
     from .tasks import repeatability as rp
     from .utils import projection as pj
     try:
         mod = importlib.import_module("utils.projection")
         mod.warp_homography = pj.warp_homography
-        swapped.append("utils.projection.warp_homography")
+        mod.warp_se3 = pj.warp_se3
+        swapped += ["utils.projection.warp_homography", "utils.projection.warp_se3"]
         mod = importlib.import_module("tasks.repeatability")
-        theirs = mod.val_key_points
 
-        def val_key_points(kps0, kps1, warp01, warp10, th=3):
-            both_homo = warp01["mode"] == "homo" and warp10["mode"] == "homo"
-            return (rp.val_key_points if both_homo else theirs)(kps0, kps1, warp01, warp10, th)
-        mod.val_key_points = val_key_points
+        mod.val_key_points = rp.val_key_points
         swapped.append("tasks.repeatability.val_key_points")
     except Exception:
         pass

@@ -37,16 +37,20 @@ def gt_mutual(k0, k01, k1, k10, scale01, scale10, th=3.0, m_dev=None, n_dev=None
 
 
 def val_key_points(kps0, kps1, warp01, warp10, th: int = 3):
-    """tasks/repeatability.py:54-92 (homography warps)."""
+    """tasks/repeatability.py:54-92 (homography and se3 warps)."""
     num_feat = min(kps0.shape[0], kps1.shape[0])
-    if warp01["mode"] != "homo" or warp10["mode"] != "homo":
-        warp(kps0, warp01)              # raises for the modes that are not built
-    a, b, _, na = warp_homography_device(kps0[:, 0:2], warp01)
-    a1, b1, _, nb = warp_homography_device(kps1[:, 0:2], warp10)
-    M, N = int(na.item()), int(nb.item())
+    if warp01["mode"] == "homo" and warp10["mode"] == "homo":       # counts stay on the device until both warps are queued
+        a, b, _, na = warp_homography_device(kps0[:, 0:2], warp01)
+        a1, b1, _, nb = warp_homography_device(kps1[:, 0:2], warp10)
+        M, N = int(na.item()), int(nb.item())
+        a, b, a1, b1 = a[:M], b[:M], a1[:N], b1[:N]
+    else:
+        a, b, _, _ = warp(kps0, warp01)
+        a1, b1, _, _ = warp(kps1, warp10)
+        M, N = a.shape[0], a1.shape[0]
     if M == 0 or N == 0:
         return {"num_feat": 0, "repeatability": 0, "mean_error": 0, "errors": None}
-    pairs, dist, errors, gt = gt_mutual(a[:M], b[:M], a1[:N], b1[:N], _scale(warp01), _scale(warp10), th)
+    pairs, dist, errors, gt = gt_mutual(a, b, a1, b1, _scale(warp01), _scale(warp10), th)
     error = dist[dist <= th].cpu().numpy()                                   # 83
     return {
         "num_feat": num_feat,

@@ -39,11 +39,35 @@ def warp_homography(kpts0: torch.Tensor, params: dict):
     return a[:k], b[:k], ids[:k], ids[k:]
 
 
+def warp_se3(kpts0: torch.Tensor, params: dict):
+    """utils/projection.py:195-268.  params: pose01 [4,4], bbox0 / bbox1 (row, col), depth0 / depth1 [H,W], intrinsics0 /
+    intrinsics1 [3,3].  Returns (kpts0_valid, kpts01_valid, ids_valid, ids_out) as the reference does."""
+    if not kpts0.is_cuda:
+        raise RuntimeError("keypoint_bench_amd needs CUDA/HIP tensors; there is no CPU path")
+    dev = kpts0.device
+    f = lambda v: torch.as_tensor(v).detach().to(torch.float32)
+    # inverse(intrinsics0) is nine numbers: taken on the host with the routine unproject (projection.py:43) uses
+    cam = torch.cat([torch.inverse(f(params["intrinsics0"]).cpu()).reshape(9), f(params["intrinsics1"]).cpu().reshape(9),
+                     f(params["pose01"]).cpu().reshape(16), f(params["bbox0"]).cpu().reshape(2), f(params["bbox1"]).cpu().reshape(2)]).to(dev)
+    d0, d1 = f(params["depth0"]).to(dev).contiguous(), f(params["depth1"]).to(dev).contiguous()
+    p = kpts0.detach().to(torch.float32).contiguous()
+    n = p.shape[0]
+    a = torch.empty((n, 2), dtype=torch.float32, device=dev); b = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    ids = torch.empty((n,), dtype=torch.int32, device=dev); out = torch.empty((n,), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((2,), dtype=torch.int32, device=dev)
+    if n:
+        ctx = Context.get(dev)
+        ctx.check(ctx.lib.kpb_warp_se3(ctx.handle, ptr(p), n, p.shape[1], ptr(d0), d0.shape[0], d0.shape[1], ptr(d1), d1.shape[0], d1.shape[1],
+                                       ptr(cam), ptr(a), ptr(b), ptr(ids), ptr(out), ptr(cnt)))
+    k, m = (int(v) for v in cnt.tolist())
+    return a[:k], b[:k], ids[:k].to(torch.int64), out[:m].to(torch.int64)
+
+
 def warp(kpts0: torch.Tensor, params: dict):
     """utils/projection.py:186-193."""
     mode = params["mode"]
     if mode == "homo":
         return warp_homography(kpts0[:, 0:2], params)
     if mode == "se3":
-        raise NotImplementedError("mode 'se3' (depth warp, projection.py:195-268) is not built; SURVEY 8(f) lists the homography path")
+        return warp_se3(kpts0[:, 0:2], params)
     raise ValueError("unknown mode!")

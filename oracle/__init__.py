@@ -56,6 +56,9 @@ def lib():
         L.kpbo_lk_track.argtypes = [fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp, fp, ctypes.c_int, ctypes.c_float,
                                     ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, fp]
         L.kpbo_lk_track.restype = None
+        L.kpbo_warp_se3.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int,
+                                    fp, fp, fp, fp, fp, ctypes.c_int, fp, fp, ip, ip, ip]
+        L.kpbo_warp_se3.restype = None
         _lib = L
     return _lib
 
@@ -181,3 +184,19 @@ def lk_track(img1_chw, img2_chw, pts1, pts2, unit, distance=3, win_size=3, level
         lib().kpbo_lk_track(_fp(a), _fp(b), C, H, W, _fp(p1), _fp(p2), _fp(u), n, float(distance), int(win_size), int(levels),
                             int(interation), _fp(out), _fp(err))
     return out, err
+
+
+def warp_se3(kps, depth0, depth1, kinv0, k1, pose01, bbox0, bbox1, fused=-1):
+    """utils/projection.py:195-268.  kinv0 = torch.inverse(intrinsics0) as unproject (43) computes it.
+    Returns (kpts0_valid, kpts01_valid, ids_valid, ids_out)."""
+    p = _f32(kps)
+    n = p.shape[0]
+    d0, d1 = _f32(depth0), _f32(depth1)
+    a = np.empty((max(n, 1), 2), np.float32); b = np.empty((max(n, 1), 2), np.float32)
+    iv = np.empty((max(n, 1),), np.int32); io = np.empty((max(n, 1),), np.int32); cnt = np.zeros(2, np.int32)
+    ipt = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+    if n:
+        lib().kpbo_warp_se3(_fp(p), n, p.shape[1], _fp(d0), d0.shape[0], d0.shape[1], _fp(d1), d1.shape[0], d1.shape[1],
+                            _fp(_f32(kinv0).reshape(9)), _fp(_f32(k1).reshape(9)), _fp(_f32(pose01).reshape(16)), _fp(_f32(bbox0)), _fp(_f32(bbox1)),
+                            int(fused), _fp(a), _fp(b), ipt(iv), ipt(io), ipt(cnt))
+    return a[:cnt[0]].copy(), b[:cnt[0]].copy(), iv[:cnt[0]].astype(np.int64), io[:cnt[1]].astype(np.int64)

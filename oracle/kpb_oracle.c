@@ -474,3 +474,75 @@ void kpbo_lk_track(const float* img1, const float* img2, int C, int H, int W, co
     }
     free(p1); free(p2); free(cur); free(l1);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * warp_se3, utils/projection.py:195-268 (with interpolate_depth 271-373, unproject 30-53, project 56-75): the
+ * depth-based covisibility warp of the 'se3' datasets.  All fp32, formulas as torch's CPU kernels evaluate them
+ * (fixture tests/golden/se3.npz).  The three einsums are [n,k] x [k,k] matmuls over the n0 points that survive
+ * interpolate_depth in image 0: this torch build hands them to its BLAS (fused multiply-add chain a0*b0, fma, fma ...)
+ * when m*n*k >= 400 and to its own unfused loop below that; `fused` < 0 follows that rule, 0/1 force a form. */
+static int se3_interp(const float* depth, int h, int w, float x, float y, float* z)
+{
+    const int border = 10;                                                       /* 272 */
+    const float i = y, j = x;                                                    /* 273: (w,h) -> (i,j) */
+    const long it = (long)floorf(i), jt = (long)floorf(j), ib = (long)ceilf(i), jr = (long)ceilf(j);
+    if (!(it >= border && jt >= border && jr < w - border && ib < h - border)) return 0;     /* 285-301: corners */
+    const float dtl = depth[it * w + jt], dtr = depth[it * w + jr], dbl = depth[ib * w + jt], dbr = depth[ib * w + jr];
+    if (!(dtl > 0.f && dtr > 0.f && dbl > 0.f && dbr > 0.f)) return 1;           /* 322-325: valid corners, no depth */
+    const float di = i - (float)it, dj = j - (float)jt;                          /* 348-349 */
+    const float wtl = (1.f - di) * (1.f - dj), wtr = (1.f - di) * dj, wbl = di * (1.f - dj), wbr = di * dj;
+    *z = ((wtl * dtl + wtr * dtr) + wbl * dbl) + wbr * dbr;                      /* 355-358 */
+    return 2;
+}
+
+static float se3_dot3(const float* a, float b0, float b1, float b2, int fused)
+{
+    return fused ? fmaf(a[2], b2, fmaf(a[1], b1, a[0] * b0)) : (a[0] * b0 + a[1] * b1) + a[2] * b2;
+}
+
+/* kps [n][stride] normalised; depth0 [H0][W0], depth1 [H1][W1]; kinv0 = inverse(intrinsics0) (computed by the caller with
+ * torch.inverse, as unproject does), k1 = intrinsics1, pose = pose01 [4][4], bbox0 / bbox1 = (row, col).
+ * out_k0 / out_k01 [n][2]; out_valid [n] ids; out_out [n] = ids_outside then ids_occlude; counts[0..1] = their lengths. */
+void kpbo_warp_se3(const float* kps, int n, int stride, const float* depth0, int H0, int W0, const float* depth1, int H1, int W1,
+                   const float* kinv0, const float* k1, const float* pose, const float* bbox0, const float* bbox1, int fused,
+                   float* out_k0, float* out_k01, int* out_valid, int* out_out, int* counts)
+{
+    int n0 = 0;
+    for (int i = 0; i < n; ++i) {
+        float z;
+        n0 += se3_interp(depth0, H0, W0, kps[(size_t)i * stride] * (float)W0, kps[(size_t)i * stride + 1] * (float)H0, &z) == 2;
+    }
+    const int f3 = fused < 0 ? 9 * n0 >= 400 : fused, f4 = fused < 0 ? 16 * n0 >= 400 : fused;
+    int nv = 0, nout = 0, nocc = 0;
+    int* occ = (int*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    for (int i = 0; i < n; ++i) {
+        const float x = kps[(size_t)i * stride] * (float)W0, y = kps[(size_t)i * stride + 1] * (float)H0;      /* 204 */
+        float z0;
+        if (se3_interp(depth0, H0, W0, x, y, &z0) != 2) continue;                                   /* 211: not in ids0 */
+        const float bu = (x + bbox0[1]) + 0.5f, bv = (y + bbox0[0]) + 0.5f;                         /* 214 */
+        const float d0 = bu * z0, d1 = bv * z0;                                                     /* 42 */
+        float p[3], q[3], zuv[3];
+        for (int r = 0; r < 3; ++r) p[r] = se3_dot3(kinv0 + 3 * r, d0, d1, z0, f3);                 /* 46 */
+        for (int r = 0; r < 3; ++r) {                                                               /* 221 */
+            const float* t = pose + 4 * r;
+            q[r] = f4 ? fmaf(t[3], 1.0f, fmaf(t[2], p[2], fmaf(t[1], p[1], t[0] * p[0]))) : ((t[0] * p[0] + t[1] * p[1]) + t[2] * p[2]) + t[3] * 1.0f;
+        }
+        for (int r = 0; r < 3; ++r) zuv[r] = se3_dot3(k1 + 3 * r, q[0], q[1], q[2], f3);            /* 68 */
+        const float u = zuv[0] / zuv[2], v = zuv[1] / zuv[2], z01 = zuv[2];                         /* 73-75 */
+        const float u01 = (u - bbox1[1]) - 0.5f, v01 = (v - bbox1[0]) - 0.5f;                       /* 227 */
+        float z1;
+        const int c = se3_interp(depth1, H1, W1, u01, v01, &z1);                                    /* 234 */
+        if (c == 0) { out_out[nout++] = i; continue; }                                              /* 236-239: ids_outside */
+        if (c == 1) continue;                                                                       /* corners but no depth: neither list */
+        if (fabsf(z01 - z1) < 0.05f) {                                                              /* 246 */
+            out_k0[2 * nv] = x / (float)W0; out_k0[2 * nv + 1] = y / (float)H0;                     /* 266 */
+            out_k01[2 * nv] = u01 / (float)W1; out_k01[2 * nv + 1] = v01 / (float)H1;               /* 267 */
+            out_valid[nv++] = i;
+        } else {
+            occ[nocc++] = i;                                                                        /* 249 */
+        }
+    }
+    for (int i = 0; i < nocc; ++i) out_out[nout + i] = occ[i];                                      /* 262 */
+    counts[0] = nv; counts[1] = nout + nocc;
+    free(occ);
+}
