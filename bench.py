@@ -308,7 +308,10 @@ def main():
         tot = sum(v[1] for v in prof.values())
         traffic = pmc_traffic(name, B, not args.sparse) if args.model == "alike" else None
         roof = dict(bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit, frac=round(achieved / peak, 4),
-                    traffic=traffic, kernel=name, avg_ms=round(avg_ms, 4), launches_per_step=calls / prof_steps,
+                    traffic=traffic, other_roof=dict(bound="hbm" if bound == "mfma" else "mfma", achieved=round(gbs if bound == "mfma" else tf, 3),
+                                                     peak=PEAK_HBM_GBS if bound == "mfma" else PEAK_F32_TFLOPS, unit="GB/s" if bound == "mfma" else "TFLOP/s",
+                                                     frac=round((gbs / PEAK_HBM_GBS) if bound == "mfma" else (tf / PEAK_F32_TFLOPS), 4)),
+                    kernel=name, avg_ms=round(avg_ms, 4), launches_per_step=calls / prof_steps,
                     share_of_step=round(total_ms / tot, 3),
                     kernels_ms_per_step={k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
 
