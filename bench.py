@@ -90,8 +90,9 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     c["conv1x1_agg2"] = (2 * (P // 4) * 16 * 16 * B2, (P // 4) * 128 * B2)
     c["conv1x1_agg3"] = (2 * (P // 64) * 32 * 16 * B2, (P // 64) * 192 * B2)
     c["conv1x1_agg4"] = (2 * (P // 1024) * 64 * 16 * B2, (P // 1024) * 320 * B2)
-    feat = 2 * 8 * 16 + 3 * 16 * 8 + 2 * 64            # agg1 + three 4-tap lerps + score dot
-    c["alike_head_dense"] = ((feat + 2 * 64 * 64) * P * B2, P * (32 + 4 + 256) * B2 + (P // 4 + P // 64 + P // 1024) * 64 * B2)
+    feat = 2 * 8 * 16 + 3 * 16 * 8 + 2 * 64            # agg1 + three 4-tap lerps + score dot (score-only kernel)
+    # head 64 -> 65 = 2 555.9 MFLOP/img, plus agg1 (8 -> 16 at full resolution, 78.6 MFLOP/img) which this kernel fuses
+    c["alike_head_dense"] = ((2 * 64 * 65 + 2 * 8 * 16) * P * B2, P * (32 + 4 + 256) * B2 + (P // 4 + P // 64 + P // 1024) * 64 * B2)
     c["alike_head_score"] = (feat * P * B2, P * (32 + 4) * B2 + (P // 4 + P // 64 + P // 1024) * 64 * B2)
     c["nms_sweep"] = (0, 2 * P * 4 * B2 / max(sweeps, 1))       # map read once + written once, spread over the sweeps
     c["select_topk"] = (0, (P * 4 + K * 16) * B2)
