@@ -7,10 +7,11 @@ GPU (pair index i goes to rank i mod W); every rank emits one fixed-width fp32 r
 all-gather (RCCL on GPUs, gloo in the CPU tests) moves the rows; rank 0 reduces them exactly as
 on_test_end would.  There is no other communication: weights are replicated and pairs are independent.
 
-Tasks: the metric functions of tasks/*.py need cv2 (RANSAC) and stay the reference's own code; pass
-them in through ``task_fn`` (or let ``install()`` swap this package's kernels under an importable
-reference checkout so that main.py runs unchanged).  ``match_stats`` is a dependency-free task used
-by bench.py and the tests: it returns [n_kps0, n_kps1, n_matches].
+Tasks: ``repeatability`` runs entirely on the device (detection, covisibility warp, val_key_points).  The other
+metric functions of tasks/*.py need cv2 (RANSAC) and stay the reference's own code; pass them in through
+``task_fn`` (or let ``install()`` swap this package's kernels under an importable reference checkout so that
+main.py runs unchanged).  ``match_stats`` is a dependency-free task used by bench.py and the tests: it returns
+[n_kps0, n_kps1, n_matches].
 """
 import os
 
@@ -157,6 +158,17 @@ def crop32(img):
     return img[..., : H - H % 32, : W - W % 32]
 
 
+def repeatability_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
+    """The 'repeatability' task of model_interface.py:205-212 on the device: one row [num_feat, repeatability, mean_error]
+    per pair (tasks/repeatability.py:87-92), the shape aggregate('repeatability', ...) reduces."""
+    from .tasks.repeatability import repeatability
+    res = repeatability(idx, img0, score0, img1, score1, warp01, warp10, params)
+    return [float(res["num_feat"]), float(res["repeatability"]), float(res["mean_error"])]
+
+
+TASKS = {"repeatability": repeatability_row}
+
+
 def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
     from .utils.extracter import detection
     from .utils.matcher import brute_force_matcher
@@ -174,7 +186,7 @@ class PairRunner:
         self.params = params
         self.device = torch.device(device)
         self.model = model if model is not None else build_model(params)
-        self.task_fn = task_fn if task_fn is not None else match_stats
+        self.task_fn = task_fn if task_fn is not None else TASKS.get(params.get("task_type"), match_stats)
         self.results = []
 
     def test_step(self, batch, idx):

@@ -58,3 +58,12 @@ def val_key_points(kps0, kps1, warp01, warp10, th: int = 3):
         "mean_error": error.mean(),                                            # 84 (nan when nothing is within th)
         "errors": errors,
     }
+
+
+def repeatability(idx, img_0, score_map_0, img_1, score_map_1, warp01, warp10, params):
+    """tasks/repeatability.py:95-122 without its plotting (cv2.imwrite of the keypoint overlays, 114-119): detection on
+    both score maps, then val_key_points.  Returns the reference's dict."""
+    from ..utils.extracter import detection
+    kps0 = detection(score_map_0, params["extractor_params"])
+    kps1 = detection(score_map_1, params["extractor_params"])
+    return val_key_points(kps0, kps1, warp01, warp10, th=params["repeatability_params"]["th"])
