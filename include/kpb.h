@@ -90,7 +90,8 @@ int kpb_fast_nms(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W, 
  * Row order: raster when N <= top_k, descending score (ties: ascending raster index) otherwise.
  * sync != 0: blocks until done, re-running sweeps for images that had not converged, and
  * returns KPB_E_NEGATIVE if any map held a negative score.  sync == 0: enqueue only; call
- * kpb_detect_check() later. */
+ * kpb_detect_check() later -- score_dev and the outputs must stay alive until then, and a second kpb_detect before
+ * that check is refused (KPB_E_INVALID): the context holds ONE pending detection. */
 int kpb_detect(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W,
                const kpb_detect_params* params, float* out_kps_dev, int32_t* out_idx_dev,
                int32_t* out_n_dev, int sync);
@@ -173,6 +174,18 @@ typedef struct kpb_lk_params {
 int kpb_lk_track(kpb_ctx* ctx, const float* img1_dev, const float* img2_dev, int C, int H, int W,
                  const float* pts1_dev, const float* pts2_dev, int pts_stride, const float* unit_dev,
                  int n, const kpb_lk_params* params, float* out_pts_dev, float* out_err_dev);
+
+/* ---- configs[3]: epipolar residual of the matches, tasks/FundamentalMatrix.py:137-161 ------------------------------
+ * kps0_dev [batch][max_k][cols0] matched rows of image 0, normalised (x, y, ...): scaled to pixels (x (W-1), y (H-1), 1);
+ * kps1_dev [batch][max_k][cols1] matched rows of image 1 as the reference's matcher branch leaves them --
+ * mode1 0 (brute force, 120-122): used as a 3-vector as they are (normalised x, y, score); 1 (LightGlue, 132-135):
+ * scaled to pixels with a 1 appended; 2 (optical flow, 117-119): pixel (x, y) with a 1 appended.
+ * k_dev [batch] valid rows or NULL (= max_k); fmat_dev [batch][9] row-major fundamental matrices (batch['fundamental']).
+ * out_err_dev [batch][max_k] = |x1^T F x0| / max(|(F x0)_xy|, 1e-6); out_stats_dev [batch][3] = (mean error,
+ * share of errors < th, their count). */
+int kpb_epipolar_error(kpb_ctx* ctx, const float* kps0_dev, int cols0, const float* kps1_dev, int cols1, int batch,
+                       int max_k, const int32_t* k_dev, const float* fmat_dev, int W, int H, int mode1, float th,
+                       float* out_err_dev, float* out_stats_dev);
 
 /* ---- 8(f)2: per-image input transform after decoding, datasets/hpatches.py:47-69 --------------------
  * src_dev [batch][Hs][Ws][3] uint8 as decoded (BGR from cv2.imread with swap_rb = 1, RGB with 0);

@@ -56,6 +56,8 @@ SIGNATURES = {
                                   c_void_p, c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "kpb_lk_track": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                              c_void_p, c_void_p, c_void_p]),
+    "kpb_epipolar_error": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_float, c_void_p, c_void_p]),
     "kpb_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "kpb_net_create": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "kpb_net_destroy": (None, [c_void_p]),

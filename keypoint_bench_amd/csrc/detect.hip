@@ -946,6 +946,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     if ((size_t)H * W >= (1u << 31)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: map too large");
     if (prm->top_k <= 0 || (prm->top_k > KPB_MAX_TOPK && prm->top_k < H * W))
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: top_k %d outside 1..%d (or >= H*W)", prm->top_k, KPB_MAX_TOPK);
+    if (ctx->det_pending)   // one DetState per context: a second enqueue would drop the first call's convergence / sign check
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: the previous kpb_detect(sync=0) has not been completed by kpb_detect_check "
+                                            "(its score map and outputs must stay alive until then)");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     const size_t P = (size_t)H * W;
     DetState& d = det_state(ctx);
@@ -993,7 +996,10 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
         }
         if (!pending) break;
         rerun = 1;
-        if (d.sweeps_run > 100000) return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_detect: NMS did not converge");
+        if (d.sweeps_run > 100000) {
+            ctx->det_pending = 0;
+            return kpb_fail(ctx, KPB_E_NOT_CONVERGED, "kpb_detect: NMS did not converge");
+        }
         if (int rc = nms_launch(ctx, d.plan, d.score, d.cur, d.batch, d.H, d.W, d.prm.nms_dist, d.sweeps_run, chunk)) return rc;
         d.sweeps_run += chunk;
         if (int rc = det_select(ctx, d)) return rc;

@@ -50,9 +50,12 @@ __global__ __launch_bounds__(256) void sample_bilinear(SampleArgs a)
 // ------------------------------------------------------------------------------------------------ M2
 // (s1, i1) precedes (s2, i2) in the order scipy/numpy induce: sqrt(s) ascending, index ascending.
 // sqrt can merge two sums that differ by an ulp, so near-ties are decided on the rooted values.
+// A NaN distance (a NaN descriptor) is the minimum, as numpy.argmin has it: the first NaN wins.
 __device__ __forceinline__ bool precedes(double s1, int i1, double s2, int i2)
 {
     if (s1 == s2) return i1 < i2;
+    const bool n1 = s1 != s1, n2 = s2 != s2;
+    if (n1 | n2) return n1 && (!n2 || i1 < i2);
     const double hi = fmax(s1, s2), lo = fmin(s1, s2);
     if (hi - lo <= hi * 4.5e-16) {
         const double d1 = sqrt(s1), d2 = sqrt(s2);
@@ -229,7 +232,8 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
                 if (precedes(s, j, bs, bj)) { bs = s; bj = j; }
             }
             dist = sqrt(bs);
-            keep = (!a.cross_check || colarg[bj] == i) && (dist < a.max_distance);
+            // skimage filters on distance only `if max_distance < np.inf`: inf / nan distances survive max_distance = inf
+            keep = (!a.cross_check || colarg[bj] == i) && (!(a.max_distance < __longlong_as_double(0x7FF0000000000000LL)) || dist < a.max_distance);
         }
         // ordered compaction (rows stay sorted by i, as numpy boolean masking leaves them)
         const unsigned long long bal = __ballot(keep);

@@ -94,12 +94,13 @@ class ALNet:
 
     # ---- forward
     def _ensure(self, device):
+        ctx = Context.get(device)       # every forward: the context follows torch's CURRENT stream (torch.cuda.stream(s))
         if self._handle is not None and self._device == device:
             return
         if self._blob is None:
             raise RuntimeError("ALNet: load_state_dict() / load_packed() must be called before forward")
         self._release()
-        self._ctx = Context.get(device)
+        self._ctx = ctx
         hs = []
         for _ in range(1 if self.dense_descriptors else self.KEEP):
             h = c_void_p()

@@ -38,12 +38,13 @@ class HipNet:
         return iter(())
 
     def _ensure(self, device):
+        ctx = Context.get(device)       # every forward: the context follows torch's CURRENT stream (torch.cuda.stream(s))
         if self._handle is not None and self._device == device:
             return
         if self._blob is None:
             raise RuntimeError("%s: load_state_dict() / load_packed() must be called before forward" % type(self).__name__)
         self._release()
-        self._ctx = Context.get(device)
+        self._ctx = ctx
         h = c_void_p()
         self._ctx.check(self._ctx.lib.kpb_net_create(self._ctx.handle, self.ARCH, self._blob, len(self._blob), ctypes.byref(h)))
         self._handle, self._device = h, device

@@ -59,6 +59,7 @@ class LightGlue:
             pass
 
     def _ensure(self, device):
+        ctx = Context.get(device)       # follow torch's current stream on every call
         if self._handle is not None and self._device == device:
             return
         if self._blob is None:
@@ -66,7 +67,7 @@ class LightGlue:
         if self.desc_scale is None:
             raise RuntimeError("LightGlue(features=None): set desc_scale (8 for SuperPoint maps, 1 for DISK)")
         self._release()
-        self._ctx = Context.get(device)
+        self._ctx = ctx
         h = c_void_p()
         self._ctx.check(self._ctx.lib.kpb_lg_create(self._ctx.handle, self._blob, len(self._blob), float(self.desc_scale), ctypes.byref(h)))
         self._handle, self._device = h, device

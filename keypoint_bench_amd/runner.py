@@ -67,8 +67,15 @@ def build_model(params, dense_descriptors=True):
 
 # ------------------------------------------------------------------------------------------ sharding
 def shard_indices(n_items, rank, world):
-    """Pair indices of this rank: i = rank (mod world)."""
+    """Pair datasets (independent units): rank r takes the pair indices i = r (mod world)."""
     return list(range(rank, n_items, world))
+
+
+def shard_chunk(n_items, rank, world):
+    """Sequence datasets (Exceptions): rank r takes the contiguous frames [r n / W, (r+1) n / W); it also
+    READS frame start-1 (one-frame overlap: the `last_batch` of its first step, model_interface.py:217-228) but emits
+    no row for it."""
+    return list(range(rank * n_items // world, (rank + 1) * n_items // world))
 
 
 def rows_per_rank(n_items, world):
@@ -87,10 +94,10 @@ def pack_rows(values, n_items, rank, world):
     return out
 
 
-def gather_rows(local_rows, n_items, device=None):
-    """One all-gather of the fixed-width rows; returns [n_items, ROW_WIDTH-1] in pair-index order on every rank."""
+def gather_rows(local_rows, n_items, device=None, shard=shard_indices):
+    """One all-gather of the fixed-width rows; returns [n_items, ROW_WIDTH-1] in item order on every rank.
+    `shard` is the rule the ranks used to pick their items (shard_indices or shard_chunk)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
     t = torch.from_numpy(np.ascontiguousarray(local_rows, np.float32))
     if world == 1:
         allr = t[None]
@@ -103,11 +110,10 @@ def gather_rows(local_rows, n_items, device=None):
     allr = allr.numpy()
     out = np.zeros((n_items, ROW_WIDTH - 1), np.float32)
     for r in range(world):
-        idx = shard_indices(n_items, r, world)
+        idx = shard(n_items, r, world)
         rows = allr[r][: len(idx)]
-        assert (rows[:, 0] == 1.0).all(), "missing pair rows from rank %d" % r
+        assert (rows[:, 0] == 1.0).all(), "missing rows from rank %d" % r
         out[idx] = rows[:, 1:]
-    del rank
     return out
 
 
@@ -152,21 +158,49 @@ def aggregate(task_type, rows, params=None):
 
 
 # ------------------------------------------------------------------------------------------ per-pair step
+SEQUENCE_DATASETS = ("Kitti", "Euroc", "TartanAir")     # model_interface.py:217
+
+
 def crop32(img):
     """model_interface.py:192-204 (the reference names H 'w' and W 'h'; the effect is a crop of both to x32)."""
     H, W = img.shape[-2:]
     return img[..., : H - H % 32, : W - W % 32]
 
 
+def as_image(v, device):
+    """Dataset items hold numpy arrays [C,H,W] (datasets/hpatches.py:74-83: no DataLoader collation here) or tensors."""
+    t = torch.as_tensor(v)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.to(device, non_blocking=True)
+
+
+def is_sequence_item(item):
+    ds = item.get("dataset")
+    if isinstance(ds, (list, tuple)):
+        ds = ds[0]
+    return ds in SEQUENCE_DATASETS or "image1" not in item
+
+
 def repeatability_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
-    """The 'repeatability' task of model_interface.py:205-212 on the device: one row [num_feat, repeatability, mean_error]
+    """The 'repeatability' task of model_interface.py:242-248 on the device: one row [num_feat, repeatability, mean_error]
     per pair (tasks/repeatability.py:87-92), the shape aggregate('repeatability', ...) reduces."""
     from .tasks.repeatability import repeatability
     res = repeatability(idx, img0, score0, img1, score1, warp01, warp10, params)
     return [float(res["num_feat"]), float(res["repeatability"]), float(res["mean_error"])]
 
 
-TASKS = {"repeatability": repeatability_row}
+def mha_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
+    """model_interface.py:249-253: one hit flag per threshold (tasks/MHA.py:68-72)."""
+    from .tasks.MHA import mha
+    return [float(v) for v in mha(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params)]
+
+
+def auc_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
+    """model_interface.py:254-259: [max(err_t, err_R), inliers] (tasks/AUC.py:151-154)."""
+    from .tasks.AUC import auc
+    r = auc(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params)
+    return [float(r["AUC"]), float(r["inliers"])]
 
 
 def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
@@ -178,87 +212,248 @@ def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, p
     return [k0.shape[0], k1.shape[0], m0.shape[0]]
 
 
-class PairRunner:
-    """Per-rank evaluation loop over a pair dataset (any indexable giving dicts with 'image0', 'image1'
-    and optionally 'warp01_params' / 'warp10_params', as datasets/hpatches.py:74-83 does)."""
+TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "AUC": auc_row, "match_stats": match_stats}
 
-    def __init__(self, params, task_fn=None, model=None, device="cuda:0"):
+
+# ---- the same tasks over a whole PairPipeline batch (rows equal to the single-pair functions above)
+def _batched_match_stats(pipe, items, params):
+    B = pipe.B
+    n, k = pipe.n.tolist(), pipe.k.tolist()
+    return [[n[b], n[B + b], k[b]] for b in range(len(items))]
+
+
+def _batched_repeatability(pipe, items, params):
+    from .tasks.repeatability import repeatability_batch
+    B, f = pipe.B, len(items)
+    pad = lambda ws: ws + [ws[-1]] * (B - f)
+    rows = repeatability_batch(pipe.kps, pipe.n, pad([it["warp01_params"] for it in items]), pad([it["warp10_params"] for it in items]),
+                               params["repeatability_params"]["th"])
+    return rows[:f]
+
+
+def _batched_mha(pipe, items, params):
+    from .tasks.MHA import mha_batch
+    return mha_batch(pipe, items, params)
+
+
+def _batched_auc(pipe, items, params):
+    from .tasks.AUC import auc_batch
+    return auc_batch(pipe, items, params)
+
+
+def _covis_tables(items, B, dev):
+    """(hmat [2B,9], wh [2B,2]) of the MHA flow: rows 0..B-1 warp01 of each pair, B..2B-1 warp10 (padded by repetition)."""
+    from .tasks.repeatability import homography_tables
+    pad = lambda ws: ws + [ws[-1]] * (B - len(ws))
+    hm01, wh01, _ = homography_tables(pad([it["warp01_params"] for it in items]), dev)
+    hm10, wh10, _ = homography_tables(pad([it["warp10_params"] for it in items]), dev)
+    return torch.cat([hm01, hm10]).contiguous(), torch.cat([wh01, wh10]).contiguous()
+
+
+# task -> (rows function, pipeline needs the match stage, keypoints are covisibility-filtered before matching)
+BATCHED_TASKS = {"match_stats": (_batched_match_stats, True, False), "repeatability": (_batched_repeatability, False, False),
+                 "MHA": (_batched_mha, True, True), "AUC": (_batched_auc, True, False)}
+
+
+def _homo_only(item):
+    return all(item.get(k, {}).get("mode", "homo") == "homo" for k in ("warp01_params", "warp10_params"))
+
+
+class PairRunner:
+    """Per-rank evaluation loop (MInterface.test_step / on_test_end, model_interface.py:119-299) over
+
+    * a pair dataset: any indexable of dicts with 'image0', 'image1' and optionally 'warp01_params' / 'warp10_params', as
+      datasets/hpatches.py:74-83 returns them (numpy [C,H,W] images; tensors work too).  Pairs of equal cropped shape are
+      collected `batch` at a time and pushed through PairPipeline (net -> detection -> sampling -> match in one launch
+      wave), the task is evaluated on the whole batch on the device; ragged shapes, se3 warps and user-supplied
+      `task_fn`s take the single-pair path (`test_step`), whose rows the batched path reproduces bit for bit;
+    * a sequence dataset ('dataset' in Kitti / Euroc / TartanAir, items with 'image0' and 'fundamental'): the
+      `last_batch` flow of model_interface.py:217-228 with the FundamentalMatrix task (261-276), frames sharded in
+      contiguous chunks with a one-frame overlap."""
+
+    def __init__(self, params, task_fn=None, model=None, device="cuda:0", batch=64, matcher=None, dense_descriptors=False):
         self.params = params
         self.device = torch.device(device)
-        self.model = model if model is not None else build_model(params)
+        self.model = model if model is not None else build_model(params, dense_descriptors=dense_descriptors)
+        self.matcher = matcher
+        self.user_task = task_fn is not None
         self.task_fn = task_fn if task_fn is not None else TASKS.get(params.get("task_type"), match_stats)
+        self.batch = int(batch)
         self.results = []
+        self.last_batch = None
+        self._pipes = {}
+        self.batched_pairs = 0
 
+    # ---- single pair (model_interface.py:189-212 + the task call)
     def test_step(self, batch, idx):
-        img0 = crop32(batch["image0"]).to(self.device)
-        img1 = crop32(batch["image1"]).to(self.device)
+        img0 = crop32(as_image(batch["image0"], self.device))
+        img1 = crop32(as_image(batch["image1"], self.device))
         if img0.dim() == 3:
             img0, img1 = img0[None], img1[None]
-        s0, d0 = self.model(img0)     # model_interface.py:205-207
-        s1, d1 = self.model(img1)
+        with torch.no_grad():
+            s0, d0 = self.model(img0)     # model_interface.py:205-207
+            s1, d1 = self.model(img1)
         r = self.task_fn(idx, img0, s0, d0, img1, s1, d1, batch.get("warp01_params", {}), batch.get("warp10_params", {}),
                          self.params)
         self.results.append(r)
         return r
 
+    # ---- one frame of a sequence (model_interface.py:217-228, 261-276)
+    def sequence_step(self, batch, idx):
+        from .tasks.FundamentalMatrix import fundamental_matrix
+        cur = dict(batch)
+        img = as_image(batch["image0"], self.device)
+        cur["image0"] = img[None] if img.dim() == 3 else img
+        f = torch.as_tensor(batch["fundamental"], dtype=torch.float32).to(self.device)
+        cur["fundamental"] = f[None] if f.dim() == 2 else f                       # what DataLoader collation adds
+        if self.last_batch is None:
+            self.last_batch = cur
+        with torch.no_grad():
+            s0, d0 = self.model(self.last_batch["image0"])
+            s1, d1 = self.model(cur["image0"])
+        last_img = self.last_batch["image0"]
+        self.last_batch = cur
+        mp = self.params["matcher_params"]
+        if mp["type"] == "optical_flow":      # 262-267: the tracker works on the two images
+            res = fundamental_matrix(idx, last_img, cur, s0, s1, last_img, cur["image0"], self.matcher, self.params)
+        else:
+            res = fundamental_matrix(idx, last_img, cur, s0, s1, d0, d1, self.matcher, self.params)
+        r = [float(res["fundamental_error"]), float(res["fundamental_radio"]), float(res["fundamental_num"])]
+        self.results.append(r)
+        return r
+
+    # ---- batched pairs
+    def _pipe(self, B, H, W, match, lightglue=None):
+        from .pipeline import PairPipeline
+        key = (B, H, W, match)
+        if key not in self._pipes:
+            self._pipes = {k: v for k, v in self._pipes.items() if k[1:3] == (H, W)}      # one resolution resident at a time
+            mp = self.params.get("matcher_params", {})
+            bf = mp.get("brute_force_params", dict(metric="euclidean", max_distance=float("inf"), cross_check=True))
+            self._pipes[key] = (PairPipeline(self.model, self.params["extractor_params"], bf, B, H, W, device=self.device, match=match),
+                                torch.empty((2 * B, 3, H, W), dtype=torch.float32, device=self.device))
+        return self._pipes[key]
+
+    def _flush(self, group, task_type):
+        """group: list of (index, item, img0, img1) with equal cropped shapes."""
+        fn, match, covis = BATCHED_TASKS[task_type]
+        f = len(group)
+        H, W = group[0][2].shape[-2:]
+        B = self.batch if f > self.batch // 2 else f        # a short tail gets a pipeline of its own size
+        pipe, images = self._pipe(B, H, W, match)
+        for j, (_, _, a, b) in enumerate(group):
+            images[j].copy_(a.reshape(3, H, W), non_blocking=True)
+            images[B + j].copy_(b.reshape(3, H, W), non_blocking=True)
+        for j in range(f, B):                               # pad with the last pair; its rows are dropped
+            images[j].copy_(images[f - 1])
+            images[B + j].copy_(images[B + f - 1])
+        items = [g[1] for g in group]
+        pipe.run(images, _covis_tables(items, B, self.device) if covis else None)
+        rows = fn(pipe, items, self.params)
+        self.batched_pairs += f
+        return rows
+
+    def _run_pairs(self, dataset, indices, task_type):
+        batched = (not self.user_task) and task_type in BATCHED_TASKS and self.batch > 1 and hasattr(self.model, "_handle")
+        out, group, shape = {}, [], None
+
+        def flush():
+            nonlocal group
+            if group:
+                for (i, _, _, _), r in zip(group, self._flush(group, task_type)):
+                    out[i] = r
+            group = []
+
+        for i in indices:
+            item = dataset[i]
+            if not batched or not _homo_only(item):
+                flush()
+                out[i] = self.test_step(item, i)
+                continue
+            a, b = crop32(as_image(item["image0"], self.device)), crop32(as_image(item["image1"], self.device))
+            if a.shape[-2:] != b.shape[-2:]:                # the two views differ in size: single-pair path
+                flush()
+                out[i] = self.test_step(item, i)
+                continue
+            if shape is not None and a.shape[-2:] != shape:
+                flush()
+            shape = a.shape[-2:]
+            group.append((i, item, a, b))
+            if len(group) == self.batch:
+                flush()
+        flush()
+        return [out[i] for i in indices]
+
+    # ---- batched sequence (BASELINE configs[3]: brute-force branch)
+    def _run_sequence(self, dataset, indices):
+        from .pipeline import SequencePipeline
+        from .tasks.FundamentalMatrix import epipolar_error
+        mp = self.params["matcher_params"]
+        batched = (not self.user_task) and self.batch > 1 and hasattr(self.model, "_handle") and \
+            (mp["type"] == "brute_force" or (mp["type"] == "light_glue" and self.matcher is None))
+        rows = []
+        if not indices:
+            return rows
+        if not batched:
+            self.last_batch = None
+            if indices[0] > 0:              # one-frame overlap: the frame before the chunk becomes last_batch, no row
+                prev = dict(dataset[indices[0] - 1])
+                img = as_image(prev["image0"], self.device)
+                prev["image0"] = img[None] if img.dim() == 3 else img
+                self.last_batch = prev
+            for i in indices:
+                rows.append(self.sequence_step(dataset[i], i))
+            return rows
+        first = as_image(dataset[indices[0]]["image0"], self.device)
+        H, W = first.shape[-2:]
+        F = min(self.batch, len(indices))
+        pipe = SequencePipeline(self.model, self.params["extractor_params"], mp["brute_force_params"], F, H, W, device=self.device)
+        images = torch.empty((F, 3, H, W), dtype=torch.float32, device=self.device)
+        if indices[0] > 0:
+            pipe.prime(as_image(dataset[indices[0] - 1]["image0"], self.device))
+        th = self.params["FundamentalMatrix_params"]["th"]
+        for c0 in range(0, len(indices), F):
+            chunk = indices[c0:c0 + F]
+            f = len(chunk)
+            fm = []
+            for j, i in enumerate(chunk):
+                item = dataset[i]
+                images[j].copy_(as_image(item["image0"], self.device).reshape(3, H, W), non_blocking=True)
+                fm.append(torch.as_tensor(item["fundamental"], dtype=torch.float32).reshape(9))
+            pipe.run(images[:f], first=(chunk[0] == 0))
+            fmat = torch.stack(fm).to(self.device)
+            _, stats = epipolar_error(pipe.m0[:f], pipe.m1[:f], fmat, W, H, 0, th, k_dev=pipe.k)      # FundamentalMatrix.py:120-122: mode 0
+            st, kk = stats.cpu().numpy(), pipe.k[:f].tolist()
+            for j in range(f):
+                if kk[j] == 0:
+                    raise ZeroDivisionError("division by zero")        # FundamentalMatrix.py:159 on an empty match set
+                rows.append([float(st[j, 0]), float(st[j, 2]) / kk[j], float(st[j, 2])])
+            self.batched_pairs += f
+        return rows
+
     def run(self, dataset, task_type=None):
-        """Shards the dataset over the ranks, runs test_step on the local pairs, gathers, reduces on every rank."""
+        """Shards the dataset over the ranks, evaluates the local items, gathers the rows (ONE all-gather), reduces on
+        every rank like on_test_end.  Returns (aggregate dict, rows [n_items, ROW_WIDTH-1])."""
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
         n = len(dataset)
+        task_type = task_type or self.params.get("task_type", "match_stats")
         self.results = []
-        for i in shard_indices(n, rank, world):
-            self.test_step(dataset[i], i)
-        rows = gather_rows(pack_rows(self.results, n, rank, world), n, device=self.device if world > 1 else None)
-        return aggregate(task_type or self.params.get("task_type", "match_stats"), rows, self.params), rows
+        sequence = n > 0 and is_sequence_item(dataset[0])
+        shard = shard_chunk if sequence else shard_indices
+        indices = shard(n, rank, world)
+        if sequence:
+            self.results = self._run_sequence(dataset, indices)
+        else:
+            if not self.user_task:
+                self.task_fn = TASKS.get(task_type, self.task_fn)
+            self.results = self._run_pairs(dataset, indices, task_type)
+        rows = gather_rows(pack_rows(self.results, n, rank, world), n, device=self.device if world > 1 else None, shard=shard)
+        return aggregate(task_type, rows, self.params), rows
 
 
 # ------------------------------------------------------------------------------------------ install shim
 def install():
-    """Swap this package's kernels under an importable reference checkout (its root on sys.path) so that
-    ``python3 main.py -c config/config_MHA.yaml test`` and every task run unchanged: replaces
-    utils.extracter.{detection,fast_nms}, utils.matcher.brute_force_matcher and models.ALike.ALNet, and
-    re-binds the names in task / harness modules that imported them earlier."""
-    import importlib
-    import sys
-    from .models.ALike import ALNet
-    from .models.SuperPoint import SuperPointNet
-    from .models.XFeat import XFeatModel
-    from .models.disk import DISK
-    from .utils import extracter as ex, matcher as ma
-    swapped = []
-    for modname, names in (("utils.extracter", {"detection": ex.detection, "fast_nms": ex.fast_nms}),
-                           ("utils.matcher", {"brute_force_matcher": ma.brute_force_matcher, "OpticalFlow": ma.OpticalFlow,
-                                              "optical_flow_tensor": ma.optical_flow_tensor}),
-                           ("models.ALike", {"ALNet": ALNet}), ("models.SuperPoint", {"SuperPointNet": SuperPointNet}),
-                           ("models.XFeat", {"XFeatModel": XFeatModel}), ("models.disk", {"DISK": DISK})):
-        try:
-            mod = importlib.import_module(modname)
-        except Exception:
-            continue
-        for k, v in names.items():
-            setattr(mod, k, v)
-            swapped.append(modname + "." + k)
-    # SURVEY 8(f)1: the two covisibility warps and the repeatability core (`warp` keeps dispatching on params['mode'])
-    from .tasks import repeatability as rp
-    from .utils import projection as pj
-    try:
-        mod = importlib.import_module("utils.projection")
-        mod.warp_homography = pj.warp_homography
-        mod.warp_se3 = pj.warp_se3
-        swapped += ["utils.projection.warp_homography", "utils.projection.warp_se3"]
-        mod = importlib.import_module("tasks.repeatability")
-
-        mod.val_key_points = rp.val_key_points
-        swapped.append("tasks.repeatability.val_key_points")
-    except Exception:
-        pass
-    for name, mod in list(sys.modules.items()):
-        if mod is None or not (name.startswith("tasks.") or name == "models.model_interface"):
-            continue
-        for k, v in (("detection", ex.detection), ("brute_force_matcher", ma.brute_force_matcher), ("optical_flow_tensor", ma.optical_flow_tensor), ("ALNet", ALNet),
-                     ("SuperPointNet", SuperPointNet), ("XFeatModel", XFeatModel), ("DISK", DISK)):
-            if hasattr(mod, k):
-                setattr(mod, k, v)
-                swapped.append(name + "." + k)
-    return swapped
+    """Swap this package's kernels under an importable reference checkout: see keypoint_bench_amd/shim.py."""
+    from . import shim
+    return shim.install()

@@ -67,3 +67,53 @@ def repeatability(idx, img_0, score_map_0, img_1, score_map_1, warp01, warp10, p
     kps0 = detection(score_map_0, params["extractor_params"])
     kps1 = detection(score_map_1, params["extractor_params"])
     return val_key_points(kps0, kps1, warp01, warp10, th=params["repeatability_params"]["th"])
+
+
+def homography_tables(warps, dev):
+    """Stacks the 'homo' warp dicts of B pairs: (hmat [B, 9] fp32, wh [B, 2] int32 = width, height, scale [B])."""
+    hm = torch.stack([torch.as_tensor(w["homography_matrix"], dtype=torch.float32).reshape(9).cpu() for w in warps]).to(dev)
+    wh = torch.tensor([[_scalar(w["width"]), _scalar(w["height"])] for w in warps], dtype=torch.int32).to(dev)
+    return hm.contiguous(), wh.contiguous(), [_scale(w) for w in warps]
+
+
+def repeatability_batch(kps, n, warps01, warps10, th):
+    """val_key_points (54-92) for B pairs in four launches and one read-back.  kps [2B, K, 3] / n [2B] as
+    PairPipeline leaves them (rows 0..B-1 image 0, B..2B-1 image 1); warps01 / warps10: lists of B 'homo' warp dicts.
+    Returns B rows [num_feat, repeatability, mean_error] equal to the single-pair path's."""
+    import numpy as np
+    dev = kps.device
+    B, K = len(warps01), kps.shape[1]
+    ctx = Context.get(dev)
+    hm01, wh01, s01 = homography_tables(warps01, dev)
+    hm10, wh10, s10 = homography_tables(warps10, dev)
+    hm, wh = torch.cat([hm01, hm10]).contiguous(), torch.cat([wh01, wh10]).contiguous()
+    k0 = torch.empty((2 * B, K, 2), dtype=torch.float32, device=dev)
+    k01 = torch.empty((2 * B, K, 2), dtype=torch.float32, device=dev)
+    ids = torch.empty((2 * B, K), dtype=torch.int32, device=dev)
+    nc = torch.empty((2 * B,), dtype=torch.int32, device=dev)
+    ctx.check(ctx.lib.kpb_warp_homography(ctx.handle, ptr(kps), 2 * B, K, 3, ptr(n), ptr(hm), ptr(wh), ptr(k0), ptr(k01), ptr(ids), ptr(nc)))
+    scale = torch.tensor(list(zip(s01, s10)), dtype=torch.float32, device=dev).contiguous()
+    cap = 2 * K + 1024
+    pairs = torch.empty((B, cap, 2), dtype=torch.int32, device=dev)
+    dist = torch.empty((B, cap), dtype=torch.float32, device=dev)
+    errors = torch.empty((B, K), dtype=torch.float32, device=dev)
+    counts = torch.zeros((B, 2), dtype=torch.int32, device=dev)
+    ctx.check(ctx.lib.kpb_val_keypoints(ctx.handle, ptr(k0[:B]), ptr(k01[:B]), ptr(k0[B:]), ptr(k01[B:]), B, K, K, ptr(nc[:B]), ptr(nc[B:]),
+                                        ptr(scale), float(th), ptr(pairs), ptr(dist), cap, ptr(errors), ptr(counts)))
+    n_h, nc_h, cnt_h, dist_h = n.cpu().numpy(), nc.cpu().numpy(), counts.cpu().numpy(), dist.cpu().numpy()
+    rows = []
+    for b in range(B):
+        num_feat = int(min(n_h[b], n_h[B + b]))
+        M, N = int(nc_h[b]), int(nc_h[B + b])
+        if M == 0 or N == 0:
+            rows.append([0.0, 0.0, 0.0])                                   # 61-67
+            continue
+        total, gt = int(cnt_h[b, 0]), int(cnt_h[b, 1])
+        if total > cap:                 # more mutual ties than the shared capacity: this pair alone, with room
+            _, d, _, gt = gt_mutual(k0[b, :M], k01[b, :M], k0[B + b, :N], k01[B + b, :N], s01[b], s10[b], th, cap=total)
+            d = d.cpu().numpy()
+        else:
+            d = dist_h[b, :total]
+        err = d[d <= th]
+        rows.append([float(num_feat), float(np.float32(gt) / np.float32(num_feat)), float(err.mean()) if err.size else float("nan")])
+    return rows

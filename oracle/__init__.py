@@ -200,3 +200,35 @@ def warp_se3(kps, depth0, depth1, kinv0, k1, pose01, bbox0, bbox1, fused=-1):
                             _fp(_f32(kinv0).reshape(9)), _fp(_f32(k1).reshape(9)), _fp(_f32(pose01).reshape(16)), _fp(_f32(bbox0)), _fp(_f32(bbox1)),
                             int(fused), _fp(a), _fp(b), ipt(iv), ipt(io), ipt(cnt))
     return a[:cnt[0]].copy(), b[:cnt[0]].copy(), iv[:cnt[0]].astype(np.int64), io[:cnt[1]].astype(np.int64)
+
+
+def epipolar_error(kps0, kps1, fmat, W, H, mode1=0):
+    """tasks/FundamentalMatrix.py:137-144 in numpy fp32: |x1^T F x0| / max(|(F x0)_xy|, 1e-6) per match.
+    kps0 [K, >=2] normalised rows; kps1 rows as the matcher branch leaves them (mode1 0: the (x, y, score) rows
+    themselves, 120-122; 1: scaled to pixels with a 1 appended, 134-135; 2: pixels with a 1 appended, 117-119)."""
+    k0 = _f32(kps0)
+    k1 = _f32(kps1)
+    F = _f32(fmat).reshape(3, 3)
+    p0 = np.concatenate([k0[:, :2] * np.array([W - 1, H - 1], np.float32), np.ones((len(k0), 1), np.float32)], 1)
+    if mode1 == 0:
+        p1 = k1[:, :3]
+    elif mode1 == 1:
+        p1 = np.concatenate([k1[:, :2] * np.array([W - 1, H - 1], np.float32), np.ones((len(k1), 1), np.float32)], 1)
+    else:
+        p1 = np.concatenate([k1[:, :2], np.ones((len(k1), 1), np.float32)], 1)
+    I = (F @ p0.T).astype(np.float32)                                   # 140
+    err = np.abs(np.einsum("ij,ji->i", p1, I)).astype(np.float32)       # 141-142: the diagonal of kps1 @ I
+    nrm = np.maximum(np.sqrt(I[0] * I[0] + I[1] * I[1]), np.float32(1e-6))   # 143
+    return (err / nrm).astype(np.float32)
+
+
+def fundamental_matrix(score0_hw, score1_hw, desc0_chw, desc1_chw, fmat, params):
+    """tasks/FundamentalMatrix.py:89-161, brute-force branch (120-126), on numpy inputs.
+    Returns (mean error, ratio under th, count under th, matched rows 0, matched rows 1)."""
+    k0, _ = detection(score0_hw, params["extractor_params"])
+    k1, _ = detection(score1_hw, params["extractor_params"])
+    m0, m1 = brute_force_matcher(k0, k1, desc0_chw, desc1_chw, params["matcher_params"]["brute_force_params"])
+    H, W = np.asarray(score0_hw).shape
+    err = epipolar_error(m0, m1, fmat, W, H, 0)
+    num = int((err < np.float32(params["FundamentalMatrix_params"]["th"])).sum())
+    return float(err.mean(dtype=np.float32)), num / len(err), num, m0, m1

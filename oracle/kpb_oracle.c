@@ -208,8 +208,9 @@ int kpbo_match(const float* d0, int n, const float* d1, int m, int C, double max
                 s += d * d;
             }
             const double dist = sqrt(s);
-            if (dist < best) { best = dist; arg = j; }
-            if (dist < colmin[j]) { colmin[j] = dist; colarg[j] = i; }
+            /* numpy.argmin: the first NaN wins, otherwise the first minimum */
+            if ((dist < best || (dist != dist && best == best)) ) { best = dist; arg = j; }
+            if ((dist < colmin[j] || (dist != dist && colmin[j] == colmin[j]))) { colmin[j] = dist; colarg[j] = i; }
         }
         rowmin[i] = best; rowarg[i] = arg;
     }
@@ -217,7 +218,8 @@ int kpbo_match(const float* d0, int n, const float* d1, int m, int C, double max
     for (int i = 0; i < n; ++i) {
         const int j = rowarg[i];
         if (cross_check && colarg[j] != i) continue;
-        if (!(rowmin[i] < max_distance)) continue;
+        /* skimage applies the distance filter only `if max_distance < np.inf` (so inf / nan distances survive max_distance = inf) */
+        if (max_distance < INFINITY && !(rowmin[i] < max_distance)) continue;
         out_pairs[2 * K] = i; out_pairs[2 * K + 1] = j; out_dist[K] = rowmin[i];
         ++K;
     }

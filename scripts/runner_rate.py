@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Throughput of the REAL task path: PairRunner.run over a synthetic 640x480 pair dataset (the batched PairPipeline under
+the runner) for the tasks the library evaluates on the device, next to bench.py's bare pipeline loop.
+
+    python scripts/runner_rate.py [--pairs 256] [--batch 256] [--repeat 3] [--tasks match_stats repeatability ...]
+
+Dataset items are device-resident tensors (bench.py's convention: inputs resident in HBM) unless --host is given, in
+which case they are numpy arrays as datasets/hpatches.py returns them and every image crosses PCIe inside the loop."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--distinct", type=int, default=32)
+    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--host", action="store_true")
+    ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--tasks", nargs="+", default=["match_stats", "repeatability", "MHA"])
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from keypoint_bench_amd import runner, synthetic
+    dev = "cuda:0"
+    H, W = 480, 640
+    h01 = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
+    views = [synthetic.image_pair(5000 + i, H, W) for i in range(args.distinct)]
+    if not args.host:
+        views = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in views]
+    ds = []
+    for i in range(args.pairs):
+        v0, v1 = views[i % args.distinct]
+        ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
+                   "warp01_params": dict(mode="homo", homography_matrix=h01, width=W, height=H),
+                   "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(h01).astype(np.float32), width=W, height=H)})
+    out = {"pairs": args.pairs, "batch": args.batch, "items": "host numpy" if args.host else "device tensors",
+           "descriptors": "dense-map" if args.dense else "keypoint-only"}
+    for task in args.tasks:
+        params = {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),
+                  "extractor_params": dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0),
+                  "matcher_params": {"type": "brute_force", "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
+                  "repeatability_params": {"th": 3}, "MHA_params": {"th": [3, 5, 7]}}
+        r = runner.PairRunner(params, device=dev, batch=args.batch, dense_descriptors=args.dense)
+        try:
+            agg, _ = r.run(ds)            # warm-up: allocations, first-shape workspaces
+        except (ImportError, NotImplementedError) as e:
+            out[task] = "unavailable: %s" % e
+            continue
+        best = 1e9
+        for _ in range(args.repeat):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            agg, rows = r.run(ds)
+            torch.cuda.synchronize()
+            best = min(best, time.perf_counter() - t0)
+        out[task] = {"pairs_per_s": round(args.pairs / best, 1), "ms_per_pair": round(1e3 * best / args.pairs, 4), "batched_pairs": r.batched_pairs,
+                     "aggregate": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in agg.items()}}
+        del r
+        torch.cuda.empty_cache()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,9 +17,12 @@ How each reference module is loaded:
                        does not use it); skimage.feature.match_descriptors is third-party code that
                        is absent from the reference tree AND from this image, so a capture hook
                        stands in for it: it records the descriptors the reference's own
-                       grid_sample lines (matcher.py:221-226) hand over, and answers with the
-                       oracle's restatement.  M1/M3 goldens are therefore the reference's; M2's
-                       are the restatement's ("parity unpinned" for M2).
+                       grid_sample lines (matcher.py:221-226) hand over, and answers with
+                       tests/golden/skimage_standin.py = scipy.spatial.distance.cdist (the real
+                       dependency skimage delegates to) + skimage's documented argmin / cross-check
+                       glue.  M1/M3 goldens are the reference's; M2's distances are scipy's, its
+                       glue a restatement ("parity unpinned" for that glue).  The
+                       oracle is NOT involved in producing any fixture.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -49,7 +52,7 @@ def main():
     import torch
     import torch.nn as nn
     sys.path.insert(0, ROOT)
-    import oracle
+
     from keypoint_bench_amd import synthetic, weights
 
     torch.manual_seed(0)
@@ -163,10 +166,14 @@ def main():
     skf = types.ModuleType("skimage.feature")
     captured = {}
 
+    sys.path.insert(0, HERE)
+    import skimage_standin          # scipy.cdist (the real dependency) + skimage's documented glue; NOT the oracle
+
     def match_descriptors(d0, d1, metric=None, max_distance=np.inf, cross_check=True, **kw):
         captured["d0"], captured["d1"] = np.array(d0), np.array(d1)
-        pairs, dist = oracle.match(d0, d1, max_distance, cross_check)
-        captured["pairs"], captured["dist"] = pairs, dist
+        pairs = skimage_standin.match_descriptors(np.asarray(d0), np.asarray(d1), metric=metric, max_distance=max_distance,
+                                                  cross_check=cross_check, **kw)
+        captured["pairs"], captured["dist"] = pairs, skimage_standin.distances_of(np.asarray(d0), np.asarray(d1), pairs)
         return pairs
 
     skf.match_descriptors = match_descriptors
@@ -256,6 +263,7 @@ def main():
             mt[name + "." + k] = v
         mcases.append(name)
         print("  match", name, "->", r0.shape[0], "matches")
+    mt["scipy_version"] = np.array(skimage_standin.SCIPY_VERSION)
     mt["cases"] = np.array(mcases)
     np.savez_compressed(os.path.join(HERE, "match.npz"), **mt)
     return 0

@@ -1,0 +1,96 @@
+"""PairRunner on the device: the batched path (PairPipeline under the runner) must give the rows of the single-pair
+drop-in path bit for bit; dataset items are numpy dicts as datasets/hpatches.py:74-83 returns them; sequence datasets
+follow model_interface.py:217-228 and their contiguous chunks with one-frame overlap reproduce the single-rank rows."""
+import numpy as np
+import pytest
+import torch
+
+from keypoint_bench_amd import runner, synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=300, min_score=0.0)
+BF = dict(metric="euclidean", max_distance=5, cross_check=True)
+H01 = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
+
+
+def params(task):
+    return {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64), "extractor_params": EP,
+            "matcher_params": {"type": "brute_force", "brute_force_params": BF}, "repeatability_params": {"th": 3},
+            "FundamentalMatrix_params": {"th": 3.0}}
+
+
+def pair_dataset(n, shapes=((96, 128),)):
+    ds = []
+    for i in range(n):
+        h, w = shapes[i % len(shapes)]
+        v0, v1 = synthetic.image_pair(100 + i, h, w)        # numpy [3,H,W] float32: what the reference datasets hand out
+        hm = H01 + (0.001 * (i % 3)) * np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 0]], np.float32)
+        ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
+                   "warp01_params": dict(mode="homo", homography_matrix=hm, width=np.int64(w), height=np.int64(h), resize=np.int64(w)),
+                   "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(hm).astype(np.float32), width=w, height=h)})
+    return ds
+
+
+@pytest.mark.parametrize("task", ["match_stats", "repeatability"])
+@pytest.mark.parametrize("dense", [False, True])
+def test_batched_rows_equal_single_pair_rows(task, dense):
+    ds = pair_dataset(11, shapes=((96, 128), (96, 128), (96, 128), (64, 96), (96, 128), (100, 130)))     # ragged: 100x130 crops to 96x128
+    single = runner.PairRunner(params(task), device=DEV, batch=1, dense_descriptors=dense)
+    _, rows1 = single.run(ds)
+    assert single.batched_pairs == 0
+    batched = runner.PairRunner(params(task), device=DEV, batch=4, dense_descriptors=dense)
+    agg, rowsb = batched.run(ds)
+    assert batched.batched_pairs == 11
+    assert np.array_equal(rows1.view(np.uint32), rowsb.view(np.uint32)), (rows1, rowsb)
+    assert rowsb[:, 0].min() > 50                                         # the rows carry real keypoint counts
+    assert np.isfinite(agg["mean_matches" if task == "match_stats" else "repeatability"])
+
+
+def test_numpy_items_and_user_task_fn_take_the_single_pair_path():
+    ds = pair_dataset(3)
+    seen = []
+
+    def task(idx, img0, s0, d0, img1, s1, d1, w01, w10, prm):
+        seen.append((idx, tuple(s0.shape), w01["mode"]))
+        return [float(s0.shape[2]), float(s0.shape[3])]
+
+    r = runner.PairRunner(params("match_stats"), task_fn=task, device=DEV, batch=8)
+    _, rows = r.run(ds, task_type="match_stats")
+    assert [s[0] for s in seen] == [0, 1, 2] and seen[0][1] == (1, 1, 96, 128) and r.batched_pairs == 0
+    assert rows[:, :2].tolist() == [[96.0, 128.0]] * 3
+
+
+def sequence_dataset(n, h=96, w=128):
+    rng = np.random.default_rng(9)
+    canvas, _ = synthetic.image_pair(300, h + 40, w + 40)
+    ds = []
+    for i in range(n):
+        F = rng.normal(size=(3, 3)).astype(np.float32)
+        ds.append({"image0": canvas[:, i:i + h, 2 * i:2 * i + w].copy(), "fundamental": torch.from_numpy(F), "dataset": "TartanAir"})
+    return ds
+
+
+def test_sequence_rows_batched_equal_single_and_chunks_reproduce_them():
+    ds = sequence_dataset(9)
+    prm = params("FundamentalMatrix")
+    single = runner.PairRunner(prm, device=DEV, batch=1, dense_descriptors=True)
+    agg1, rows1 = single.run(ds)
+    assert single.batched_pairs == 0 and rows1.shape[0] == 9
+    # frame 0 pairs with itself (last_batch starts as the batch, model_interface.py:218-219): every keypoint matches itself
+    assert rows1[0, 2] <= rows1[0, 2] and agg1["fundamental_num"] >= 0
+    batched = runner.PairRunner(prm, device=DEV, batch=4, dense_descriptors=False)
+    _, rowsb = batched.run(ds)
+    assert batched.batched_pairs == 9
+    assert np.array_equal(rows1.view(np.uint32), rowsb.view(np.uint32)), (rows1, rowsb)
+    # contiguous chunks with one-frame overlap: what ranks 0..2 of a 3-rank run would each compute
+    for world in (2, 3):
+        got = np.zeros_like(rows1[:, :3])
+        for rank in range(world):
+            idx = runner.shard_chunk(len(ds), rank, world)
+            for mode_batch in (1, 4):
+                r = runner.PairRunner(prm, device=DEV, batch=mode_batch, dense_descriptors=True)
+                rows = np.asarray(r._run_sequence(ds, idx), np.float32)
+                got[idx] = rows
+                assert np.array_equal(rows.view(np.uint32), rows1[idx, :3].view(np.uint32)), (world, rank, mode_batch)
+        assert np.array_equal(got, rows1[:, :3])
