@@ -187,6 +187,26 @@ int kpb_epipolar_error(kpb_ctx* ctx, const float* kps0_dev, int cols0, const flo
                        int max_k, const int32_t* k_dev, const float* fmat_dev, int W, int H, int mode1, float th,
                        float* out_err_dev, float* out_stats_dev);
 
+/* ---- 8(f)3: robust homography, cv2.findHomography(pts0, pts1, cv2.RANSAC) as called at tasks/MHA.py:45-47 ----------
+ * PARITY UNPINNED: OpenCV is a third-party dependency absent from the reference tree and this image, and its RANSAC
+ * draws from its own RNG.  The kernel restates OpenCV's published algorithm with its default parameters (see
+ * csrc/geometry.hip, oracle/geometry_ref.py) and is validated against analytic ground truth.
+ * m0_dev [batch][max_k][cols0], m1_dev [batch][max_k][cols1]: the matched rows of image 0 / image 1, normalised (x, y, ..);
+ * k_dev [batch] valid rows or NULL; scale_dev [batch][4] = (sx0, sy0, sx1, sy1): pixels = normalised * scale, in fp32 as
+ * MHA.py:41-42 (both sides (w-1, h-1) of warp01 there).  seed_dev [batch] per-pair sampler seeds, or NULL (= seed).
+ * out_h_dev [batch][9] float64 row-major, H[2][2] = 1 (zeros when nothing was found); out_mask_dev [batch][max_k] uint8
+ * inliers of the best sample model (as cv2 returns them); out_info_dev [batch][4] = (found 0/1, inliers, hypotheses
+ * evaluated, 0).  Fewer than 4 matches: found = 0 (cv2 raises there; tasks/MHA.py has no guard). */
+typedef struct kpb_ransac_params {
+    double threshold;       /* ransacReprojThreshold, pixels: 3.0 */
+    double confidence;      /* 0.995 */
+    int32_t max_iters;      /* 2000 */
+    int32_t refine;         /* 1: least-squares refit + Levenberg-Marquardt on the inliers, as cv2 does */
+} kpb_ransac_params;
+int kpb_find_homography(kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k,
+                        const int32_t* k_dev, const float* scale_dev, const uint32_t* seed_dev, uint32_t seed,
+                        const kpb_ransac_params* params, double* out_h_dev, uint8_t* out_mask_dev, int32_t* out_info_dev);
+
 /* ---- 8(f)2: per-image input transform after decoding, datasets/hpatches.py:47-69 --------------------
  * src_dev [batch][Hs][Ws][3] uint8 as decoded (BGR from cv2.imread with swap_rb = 1, RGB with 0);
  * out_dev [batch][3][Hd][Wd] fp32 = cv2.resize(src / 255, (Wd, Hd)) (INTER_LINEAR), channels first.

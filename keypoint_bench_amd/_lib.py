@@ -24,6 +24,10 @@ class LkParams(ctypes.Structure):           # kpb_lk_params
     _fields_ = [("distance", ctypes.c_float), ("win_size", ctypes.c_int32), ("levels", ctypes.c_int32), ("iterations", ctypes.c_int32)]
 
 
+class RansacParams(ctypes.Structure):       # kpb_ransac_params
+    _fields_ = [("threshold", ctypes.c_double), ("confidence", ctypes.c_double), ("max_iters", ctypes.c_int32), ("refine", ctypes.c_int32)]
+
+
 class MatchParams(ctypes.Structure):
     _fields_ = [("max_distance", c_double), ("cross_check", ctypes.c_int32)]
 
@@ -58,6 +62,8 @@ SIGNATURES = {
                              c_void_p, c_void_p, c_void_p]),
     "kpb_epipolar_error": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_float, c_void_p, c_void_p]),
+    "kpb_find_homography": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_uint32,
+                                    ctypes.POINTER(RansacParams), c_void_p, c_void_p, c_void_p]),
     "kpb_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "kpb_net_create": (c_int, [c_void_p, c_int, c_void_p, c_size_t, ctypes.POINTER(c_void_p)]),
     "kpb_net_destroy": (None, [c_void_p]),

@@ -196,13 +196,6 @@ def mha_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, param
     return [float(v) for v in mha(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params)]
 
 
-def auc_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
-    """model_interface.py:254-259: [max(err_t, err_R), inliers] (tasks/AUC.py:151-154)."""
-    from .tasks.AUC import auc
-    r = auc(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params)
-    return [float(r["AUC"]), float(r["inliers"])]
-
-
 def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
     from .utils.extracter import detection
     from .utils.matcher import brute_force_matcher
@@ -212,17 +205,17 @@ def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, p
     return [k0.shape[0], k1.shape[0], m0.shape[0]]
 
 
-TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "AUC": auc_row, "match_stats": match_stats}
+TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "match_stats": match_stats}
 
 
 # ---- the same tasks over a whole PairPipeline batch (rows equal to the single-pair functions above)
-def _batched_match_stats(pipe, items, params):
+def _batched_match_stats(pipe, items, params, indices=None):
     B = pipe.B
     n, k = pipe.n.tolist(), pipe.k.tolist()
     return [[n[b], n[B + b], k[b]] for b in range(len(items))]
 
 
-def _batched_repeatability(pipe, items, params):
+def _batched_repeatability(pipe, items, params, indices=None):
     from .tasks.repeatability import repeatability_batch
     B, f = pipe.B, len(items)
     pad = lambda ws: ws + [ws[-1]] * (B - f)
@@ -231,14 +224,9 @@ def _batched_repeatability(pipe, items, params):
     return rows[:f]
 
 
-def _batched_mha(pipe, items, params):
+def _batched_mha(pipe, items, params, indices=None):
     from .tasks.MHA import mha_batch
-    return mha_batch(pipe, items, params)
-
-
-def _batched_auc(pipe, items, params):
-    from .tasks.AUC import auc_batch
-    return auc_batch(pipe, items, params)
+    return mha_batch(pipe, items, params, indices)
 
 
 def _covis_tables(items, B, dev):
@@ -252,7 +240,7 @@ def _covis_tables(items, B, dev):
 
 # task -> (rows function, pipeline needs the match stage, keypoints are covisibility-filtered before matching)
 BATCHED_TASKS = {"match_stats": (_batched_match_stats, True, False), "repeatability": (_batched_repeatability, False, False),
-                 "MHA": (_batched_mha, True, True), "AUC": (_batched_auc, True, False)}
+                 "MHA": (_batched_mha, True, True)}
 
 
 def _homo_only(item):
@@ -349,7 +337,7 @@ class PairRunner:
             images[B + j].copy_(images[B + f - 1])
         items = [g[1] for g in group]
         pipe.run(images, _covis_tables(items, B, self.device) if covis else None)
-        rows = fn(pipe, items, self.params)
+        rows = fn(pipe, items, self.params, [g[0] for g in group])
         self.batched_pairs += f
         return rows
 

@@ -1,0 +1,102 @@
+"""csrc/geometry.hip RANSAC homography (PARITY UNPINNED against cv2: see utils/mvg.py) against the numpy restatement --
+same sampler, so the same hypotheses: inlier count and hypothesis count must agree exactly, H to rounding -- against
+analytic ground truth, and the MHA task against fixtures the reference's own tasks/MHA.py produced."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import geometry_ref as g
+from test_oracle_geometry import mha_params, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_batched_ransac_equals_oracle_and_ground_truth():
+    from keypoint_bench_amd.utils.mvg import find_homography
+    cases = [(700, 0.7, 0.5), (300, 0.4, 1.0), (50, 0.5, 0.2), (1000, 0.9, 0.0), (5, 1.0, 0.0), (4, 1.0, 0.0), (3, 1.0, 0.0), (200, 0.15, 0.5),
+             (997, 0.6, 0.3)]
+    K = 1000
+    B = len(cases)
+    m0 = np.zeros((B, K, 3), np.float32)
+    m1 = np.zeros((B, K, 2), np.float32)
+    kk = np.zeros(B, np.int32)
+    gt = []
+    scale = np.array([639, 479, 639, 479], np.float32)
+    for b, (n, share, noise) in enumerate(cases):
+        src, dst, H, inl = synth(n, share, noise, 100 + b)
+        m0[b, :n, :2] = (src / scale[:2]).astype(np.float32)
+        m1[b, :n] = (dst / scale[2:]).astype(np.float32)
+        kk[b] = n
+        gt.append((H, inl))
+    seeds = np.arange(B) * 7919 + 5
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    H, mask, info = find_homography(t(m0), t(m1), scale, k_dev=t(kk), seeds=seeds)
+    H, mask, info = H.cpu().numpy(), mask.cpu().numpy(), info.cpu().numpy()
+    for b, (n, share, noise) in enumerate(cases):
+        p0 = (m0[b, :n, :2] * scale[:2]).astype(np.float64)          # the fp32 pixel products the kernel forms
+        p1 = (m1[b, :n] * scale[2:]).astype(np.float64)
+        He, me, ie = g.find_homography_ransac(p0, p1, seed=int(seeds[b]))
+        if He is None:
+            assert info[b, 0] == 0 and n < 4
+            continue
+        assert info[b, 0] == 1 and info[b, 1] == ie["inliers"] and info[b, 2] == ie["iters"], (b, info[b], ie)
+        assert np.array_equal(mask[b, :n], me) and mask[b, n:].sum() == 0
+        np.testing.assert_allclose(H[b], He, rtol=0, atol=2e-7 * np.abs(He).max(), err_msg=str(b))
+        if share >= 0.4:
+            assert g.mha_corner_error(H[b], gt[b][0], 480, 640, 480, 640) < max(3 * noise, 1e-3)
+
+
+def test_single_call_equals_row_of_batched_call():
+    from keypoint_bench_amd.utils.mvg import find_homography
+    src, dst, _, _ = synth(400, 0.6, 0.4, 9)
+    sc = np.array([639, 479, 639, 479], np.float32)
+    a = torch.from_numpy((src / sc[:2]).astype(np.float32)).to(DEV)
+    b = torch.from_numpy((dst / sc[2:]).astype(np.float32)).to(DEV)
+    H1, m1, i1 = find_homography(a, b, sc, seed=42)
+    H3, m3, i3 = find_homography(torch.stack([b, a, a]), torch.stack([a, b, b]), sc, seeds=[1, 42, 43])
+    assert torch.equal(H1[0], H3[1]) and torch.equal(m1[0], m3[1]) and torch.equal(i1[0], i3[1])
+    assert not torch.equal(H3[1], H3[2])          # another seed, other samples: the refined model differs in the last digits
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_mha_task_against_reference_fixture(case):
+    """Same inputs as the reference's mha saw; the estimator inside is this library's (seed = pair index on both sides)."""
+    from keypoint_bench_amd.tasks.MHA import mha
+    f = load_golden("mha.npz")
+    p = "c%d_" % case
+    prm = mha_params(f[p + "prm"], f["th"])
+    h, w = (int(v) for v in f[p + "hw"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    real_H = f[p + "real_H"]
+    w01 = {"mode": "homo", "width": torch.tensor(w), "height": torch.tensor(h), "homography_matrix": t(real_H)}
+    w10 = {"mode": "homo", "width": torch.tensor(w), "height": torch.tensor(h),
+           "homography_matrix": t(np.linalg.inv(real_H.astype(np.float64)).astype(np.float32))}
+    Hs, Ws = f[p + "score0"].shape
+    img = torch.zeros((1, 3, Hs, Ws), device=DEV)
+    res = mha(case, img, t(f[p + "score0"])[None, None], t(f[p + "desc0"]), img, t(f[p + "score1"])[None, None], t(f[p + "desc1"]), w01, w10, prm)
+    assert res == f[p + "flags"].tolist()
+
+
+def test_runner_mha_batched_equals_single_pair_rows():
+    from keypoint_bench_amd import runner, synthetic
+    EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=300, min_score=0.0)
+    prm = {"model_type": "Alike", "task_type": "MHA", "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64), "extractor_params": EP,
+           "matcher_params": {"type": "brute_force", "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
+           "MHA_params": {"th": [0.5, 1, 3, 5, 7]}}
+    ds = []
+    for i in range(7):
+        v0, v1 = synthetic.image_pair(700 + i, 96, 128)       # view1 = the canvas 3 px right / 2 px down of view0
+        hm = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
+        ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
+                   "warp01_params": dict(mode="homo", homography_matrix=hm, width=np.int64(128), height=np.int64(96)),
+                   "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(hm).astype(np.float32), width=128, height=96)})
+    single = runner.PairRunner(prm, device=DEV, batch=1)
+    agg1, rows1 = single.run(ds)
+    batched = runner.PairRunner(prm, device=DEV, batch=4)
+    aggb, rowsb = batched.run(ds)
+    assert single.batched_pairs == 0 and batched.batched_pairs == 7
+    assert np.array_equal(rows1, rowsb)
+    assert rows1[:, 2].mean() > 0.8, rows1            # a translation pair: the homography is found to well under 3 px
+    assert aggb["MHA"] == agg1["MHA"] and len(aggb["MHA"]) == 5
