@@ -150,6 +150,18 @@ def superpoint_costs(B2):
     return c
 
 
+def workload_label(model, matcher):
+    """Names the workload and the BASELINE.json config it belongs to (configs[1] is the headline; the others are run with
+    --model / --matcher and seeded stand-in weights)."""
+    net = {"alike": "ALIKE-t", "superpoint": "SuperPoint", "xfeat": "XFeat", "disk": "DISK"}[model]
+    cfg = {("alike", "brute_force"): "BASELINE configs[1]", ("superpoint", "brute_force"): "BASELINE configs[2] extract+match stage",
+           ("xfeat", "brute_force"): "BASELINE configs[3] extract+match stage", ("disk", "lightglue"): "BASELINE configs[4] extract+match stage"}
+    tag = cfg.get((model, matcher), "not a BASELINE config")
+    m = ("brute-force mutual match (euclidean fp64, max_distance=5, cross_check)" if matcher == "brute_force"
+         else "LightGlue attention matcher (fp32 MFMA, 9 layers, early stop + pruning)")
+    return "%s extract + NMS(nms_dist=6, border=8, top_k=1000) + %s, 640x480 pairs [%s]" % (net, m, tag)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,13 +170,30 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=None, help="pairs per GPU per step (default: 256 ALIKE and XFeat [SURVEY 8d], 16 SuperPoint and DISK)")
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic pairs generated (cycled to fill a batch)")
+    ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic pairs generated (default: one per pair of the batch; fewer are cycled)")
     ap.add_argument("--matcher", default="brute_force", choices=["brute_force", "lightglue"],
                     help="lightglue = BASELINE configs[4] (with --model disk or superpoint), seeded stand-in weights")
     ap.add_argument("--model", default="alike", choices=["alike", "superpoint", "xfeat", "disk"],
                     help="alike = BASELINE configs[1] (the headline); superpoint = configs[2] with seeded random weights")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks as a CHILD torchrun (nothing in this process has touched the
+        # GPU yet -- a process that has must never be replaced by another program on this pool) and relay its JSON line
+        import socket
+        import subprocess
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            print(lines[-1])
+        raise SystemExit(proc.returncode if proc.returncode else (0 if lines else 1))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -225,8 +254,10 @@ def main():
         lg.load_state_dict(kw.random_lightglue_state_dict(31, dim, "plain"))
     pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev, lightglue=lg)
     # synthetic pairs, different per rank, resident in HBM
-    nd = min(args.distinct, B)
-    v0s, v1s = zip(*[synthetic.image_pair(rank * 1000 + i, H, W) for i in range(nd)])
+    nd = min(args.distinct or B, B)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max(1, min(len(os.sched_getaffinity(0)), 16))) as ex:     # numpy releases the GIL: ~0.1 s per pair per thread
+        v0s, v1s = zip(*ex.map(lambda i: synthetic.image_pair(rank * 1000 + i, H, W), range(nd)))
     sel = [i % nd for i in range(B)]
     images = torch.from_numpy(np.stack([v0s[i] for i in sel] + [v1s[i] for i in sel])).to(dev).contiguous()
 
@@ -322,8 +353,7 @@ def main():
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"alike": "ALIKE-t", "superpoint": "SuperPoint", "xfeat": "XFeat", "disk": "DISK"}[args.model] + " extract + NMS(nms_dist=6, border=8, top_k=1000) + brute-force mutual match "
-                                   "(euclidean fp64, max_distance=5, cross_check), 640x480 pairs [BASELINE configs[1]]",
+            "config": {"workload": workload_label(args.model, args.matcher),
                        "matcher": args.matcher, "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns},

@@ -451,6 +451,17 @@ __device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, in
 // from the registers that built the features, and step s of the K loop consumes channel 16*(s/8) + 8h + (s%8) from A
 // and B alike (the MFMA does not care which k a lane calls its own, as long as A and B agree).  In the tap steps the
 // lane supplies the weight of pixel p for source column 2s + h.
+// MAP: which image rows the four waves of a workgroup own.
+//   0  four consecutive 128-pixel segments in raster order (r01): vertically adjacent rows sit in different workgroups,
+//      hence on different XCDs, and every a2 row is fetched once per output row that taps it (2.6x read amplification);
+//   1  the SAME 128-pixel column band of four consecutive rows: the <= 3 a2 rows and the 2 E3 / E4 rows those four
+//      output rows tap are fetched once per workgroup (they meet in the CU's L1 / the XCD's L2);
+//   2  as 1, and the workgroups of one XCD (blockIdx.x % 8) walk DOWN a column band, so the a2 row two vertically
+//      adjacent workgroups share is an L2 hit as well.  Needs gridDim.x % 8 == 0 (the host falls back to 1 otherwise).
+// ST4: operands swapped (A = head weights, B = features) so that D = [out channel][pixel]: a lane then holds four
+//      CONSECUTIVE channels of its pixel per accumulator quad and stores them as one 16-byte piece (8 store instructions
+//      per tile instead of 32).
+template <int MAP, bool ST4>
 __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
 {
     __shared__ __attribute__((aligned(16))) float Bl[16 * 2 * 64];   // [s][h][out]: head weight of chan(s,h), s < 16
@@ -476,9 +487,21 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
     const float sy8 = (float)(H8 - 1) / (float)(a.H - 1), sx8 = (float)(W8 - 1) / (float)(a.W - 1);
     const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
     const int tiles_per_row = a.W / 32, segs_per_row = (tiles_per_row + SEG_TILES - 1) / SEG_TILES;
-    const int seg = blockIdx.x * 4 + wv;
-    const bool live = seg < a.H * segs_per_row;
-    const int y = live ? seg / segs_per_row : 0, xs = live ? (seg - y * segs_per_row) * (32 * SEG_TILES) : 0;
+    int y, xs;
+    bool live;
+    if (MAP == 0) {
+        const int seg = blockIdx.x * 4 + wv;
+        live = seg < a.H * segs_per_row;
+        y = live ? seg / segs_per_row : 0; xs = live ? (seg - y * segs_per_row) * (32 * SEG_TILES) : 0;
+    } else {
+        const int groups = (a.H + 3) / 4;                       // row groups of four
+        int w = blockIdx.x;
+        if (MAP == 2) { const int per = gridDim.x / 8; w = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
+        const int band = MAP == 2 ? w / groups : w % segs_per_row, grp = MAP == 2 ? w - band * groups : w / segs_per_row;
+        y = 4 * grp + wv; xs = band * (32 * SEG_TILES);
+        live = y < a.H;
+        if (!live) { y = 0; xs = 0; }
+    }
     const int ntile = live ? min(SEG_TILES, tiles_per_row - xs / 32) : 0;
     // a 128-pixel segment spans < 16 source columns of the up8 map and < 4 of the up32 map (scale < 1/8, 1/32), a tile
     // starts at most 12 (3) columns into the strip and uses 6 (4) rows from there: NT3 = 12 + 6, NT4 = 3 + 4
@@ -532,36 +555,54 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
 
         f32x16 acc0 = {0}, acc1 = {0};
+        // the product is symmetric in (lane's feature, lane's weight column): ST4 only swaps which one is called A
+#define HEAD_MFMA(fv, w0, w1)                                                                          \
+        if (ST4) { acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, fv, acc0, 0, 0, 0);                    \
+                   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, fv, acc1, 0, 0, 0); }                  \
+        else     { acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, w0, acc0, 0, 0, 0);                    \
+                   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, w1, acc1, 0, 0, 0); }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float b0 = Blz[(s * 2 + h) * 64 + p], b1 = Blz[(s * 2 + h) * 64 + 32 + p];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f[s], b1, acc1, 0, 0, 0);
+            HEAD_MFMA(f[s], b0, b1)
         }
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             const int k = 2 * s + h;
             const float w = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f);
             const float b0 = v3[k * ESTRIDE + p], b1 = v3[k * ESTRIDE + 32 + p];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
+            HEAD_MFMA(w, b0, b1)
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int k = 2 * s + h;
             const float w = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f);
             const float b0 = v4[k * ESTRIDE + p], b1 = v4[k * ESTRIDE + 32 + p];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
+            HEAD_MFMA(w, b0, b1)
         }
-        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  40 GB per launch
-        // that nothing re-reads before they have left every cache: streaming stores keep the L2 for a2 and the strips
+#undef HEAD_MFMA
+        // 40 GB per launch that nothing re-reads before they have left every cache: streaming stores keep the L2 for a2
+        // and the strips
         float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
+        if (ST4) {
+            // D[row = out channel][col = pixel]: lane (p, h) holds, of pixel p, channels 8g + 4h + (0..3) in registers 4g..4g+3
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            f4* dp = reinterpret_cast<f4*>(d + (size_t)p * 64 + 4 * h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
-            __builtin_nontemporal_store(acc0[r], d + (size_t)rowp * 64 + p);
-            __builtin_nontemporal_store(acc1[r], d + (size_t)rowp * 64 + 32 + p);
+            for (int g = 0; g < 4; ++g) {
+                f4 v0 = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
+                f4 v1 = {acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
+                __builtin_nontemporal_store(v0, dp + 2 * g);
+                __builtin_nontemporal_store(v1, dp + 8 + 2 * g);
+            }
+        } else {
+            // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
+                __builtin_nontemporal_store(acc0[r], d + (size_t)rowp * 64 + p);
+                __builtin_nontemporal_store(acc1[r], d + (size_t)rowp * 64 + 32 + p);
+            }
         }
     }
 }
@@ -785,8 +826,18 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     // upsample + concat + head (151-162)
     if (desc_out_dev) {
         HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W};
-        const int segs = H * cdiv(W / 32, SEG_TILES);
-        KPB_LAUNCH(ctx, "alike_head_dense", alike_head_hyb, dim3(cdiv(segs, 4), batch), dim3(256), 0, st, hy);
+        const int segs_per_row = cdiv(W / 32, SEG_TILES);
+        const int segs = H * segs_per_row, work4 = cdiv(H, 4) * segs_per_row;
+        static const int map_env = kpb_env_int("KPB_HEAD_MAP", 2), st4 = kpb_env_int("KPB_HEAD_ST4", 0);
+        int map = map_env;
+        if (map == 2 && work4 % 8 != 0) map = 1;
+        const dim3 grid(map == 0 ? cdiv(segs, 4) : work4, batch);
+        if (map == 0 && !st4) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<0, false>), grid, dim3(256), 0, st, hy);
+        else if (map == 0) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<0, true>), grid, dim3(256), 0, st, hy);
+        else if (map == 1 && !st4) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<1, false>), grid, dim3(256), 0, st, hy);
+        else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<1, true>), grid, dim3(256), 0, st, hy);
+        else if (!st4) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<2, false>), grid, dim3(256), 0, st, hy);
+        else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<2, true>), grid, dim3(256), 0, st, hy);
     } else {
         LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W};
         KPB_LAUNCH(ctx, "alike_head_score", alike_score_lin, dim3(cdiv(H * W, 256), batch), dim3(256), 0, st, la);

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <string>
@@ -85,6 +86,13 @@ inline int kpb_reserve(kpb_ctx* ctx, kpb_buf& b, size_t bytes)
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// integer tuning knob from the environment (experiments only; the defaults are the measured choices)
+static inline int kpb_env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 
 // Brackets one kernel launch with two events on the context's stream when profiling is enabled.
 struct ProfScope {

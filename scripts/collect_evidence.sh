@@ -11,6 +11,9 @@ bash scripts/prof_pmc.sh ${R}_dense > gpurun_out/$R/pmc_dense.txt 2>&1 || exit 1
 bash scripts/prof_pmc.sh ${R}_sparse --sparse > gpurun_out/$R/pmc_sparse.txt 2>&1 || exit 1
 cp gpurun_out/pmc_${R}_dense/traffic.json profiles/pmc_traffic_b256_dense.json
 cp gpurun_out/pmc_${R}_sparse/traffic.json profiles/pmc_traffic_b256_sparse.json
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python bench.py > gpurun_out/$R/bench_default.json 2> gpurun_out/$R/bench_default.err || exit 1
-python bench.py --sparse --no-cpu-baseline > gpurun_out/$R/bench_sparse.json 2> /dev/null || exit 1
+# the profiled pass never starts the CPU-baseline worker pool (child processes of a profiled parent are fragile on this
+# pool): kernel stats come from the --no-cpu-baseline run under rocprofv3, the bench line with cpu_baseline from a plain run
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -- python3 bench.py --no-cpu-baseline > gpurun_out/$R/bench_profiled.json 2> gpurun_out/$R/bench_profiled.err || exit 1
+python3 bench.py > gpurun_out/$R/bench_default.json 2> gpurun_out/$R/bench_default.err || exit 1
+python3 bench.py --sparse --no-cpu-baseline > gpurun_out/$R/bench_sparse.json 2> /dev/null || exit 1
 cat gpurun_out/$R/bench_default.json

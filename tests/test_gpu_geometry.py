@@ -57,7 +57,8 @@ def test_single_call_equals_row_of_batched_call():
     H1, m1, i1 = find_homography(a, b, sc, seed=42)
     H3, m3, i3 = find_homography(torch.stack([b, a, a]), torch.stack([a, b, b]), sc, seeds=[1, 42, 43])
     assert torch.equal(H1[0], H3[1]) and torch.equal(m1[0], m3[1]) and torch.equal(i1[0], i3[1])
-    assert not torch.equal(H3[1], H3[2])          # another seed, other samples: the refined model differs in the last digits
+    # another seed draws other samples, but on this easy pair both reach the same inlier set, hence the same refit
+    assert torch.equal(m3[1], m3[2]) and torch.allclose(H3[1], H3[2], rtol=0, atol=1e-9)
 
 
 @pytest.mark.parametrize("case", range(4))
