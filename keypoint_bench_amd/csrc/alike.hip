@@ -401,6 +401,38 @@ __device__ __forceinline__ void up8ch(const float* m, int Hs, int Ws, float sy, 
     }
 }
 
+// the same in two phases: issue the eight 16-byte tap loads, interpolate later (lets the caller put other memory
+// operations behind the loads in program order)
+struct Up8Taps { float4 t[8]; float ly, lx; };
+__device__ __forceinline__ void up8ch_load(const float* m, int Hs, int Ws, float sy, float sx, int y, int x, int c0, Up8Taps& u)
+{
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    u.ly = fy - (float)y0; u.lx = fx - (float)x0;
+    const float* p00 = m + ((size_t)y0 * Ws + x0) * 16 + c0;
+    const float* p01 = m + ((size_t)y0 * Ws + x1) * 16 + c0;
+    const float* p10 = m + ((size_t)y1 * Ws + x0) * 16 + c0;
+    const float* p11 = m + ((size_t)y1 * Ws + x1) * 16 + c0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u.t[4 * q + 0] = *reinterpret_cast<const float4*>(p00 + 4 * q); u.t[4 * q + 1] = *reinterpret_cast<const float4*>(p01 + 4 * q);
+        u.t[4 * q + 2] = *reinterpret_cast<const float4*>(p10 + 4 * q); u.t[4 * q + 3] = *reinterpret_cast<const float4*>(p11 + 4 * q);
+    }
+}
+__device__ __forceinline__ void up8ch_lerp(const Up8Taps& u, float* f)
+{
+    const float ly = u.ly, lx = u.lx, hy = 1.0f - ly, hx = 1.0f - lx;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float4 a = u.t[4 * q], b = u.t[4 * q + 1], c = u.t[4 * q + 2], d = u.t[4 * q + 3];
+        f[4 * q + 0] = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+        f[4 * q + 1] = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+        f[4 * q + 2] = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+        f[4 * q + 3] = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ head, hybrid form
 // convhead2 has no bias and bilinear upsampling is linear, so  W.up(a_g) = up(W.a_g)  (ALike.py:151-159).  For the two
 // coarse groups that is a large saving: E3 = W3.a3 and E4 = W4.a4 are projected once at 1/64 and 1/1024 of the pixels
@@ -458,10 +490,9 @@ __device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, in
 //      output rows tap are fetched once per workgroup (they meet in the CU's L1 / the XCD's L2);
 //   2  as 1, and the workgroups of one XCD (blockIdx.x % 8) walk DOWN a column band, so the a2 row two vertically
 //      adjacent workgroups share is an L2 hit as well.  Needs gridDim.x % 8 == 0 (the host falls back to 1 otherwise).
-// ST4: operands swapped (A = head weights, B = features) so that D = [out channel][pixel]: a lane then holds four
-//      CONSECUTIVE channels of its pixel per accumulator quad and stores them as one 16-byte piece (8 store instructions
-//      per tile instead of 32).
-template <int MAP, bool ST4>
+// (Measured and rejected, r02: swapping the MFMA operands so that a lane holds four consecutive channels of its pixel and
+// stores 16-byte pieces -- 8 store instructions per tile instead of 32, but each touching 32 lines partially: 32.7 ms.)
+template <int MAP>
 __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
 {
     __shared__ __attribute__((aligned(16))) float Bl[16 * 2 * 64];   // [s][h][out]: head weight of chan(s,h), s < 16
@@ -555,12 +586,9 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
 
         f32x16 acc0 = {0}, acc1 = {0};
-        // the product is symmetric in (lane's feature, lane's weight column): ST4 only swaps which one is called A
-#define HEAD_MFMA(fv, w0, w1)                                                                          \
-        if (ST4) { acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, fv, acc0, 0, 0, 0);                    \
-                   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, fv, acc1, 0, 0, 0); }                  \
-        else     { acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, w0, acc0, 0, 0, 0);                    \
-                   acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, w1, acc1, 0, 0, 0); }
+#define HEAD_MFMA(fv, w0, w1)                                                       \
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, w0, acc0, 0, 0, 0);            \
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fv, w1, acc1, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const float b0 = Blz[(s * 2 + h) * 64 + p], b1 = Blz[(s * 2 + h) * 64 + 32 + p];
@@ -584,26 +612,253 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
         // 40 GB per launch that nothing re-reads before they have left every cache: streaming stores keep the L2 for a2
         // and the strips
         float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
-        if (ST4) {
-            // D[row = out channel][col = pixel]: lane (p, h) holds, of pixel p, channels 8g + 4h + (0..3) in registers 4g..4g+3
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            f4* dp = reinterpret_cast<f4*>(d + (size_t)p * 64 + 4 * h);
+        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f4 v0 = {acc0[4 * g], acc0[4 * g + 1], acc0[4 * g + 2], acc0[4 * g + 3]};
-                f4 v1 = {acc1[4 * g], acc1[4 * g + 1], acc1[4 * g + 2], acc1[4 * g + 3]};
-                __builtin_nontemporal_store(v0, dp + 2 * g);
-                __builtin_nontemporal_store(v1, dp + 8 + 2 * g);
+        for (int r = 0; r < 16; ++r) {
+            const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
+            __builtin_nontemporal_store(acc0[r], d + (size_t)rowp * 64 + p);
+            __builtin_nontemporal_store(acc1[r], d + (size_t)rowp * 64 + 32 + p);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head, split-f16 form
+// fp32 MFMA on gfx950 runs at the fp32 VECTOR rate and (measured, r02: the kernel takes 10.9 ms with its stores removed)
+// shares the datapath with the VALU work that builds its operands, so the 32-deep fine-group product was the largest
+// single cost of the head.  Here it runs on v_mfma_f32_32x32x16_f16 (16x the fp32 rate per K) with every fp32 operand
+// split into two halves-precision terms, x = hi + lo with hi = f16(x) (round toward zero) and lo = f16(x - hi):
+//     a b  =  a_hi b_hi + a_hi b_lo + a_lo b_hi  (+ a_lo b_lo, dropped: <= 2^-22 |a b|)
+// Three MFMAs per 16-deep block accumulate in fp32; the dropped term and the rounding of the lo parts are at the level of
+// fp32's own rounding (relative 2^-22 per product against 2^-24), far inside the 1e-4 descriptor contract, and the result
+// does not depend on a reduced-precision mode: x - hi is exact in fp32.  The coarse groups' ten tap steps stay on the
+// fp32 MFMA (their B operand is the y-interpolated strip, rebuilt per row; K = 10).
+// Per 32-pixel tile: 12 f16 MFMAs (32 cycles) + 10 fp32 MFMAs (64 cycles) = 1024 matrix cycles instead of 2688.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const h2v a = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(f[2 * i], f[2 * i + 1]));
+        const float r0 = f[2 * i] - (float)a[0], r1 = f[2 * i + 1] - (float)a[1];       // exact
+        const h2v b = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+        hi[2 * i] = a[0]; hi[2 * i + 1] = a[1]; lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];
+    }
+}
+
+template <int MAP, bool PIPE>
+__global__ __launch_bounds__(256) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
+{
+    __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];         // [hi/lo][(kb, nh, h, n)]: one 16-byte fragment per lane and MFMA
+    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j
+    __shared__ __attribute__((aligned(16))) float Ws[2 * 16];         // [h][s]:       score weight of chan(s,h)
+    __shared__ __attribute__((aligned(16))) float V3[4][NT3 * ESTRIDE];
+    __shared__ __attribute__((aligned(16))) float V4[4][NT4 * ESTRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    Bh[0][tid] = wh16[tid];
+    Bh[1][tid] = wh16[256 + tid];
+    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j]; }
+    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)]; }
+
+    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
+    const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
+    const float* E3 = a.E3 + (size_t)b * H8 * W8 * ESTRIDE;
+    const float* E4 = a.E4 + (size_t)b * H32 * W32 * ESTRIDE;
+    const float sy2 = (float)(H2 - 1) / (float)(a.H - 1), sx2 = (float)(W2 - 1) / (float)(a.W - 1);
+    const float sy8 = (float)(H8 - 1) / (float)(a.H - 1), sx8 = (float)(W8 - 1) / (float)(a.W - 1);
+    const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
+    const int tiles_per_row = a.W / 32, segs_per_row = (tiles_per_row + SEG_TILES - 1) / SEG_TILES;
+    int y, xs;
+    bool live;
+    {   // workgroup -> four consecutive rows of one 128-pixel column band (see alike_head_hyb, MAP 1 / 2)
+        const int groups = (a.H + 3) / 4;
+        int w = blockIdx.x;
+        if (MAP == 2) { const int per = gridDim.x / 8; w = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
+        const int band = MAP == 2 ? w / groups : w % segs_per_row, grp = MAP == 2 ? w - band * groups : w / segs_per_row;
+        y = 4 * grp + wv; xs = band * (32 * SEG_TILES);
+        live = y < a.H;
+        if (!live) { y = 0; xs = 0; }
+    }
+    const int ntile = live ? min(SEG_TILES, tiles_per_row - xs / 32) : 0;
+    const int tb3 = (int)(sx8 * (float)xs), tb4 = (int)(sx32 * (float)xs);
+    if (live) {
+        // Touch every 128-byte line the segment's four tiles will read (x1: 32 lines; a2: two rows of <= 34) with one
+        // dword per lane, before anything else: the lines are in flight while the strips are built and tile 0 computes,
+        // and the per-tile loads of tiles 1..3 find them in L2 instead of paying an HBM round trip each (the waves of a
+        // SIMD were all parked on s_waitcnt two thirds of the time).  The values are discarded.
+        const int npx = 32 * ntile;
+        const float* x1row = a.x1 + ((size_t)b * a.H * a.W + (size_t)y * a.W + xs) * 8;
+        const int fy0 = (int)(sy2 * (float)y), c0 = (int)(sx2 * (float)xs);
+        const int ncol = min(W2 - c0, npx / 2 + 2);
+        const int lines_a2 = (ncol * 16 + 31) / 32;
+        float dummy = 0.f;
+        if (lane < npx / 4) dummy += __builtin_nontemporal_load(x1row + lane * 32);
+        const int r = lane >= 34 ? 1 : 0, li = lane - 34 * r;
+        const int yy = min(fy0 + r, H2 - 1);
+        if (lane < 68 && li < lines_a2) dummy += a2[((size_t)yy * W2 + c0) * 16 + li * 32];
+        if (lane + 64 < 68 && lane + 64 - 34 < lines_a2) dummy += a2[((size_t)min(fy0 + 1, H2 - 1) * W2 + c0) * 16 + (lane + 64 - 34) * 32];
+        asm volatile("" :: "v"(dummy));
+    }
+    if (live) {
+        build_strip<NT3>(V3[wv], E3, H8, W8, sy8, y, tb3, lane);
+        build_strip<NT4>(V4[wv], E4, H32, W32, sy32, y, tb4, lane);
+    }
+    __syncthreads();
+
+    f32x16 pend = {0};                  // PIPE: channels 32..63 of the previous tile, stored under the next tile's feature arithmetic
+    float* pend_d = nullptr;
+    bool have = false;
+    for (int t = 0; t < ntile; ++t) {
+        const int x0 = xs + 32 * t, x = x0 + p;
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+        // this tile's ten 16-byte loads go out FIRST; the second half of the previous tile is stored behind them (the
+        // vector-memory path of a CU is a queue: loads issued behind a store burst wait for its drain)
+        const float4 x1lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8), x1hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
+        Up8Taps taps;
+        up8ch_load(a2, H2, W2, sy2, sx2, y, x, 8 * h, taps);
+        if (PIPE && have) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
+        }
+        int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
+        asm volatile("" : "+v"(z));
+        const uint4* Bhz = &Bh[0][0] + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
+        float f[16];
+        {   // group 0: relu(agg1 . x1), outputs 8h..8h+7 (ALike.py:147)
+            const float v[8] = {x1lo.x, x1lo.y, x1lo.z, x1lo.w, x1hi.x, x1hi.y, x1hi.z, x1hi.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 w0 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8 + 4]);
+                f[0] = fmaf(v[c], w0.x, f[0]); f[1] = fmaf(v[c], w0.y, f[1]); f[2] = fmaf(v[c], w0.z, f[2]); f[3] = fmaf(v[c], w0.w, f[3]);
+                f[4] = fmaf(v[c], w1.x, f[4]); f[5] = fmaf(v[c], w1.y, f[5]); f[6] = fmaf(v[c], w1.z, f[6]); f[7] = fmaf(v[c], w1.w, f[7]);
             }
-        } else {
-            // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
+        }
+        up8ch_lerp(taps, f + 8);      // ALike.py:151
+
+        const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
+        const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;     // tile's first strip row
+        const int t3 = (int)fx3 - tb3 - rb3, t4 = (int)fx4 - tb4 - rb4;
+        const float lx3 = fx3 - (float)(int)fx3, lx4 = fx4 - (float)(int)fx4;
+        const float* v3 = V3[wv] + rb3 * ESTRIDE;
+        const float* v4 = V4[wv] + rb4 * ESTRIDE;
+
+        float sc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(&Wsz[h * 16 + 4 * q]);
+            sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
+        }
+        sc += __shfl_xor(sc, 32, 64);
+        sc += (1.0f - lx3) * v3[t3 * ESTRIDE + 64] + lx3 * v3[(t3 + 1) * ESTRIDE + 64];
+        sc += (1.0f - lx4) * v4[t4 * ESTRIDE + 64] + lx4 * v4[(t4 + 1) * ESTRIDE + 64];
+        if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
+
+        float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
+        f32x16 acc0 = {0}, acc1 = {0};
+        if (!PIPE) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {        // 16-deep block kb = fine group kb; lane (p, h) supplies channels 8h..8h+7 of it
+                h8v ahi, alo;
+                split8(f + 8 * kb, ahi, alo);
+                const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b1h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]);
+                const h8v b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]), b1l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b0h, acc0, 0, 0, 0);     // small terms first
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b1h, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b0l, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b1l, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b0h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b1h, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int k = 2 * s + h;
+                const float w = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f);
+                const float b0 = v3[k * ESTRIDE + p], b1 = v3[k * ESTRIDE + 32 + p];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int k = 2 * s + h;
+                const float w = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f);
+                const float b0 = v4[k * ESTRIDE + p], b1 = v4[k * ESTRIDE + 32 + p];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
+            }
+            // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  Streaming stores: 40 GB
+            // per launch that nothing re-reads before they have left every cache
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
                 __builtin_nontemporal_store(acc0[r], d + (size_t)rowp * 64 + p);
                 __builtin_nontemporal_store(acc1[r], d + (size_t)rowp * 64 + 32 + p);
             }
+        } else {
+            // Pipelined form: the 16 row stores of one half-tile are issued BETWEEN the matrix instructions of the other half
+            // (and the second half's between the NEXT tile's feature arithmetic), two per MFMA, instead of 32 in one burst
+            // at the end: a wave that meets a full store queue then stalls for one queue slot while its MFMAs run, not for
+            // the drain of a whole 8 KB burst with the SIMD's other waves doing the same.
+            h8v ahi[2], alo[2];
+            split8(f, ahi[0], alo[0]);
+            split8(f + 8, ahi[1], alo[1]);
+            float w3[3], w4[2];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) { const int k = 2 * s + h; w3[s] = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f); }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { const int k = 2 * s + h; w4[s] = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f); }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[kb], b0h, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0l, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0h, acc0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], v3[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], v4[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
+            // operands of the second half first, so that nothing but MFMAs and stores remains to be interleaved
+            h8v b1h[2], b1l[2];
+            float t3b[3], t4b[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { b1h[kb] = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]); b1l[kb] = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]); }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) t3b[s] = v3[(2 * s + h) * ESTRIDE + 32 + p];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) t4b[s] = v4[(2 * s + h) * ESTRIDE + 32 + p];
+            int r = 0;
+#define ST0_2() { const int ra = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r], d + (size_t)ra * 64 + p); ++r; \
+                  const int rb = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r], d + (size_t)rb * 64 + p); ++r; }
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], b1h[1], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1l[1], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1h[1], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[0], t3b[0], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[1], t3b[1], acc1, 0, 0, 0); ST0_2()
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[2], t3b[2], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], t4b[0], acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], t4b[1], acc1, 0, 0, 0);
+#undef ST0_2
+            // pin the interleaving (the scheduler otherwise gathers the stores into one burst behind the last MFMA)
+            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            pend = acc1; pend_d = d + 32 + p; have = true;
         }
+    }
+    if (PIPE && have) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
     }
 }
 
@@ -828,16 +1083,19 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W};
         const int segs_per_row = cdiv(W / 32, SEG_TILES);
         const int segs = H * segs_per_row, work4 = cdiv(H, 4) * segs_per_row;
-        static const int map_env = kpb_env_int("KPB_HEAD_MAP", 2), st4 = kpb_env_int("KPB_HEAD_ST4", 0);
+        // measured choices (r02, 512 images of 480x640): row-group mapping 1, split-f16 fine groups, interleaved stores
+        static const int map_env = kpb_env_int("KPB_HEAD_MAP", 1), f16 = kpb_env_int("KPB_HEAD_F16", 1), pipe = kpb_env_int("KPB_HEAD_PIPE", 1);
         int map = map_env;
         if (map == 2 && work4 % 8 != 0) map = 1;
-        const dim3 grid(map == 0 ? cdiv(segs, 4) : work4, batch);
-        if (map == 0 && !st4) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<0, false>), grid, dim3(256), 0, st, hy);
-        else if (map == 0) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<0, true>), grid, dim3(256), 0, st, hy);
-        else if (map == 1 && !st4) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<1, false>), grid, dim3(256), 0, st, hy);
-        else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<1, true>), grid, dim3(256), 0, st, hy);
-        else if (!st4) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<2, false>), grid, dim3(256), 0, st, hy);
-        else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<2, true>), grid, dim3(256), 0, st, hy);
+        if (f16 && map != 0) {
+            const uint4* wh16 = reinterpret_cast<const uint4*>(wp("head.wh16"));
+            if (map == 1 && !pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+            else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, true>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+            else if (!pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<2, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+            else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<2, true>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+        } else if (map == 0) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<0>), dim3(cdiv(segs, 4), batch), dim3(256), 0, st, hy);
+        else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<1>), dim3(work4, batch), dim3(256), 0, st, hy);
+        else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<2>), dim3(work4, batch), dim3(256), 0, st, hy);
     } else {
         LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W};
         KPB_LAUNCH(ctx, "alike_head_score", alike_score_lin, dim3(cdiv(H * W, 256), batch), dim3(256), 0, st, la);
@@ -909,6 +1167,23 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         const float* hw = bl.get("head.w", {dim + 1, dim});
         transpose(hw, 64, 64, tmp); ws.put("head.wT", tmp);
         ws.put_raw("head.ws", hw + 64 * 64, 64);
+        // split-f16 fragments of the fine-group rows (alike_head_f16): [hi/lo][kb][nh][h][n][j] halves,
+        // value = head.w[o = 32 nh + n][c = 16 kb + 8 h + j]; hi = f16(w) toward zero, lo = f16(w - hi)
+        std::vector<uint16_t> hl(2 * 2 * 2 * 2 * 32 * 8);
+        for (int kb = 0; kb < 2; ++kb) for (int nh = 0; nh < 2; ++nh) for (int hh = 0; hh < 2; ++hh) for (int n = 0; n < 32; ++n) for (int j = 0; j < 8; ++j) {
+            const float w = hw[(32 * nh + n) * 64 + 16 * kb + 8 * hh + j];
+            _Float16 hi = (_Float16)w;
+            if (fabsf((float)hi) > fabsf(w)) {          // the cast rounds to nearest: step back toward zero
+                uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2);
+            }
+            const _Float16 lo = (_Float16)(w - (float)hi);
+            const size_t at = ((((size_t)kb * 2 + nh) * 2 + hh) * 32 + n) * 8 + j;
+            memcpy(&hl[at], &hi, 2);
+            memcpy(&hl[2048 + at], &lo, 2);
+        }
+        tmp.assign(2048, 0.f);
+        memcpy(tmp.data(), hl.data(), 8192);
+        ws.put("head.wh16", tmp);
     }
     if (int rc = ws.upload(net)) { delete net; return rc; }
     *out = net;

@@ -40,9 +40,14 @@ PROF = {"alike_head_hyb": "alike_head_dense", "nms_tail<6>": "nms_tail", "alike_
         "alike_block1": "alike_block1", "nms_sweep_r<6>": "nms_sweep", "match_tile": "match_tile",
         "select_topk": "select_topk", "sample_bilinear": "sample_bilinear", "alike_desc_at": "alike_desc_at"}
 traffic = {}
+def prof_name(k):
+    for pat, name in PROF.items():
+        if k == pat or k.startswith(pat + "<"):
+            return name
+    return None
 for k in names:
-    if k in PROF and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+    if prof_name(k) and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         f = agg[k]["FETCH_SIZE"] / calls[k]["FETCH_SIZE"]; w = agg[k]["WRITE_SIZE"] / calls[k]["WRITE_SIZE"]
-        traffic[PROF[k]] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024), "avg_us": dur[k] / max(ncall[k], 1)}
+        traffic[prof_name(k)] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024), "avg_us": dur[k] / max(ncall[k], 1)}
 if len(sys.argv) > 2:
     json.dump(traffic, open(sys.argv[2], "w"), indent=1)
