@@ -35,14 +35,20 @@ struct Block1Args {
     int H, W;
 };
 
-// 32x32 output tile per workgroup.  conv1 is evaluated on the 34x34 halo'd positions as 1x2 strips,
-// conv2 as 1x4 strips per thread, so every scalar-loaded weight feeds 2 / 4 FMAs and the sliding
-// window re-uses LDS reads across kx.
+// 32x32 output tile per workgroup.  conv1 is evaluated on the 34x34 halo'd positions as 1x2 strips, conv2 on four
+// pixels per thread, so every scalar-loaded weight feeds 2 / 4 FMAs.
+//
+// LDS layout of the intermediate map (r02): two PLANES of float4, mid_lo[34][34] = channels 0..3 and mid_hi = 4..7, and
+// conv2's thread (row r0 = tid / 32, column tid % 32) owns the pixels of rows r0, r0 + 8, r0 + 16, r0 + 24 of its column.
+// A wave's ds_read_b128 then finds 32 consecutive lanes on 32 consecutive 16-byte slots of one map row, so each of the
+// instruction's 16-lane groups ({0-3, 12-15, 20-27}, ...) lands on 16 distinct 4-bank sets at ANY row pitch.  The r01
+// layout ([34][34][8] with 4 consecutive pixels per thread: lanes 128 bytes apart, rows 16 banks apart) put lanes 0/2 and
+// 1/3 of every group on the same banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 70 %.
 __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
 {
     constexpr int IH = B1_TH + 4, IW = B1_TW + 4, MH = B1_TH + 2, MW = B1_TW + 2;
     __shared__ float in[3][IH][IW];
-    __shared__ __attribute__((aligned(16))) float mid[MH][MW][8];
+    __shared__ __attribute__((aligned(16))) float4 mid[2][MH][MW];          // [lo / hi][row][column]
     const int tid = threadIdx.x, b = blockIdx.z;
     const int ty0 = blockIdx.y * B1_TH, tx0 = blockIdx.x * B1_TW;
     const size_t P = (size_t)a.H * a.W;
@@ -100,13 +106,13 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
                 lo = make_float4(relu(acc[q][0]), relu(acc[q][1]), relu(acc[q][2]), relu(acc[q][3]));
                 hi = make_float4(relu(acc[q][4]), relu(acc[q][5]), relu(acc[q][6]), relu(acc[q][7]));
             }
-            *reinterpret_cast<float4*>(&mid[my][mx + q][0]) = lo;
-            *reinterpret_cast<float4*>(&mid[my][mx + q][4]) = hi;
+            mid[0][my][mx + q] = lo;
+            mid[1][my][mx + q] = hi;
         }
     }
     __syncthreads();
-    // conv2 + ReLU: thread = row tid/8, pixels 4*(tid%8) .. +3
-    const int oy = tid >> 3, ox = (tid & 7) * 4;
+    // conv2 + ReLU: thread = column tid % 32, rows tid / 32 + 8 q
+    const int oy = tid >> 5, ox = tid & 31;
     float acc[4][8];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -118,8 +124,8 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
         float v[4][8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 lo = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx + q][0]);
-            const float4 hi = *reinterpret_cast<const float4*>(&mid[oy + ky][ox + kx + q][4]);
+            const float4 lo = mid[0][oy + 8 * q + ky][ox + kx];
+            const float4 hi = mid[1][oy + 8 * q + ky][ox + kx];
             v[q][0] = lo.x; v[q][1] = lo.y; v[q][2] = lo.z; v[q][3] = lo.w;
             v[q][4] = hi.x; v[q][5] = hi.y; v[q][6] = hi.z; v[q][7] = hi.w;
         }
@@ -135,11 +141,11 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
     // stage the 32x32x8 result through LDS (the mid tile is dead now) so that every wave store
     // instruction writes one whole 1 KiB pixel row segment instead of 64 scattered 16-byte pieces
     __syncthreads();
-    float* stage = &mid[0][0][0];
+    float* stage = reinterpret_cast<float*>(&mid[0][0][0]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        *reinterpret_cast<float4*>(stage + (oy * B1_TW + ox + q) * 8) = make_float4(relu(acc[q][0]), relu(acc[q][1]), relu(acc[q][2]), relu(acc[q][3]));
-        *reinterpret_cast<float4*>(stage + (oy * B1_TW + ox + q) * 8 + 4) = make_float4(relu(acc[q][4]), relu(acc[q][5]), relu(acc[q][6]), relu(acc[q][7]));
+        *reinterpret_cast<float4*>(stage + ((oy + 8 * q) * B1_TW + ox) * 8) = make_float4(relu(acc[q][0]), relu(acc[q][1]), relu(acc[q][2]), relu(acc[q][3]));
+        *reinterpret_cast<float4*>(stage + ((oy + 8 * q) * B1_TW + ox) * 8 + 4) = make_float4(relu(acc[q][4]), relu(acc[q][5]), relu(acc[q][6]), relu(acc[q][7]));
     }
     __syncthreads();
 #pragma unroll
@@ -183,14 +189,23 @@ struct ConvArgs {
     int H, W;            // output size
 };
 
-// Each thread: one pixel x 16 output channels.  Waves split into COUT/16 channel groups and
-// 4/(COUT/16) pixel groups of 4x16 pixels; weights are wave-uniform -> scalar loads.
-template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool RELU, bool DSOUT = false>
+// Each thread: one pixel x 16 output channels.  Waves split into COUT/16 channel groups and 4/(COUT/16) pixel groups;
+// weights are wave-uniform -> scalar loads.
+//
+// LDS layout (r02): the input tile is kept as CIN/4 PLANES of float4 (plane c4 = channels 4 c4 .. 4 c4 + 3) and a wave
+// covers 64/TW rows of TW consecutive pixels, so the lanes of a ds_read_b128 sit on consecutive 16-byte slots.  With
+// TW = 32 a whole 32-lane half-wave reads one tile row: every 16-lane group of the instruction hits 16 distinct 4-bank
+// sets at any pitch; with TW = 16 the row pitch is 32 slots, which keeps the two rows of a group ({0-3, 12-15} of one
+// row, {4-11} of the next) apart.  The r01 layout ([position][CIN], lanes CIN floats apart) measured 70-86 % conflict
+// cycles.  Planes are padded to 4 (mod 8) slots so that the staging writes of neighbouring planes do not collide.
+template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool RELU, bool DSOUT = false, int TW = 32>
 __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
 {
-    constexpr int G = COUT / 16, PG = 4 / G, TH = 4 * PG, TW = 16, C4 = CIN / 4;
-    static_assert(COUT % 16 == 0 && (G == 1 || G == 2 || G == 4) && CIN % 4 == 0, "channel config");
-    __shared__ __attribute__((aligned(16))) float tile[(TH + 2) * (TW + 2) * CIN];
+    constexpr int G = COUT / 16, PG = 4 / G, RW = 64 / TW, TH = RW * PG, C4 = CIN / 4;
+    constexpr int RP = TW == 16 ? 32 : TW + 2;                       // row pitch in float4 slots
+    constexpr int NPOS = (TH + 2) * RP, NPOSP = NPOS + ((4 - NPOS % 8) + 8) % 8;
+    static_assert(COUT % 16 == 0 && (G == 1 || G == 2 || G == 4) && CIN % 4 == 0 && (TW == 16 || TW == 32), "channel config");
+    __shared__ __attribute__((aligned(16))) float4 tile[C4 * NPOSP];
     const int tid = threadIdx.x, b = blockIdx.z;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int cg = wv % G, pg = wv / G;
@@ -215,11 +230,11 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
                     v.x = fmaxf(v.x, q.x); v.y = fmaxf(v.y, q.y); v.z = fmaxf(v.z, q.z); v.w = fmaxf(v.w, q.w);
                 }
         }
-        *reinterpret_cast<float4*>(&tile[pos * CIN + c4 * 4]) = v;
+        tile[c4 * NPOSP + y * RP + x] = v;
     }
     __syncthreads();
 
-    const int row = pg * 4 + (lane >> 4), col = lane & 15;
+    const int row = pg * RW + lane / TW, col = lane % TW;
     const int gy = ty0 + row, gx = tx0 + col;
     float acc[16];
     const float* bias = a.bias + cg * 16;
@@ -229,11 +244,11 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const float* t = &tile[((row + ky) * (TW + 2) + col + kx) * CIN];
+            const float4* t = &tile[(row + ky) * RP + col + kx];
             const float* w = a.w + (size_t)((ky * 3 + kx) * CIN) * COUT + cg * 16;
 #pragma unroll 2
             for (int c4 = 0; c4 < C4; ++c4) {
-                const float4 v4 = *reinterpret_cast<const float4*>(t + c4 * 4);
+                const float4 v4 = t[c4 * NPOSP];
                 const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -247,11 +262,11 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
         const float* db = a.ds_b + cg * 16;
 #pragma unroll
         for (int j = 0; j < 16; ++j) ds[j] = db[j];
-        const float* t = &tile[((row + 1) * (TW + 2) + col + 1) * CIN];
+        const float4* t = &tile[(row + 1) * RP + col + 1];
         const float* dw = a.ds_w + cg * 16;
 #pragma unroll 2
         for (int c4 = 0; c4 < C4; ++c4) {
-            const float4 v4 = *reinterpret_cast<const float4*>(t + c4 * 4);
+            const float4 v4 = t[c4 * NPOSP];
             const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -1011,11 +1026,11 @@ void transpose(const float* w, int co, int ci, std::vector<float>& out)
         for (int c = 0; c < ci; ++c) out[(size_t)c * co + o] = w[(size_t)o * ci + c];
 }
 
-template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool DSOUT = false>
+template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool DSOUT = false, int TW = 32>
 void launch_conv(kpb_ctx* ctx, const char* name, hipStream_t st, const ConvArgs& a, int B)
 {
-    constexpr int G = COUT / 16, TH = 4 * (4 / G), TW = 16;
-    KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true, DSOUT>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
+    constexpr int G = COUT / 16, TH = (64 / TW) * (4 / G);
+    KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true, DSOUT, TW>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
 }
 
 int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev)
@@ -1056,7 +1071,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     launch_conv<16, 16, 1, true, 8, 1>(ctx, "conv3x3_b2c2", st, c, batch);
     // block3 @ H/8 (141-142): pool4
     c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
-    launch_conv<16, 32, 4, false, 4, 1, true>(ctx, "conv3x3_b3c1", st, c, batch);
+    launch_conv<16, 32, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b3c1", st, c, batch);        // 80 columns at 480x640: 16-wide tiles divide them
     {   // conv2 of block3 on the MFMA kernel, identity branch precomputed (ALike.py:72-80)
         ConvM m;
         m.in = t3; m.out = x3; m.wp = wp("b3c2.wp"); m.bias = wp("b3c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r3;
@@ -1066,7 +1081,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     }
     // block4 @ H/32 (143-144): pool4
     c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, wp("b4ds.w"), wp("b4ds.b"), r4, H / 32, W / 32};
-    launch_conv<32, 64, 4, false, 4, 1, true>(ctx, "conv3x3_b4c1", st, c, batch);
+    launch_conv<32, 64, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b4c1", st, c, batch);
     {
         ConvM m;
         m.in = t4; m.out = x4; m.wp = wp("b4c2.wp"); m.bias = wp("b4c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r4;

@@ -77,12 +77,19 @@ struct MatchArgs {
 
 // One MTI x MTJ tile of the distance matrix per workgroup, TM x TN of it per thread: every float64 operand read from LDS
 // feeds TN (TM) subtract / multiply / add triples, which keeps the LDS pipe far below the vector ALUs' rate.
+//
+// Column ownership (r02): thread column c owns the tile columns 2c, 2c+1, 32+2c, 32+2c+1, 64+.., 96+.. (COLJ below), not
+// eight consecutive ones: the four 16-byte reads of a k step then find the 16 lanes of a read group on 16 consecutive
+// slots (r01: lanes 64 bytes apart -> every group on 4 bank sets, 67 % conflict cycles).  Row pitches are padded by two
+// doubles so that the k-major staging writes of a float4 (four k rows) fall on different banks pairwise.
+#define COLJ(c, q) (2 * (c) + 32 * ((q) >> 1) + ((q) & 1))
 __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
 {
-    constexpr int STAGE = KC * (MTI + MTJ) * 2, RED = 16 * MTJ * 3;       // words: operand tiles / column-minimum exchange
+    constexpr int PA = MTI + 2, PB = MTJ + 2;                             // padded pitches (doubles)
+    constexpr int STAGE = KC * (PA + PB) * 2, RED = 16 * MTJ * 3;         // words: operand tiles / column-minimum exchange
     __shared__ __attribute__((aligned(16))) unsigned smem[STAGE > RED ? STAGE : RED];
-    double (*A)[MTI] = reinterpret_cast<double (*)[MTI]>(smem);
-    double (*Bt)[MTJ] = reinterpret_cast<double (*)[MTJ]>(smem + KC * MTI * 2);
+    double (*A)[PA] = reinterpret_cast<double (*)[PA]>(smem);
+    double (*Bt)[PB] = reinterpret_cast<double (*)[PB]>(smem + KC * PA * 2);
     const int b = blockIdx.z, tj = blockIdx.x, ti = blockIdx.y, tid = threadIdx.x;
     const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
     const int i0 = ti * MTI, j0 = tj * MTJ;
@@ -108,7 +115,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (kk < a.C) v = *reinterpret_cast<const float4*>(src + kk);
                 double* dst = second ? &Bt[4 * kq][lr] : &A[4 * kq][lr];
-                const int pitch = second ? MTJ : MTI;
+                const int pitch = second ? PB : PA;
                 dst[0] = (double)v.x; dst[pitch] = (double)v.y; dst[2 * pitch] = (double)v.z; dst[3 * pitch] = (double)v.w;
             }
         } else {
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
 #pragma unroll
             for (int p = 0; p < TM; ++p) av[p] = A[k][TM * r + p];
 #pragma unroll
-            for (int q = 0; q < TN; ++q) bv[q] = Bt[k][TN * c + q];
+            for (int q = 0; q < TN; ++q) bv[q] = Bt[k][COLJ(c, q)];
 #pragma unroll
             for (int p = 0; p < TM; ++p)
 #pragma unroll
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
         int bj = 0x7FFFFFFF;
 #pragma unroll
         for (int q = 0; q < TN; ++q) {
-            const int j = j0 + TN * c + q;
+            const int j = j0 + COLJ(c, q);
             if (j < m && precedes(acc[p][q], j, bs, bj)) { bs = acc[p][q]; bj = j; }
         }
 #pragma unroll
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
             const int i = i0 + TM * r + p;
             if (i < n && precedes(acc[p][q], i, bs, bi)) { bs = acc[p][q]; bi = i; }
         }
-        cs[r][TN * c + q] = bs; ci[r][TN * c + q] = bi;
+        cs[r][COLJ(c, q)] = bs; ci[r][COLJ(c, q)] = bi;
     }
     __syncthreads();
     if (tid < MTJ) {
