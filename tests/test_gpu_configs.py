@@ -1,0 +1,108 @@
+"""BASELINE configs[2..4] at the CONFIGURED size: PairPipeline at 480x640 / top_k 1000 for SuperPoint, XFeat and DISK with the
+brute-force matcher, and DISK / SuperPoint with the LightGlue matcher at N = 1000 keypoints (not a multiple of the
+kernel's 32-query tile) and with unequal sides, against the oracle chain evaluated on the GPU's OWN score / descriptor
+maps: bit-exact for the integer stages (keypoints, sampled descriptors, match indices, float64 distances, gathered
+rows), set-level with threshold flips for LightGlue's fp32 transformer.  (The nets' forward passes are pinned at this
+size against reference outputs in test_gpu_superpoint / xfeat / disk.)"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from keypoint_bench_amd import synthetic, weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+H, W = 480, 640
+EP = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)       # config/config_MHA.yaml:68-73
+BF = dict(metric="euclidean", max_distance=5, cross_check=True)                        # config/config_MHA.yaml:82-85
+
+
+def _net(name):
+    if name == "superpoint":
+        from keypoint_bench_amd.models.SuperPoint import superpoint_random
+        return superpoint_random(7).eval()
+    if name == "xfeat":
+        from keypoint_bench_amd.models.XFeat import xfeat_random
+        return xfeat_random(9).eval()
+    from keypoint_bench_amd.models.disk import disk_random
+    return disk_random(5).eval()
+
+
+def _images(B):
+    v = [synthetic.image_pair(60 + i, H, W) for i in range(B)]
+    return torch.from_numpy(np.stack([a for a, _ in v] + [b for _, b in v])).to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("name", ["superpoint", "xfeat", "disk"])
+def test_brute_force_pipeline_at_configured_size(name):
+    from keypoint_bench_amd.pipeline import PairPipeline
+    B = 2
+    pipe = PairPipeline(_net(name), EP, BF, B, H, W, device=DEV).run(_images(B))
+    n = pipe.n.cpu().numpy()
+    assert (n == 1000).all(), n                                    # top_k is the binding limit at this size
+    for b in range(B):
+        kps, sdesc = [], []
+        for side in (0, 1):
+            i = side * B + b
+            k, idx = oracle.detection(pipe.score[i, 0].cpu().numpy(), EP)
+            assert np.array_equal(pipe.kps[i, : n[i]].cpu().numpy().view(np.uint32), k.view(np.uint32)), (name, b, side)
+            assert np.array_equal(pipe.idx[i, : n[i]].cpu().numpy(), idx)
+            d = oracle.sample(pipe.desc[i].permute(2, 0, 1).cpu().numpy(), k)         # [C, Hd, Wd] view of the channels-last map
+            assert np.array_equal(pipe.sdesc[i, : n[i]].cpu().numpy(), d), (name, b, side)
+            kps.append(k); sdesc.append(d)
+        pairs, dist = oracle.match(sdesc[0], sdesc[1], BF["max_distance"], BF["cross_check"])
+        kk = int(pipe.k[b])
+        assert kk == len(pairs), (name, b, kk, len(pairs))
+        assert np.array_equal(pipe.pairs[b, :kk].cpu().numpy(), pairs) and np.array_equal(pipe.dist[b, :kk].cpu().numpy(), dist)
+        assert np.array_equal(pipe.m0[b, :kk].cpu().numpy(), kps[0][pairs[:, 0]]) and np.array_equal(pipe.m1[b, :kk].cpu().numpy(), kps[1][pairs[:, 1]])
+
+
+def _lightglue(dim, scale, seed, variant="plain"):
+    from keypoint_bench_amd.models.lightglue import LightGlue
+    sd = weights.random_lightglue_state_dict(seed, dim, variant)
+    m = LightGlue(features=None, desc_scale=scale)
+    m.load_state_dict(sd)
+    return m, {k: torch.from_numpy(v) for k, v in weights.tensors_lightglue(sd).items()}
+
+
+def _compare_lightglue(got_pairs, got_scores, out):
+    ws = {tuple(r): s for r, s in zip(out["matches"].numpy().tolist(), out["scores"].numpy().tolist())}
+    gs = {tuple(r): s for r, s in zip(got_pairs.tolist(), got_scores.tolist())}
+    for r in set(ws) ^ set(gs):     # nine fp32 layers: only a match whose score sits at the 0.1 threshold may flip
+        s = ws.get(r, gs.get(r))
+        assert abs(s - 0.1) < 2e-3, "match %s (score %.4f) differs and is not at the threshold" % (r, s)
+    common = sorted(set(ws) & set(gs))
+    assert len(common) >= 0.97 * max(len(ws), 1)
+    np.testing.assert_allclose([gs[r] for r in common], [ws[r] for r in common], rtol=5e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("name,dim,scale", [("disk", 128, 1), ("superpoint", 256, 8)])
+def test_lightglue_pipeline_at_configured_size(name, dim, scale):
+    """configs[4] (and SuperPoint + LightGlue): N = 1000 per side through the batched pipeline, then unequal sides (977 / 1000)
+    through the drop-in, each against oracle/lightglue_ref.py on the same keypoints and the GPU's own descriptor maps."""
+    from keypoint_bench_amd.pipeline import PairPipeline
+    from oracle import lightglue_ref as R
+    lg, t = _lightglue(dim, scale, 31)
+    B = 1
+    pipe = PairPipeline(_net(name), EP, BF, B, H, W, device=DEV, lightglue=lg).run(_images(B))
+    n = pipe.n.cpu().numpy()
+    assert (n == 1000).all()
+    k0, k1 = pipe.kps[0].cpu(), pipe.kps[1].cpu()
+    d0 = pipe.desc[0].permute(2, 0, 1)[None].cpu().contiguous()
+    d1 = pipe.desc[1].permute(2, 0, 1)[None].cpu().contiguous()
+    with torch.no_grad():
+        _, _, out = R.match(t, k0, k1, d0, d1, {"w": W, "h": H}, scale)
+    kk = int(pipe.k[0])
+    assert int(pipe.lg_stop[0]) == out["stop"]
+    _compare_lightglue(pipe.pairs[0, :kk].cpu().numpy(), pipe.lg_scores[0, :kk].cpu().numpy(), out)
+    got = pipe.pairs[0, :kk].cpu().numpy()
+    assert np.array_equal(pipe.m0[0, :kk].cpu().numpy(), k0.numpy()[got[:, 0]]) and np.array_equal(pipe.m1[0, :kk].cpu().numpy(), k1.numpy()[got[:, 1]])
+    # unequal sides, neither a multiple of 32
+    p0, p1 = pipe.kps[0, :977].contiguous(), pipe.kps[1, :1000].contiguous()
+    dm0, dm1 = pipe.desc[0].permute(2, 0, 1)[None], pipe.desc[1].permute(2, 0, 1)[None]
+    pairs, scores, stop = lg.match_indices(p0, p1, dm0, dm1, {"w": W, "h": H})
+    with torch.no_grad():
+        _, _, out2 = R.match(t, p0.cpu(), p1.cpu(), d0, d1, {"w": W, "h": H}, scale)
+    assert stop == out2["stop"]
+    _compare_lightglue(pairs.cpu().numpy(), scores.cpu().numpy(), out2)

@@ -23,11 +23,11 @@ def _matcher(seed, dim, scale, variant, **kw):
     return m
 
 
-@pytest.mark.parametrize("name", ["sp_plain", "sp_stop", "sp_prune", "disk_plain", "disk_prune"])
+@pytest.mark.parametrize("name", ["sp_plain", "sp_stop", "sp_prune", "disk_plain", "disk_prune", "disk_n1000", "sp_n1000"])
 def test_lightglue_against_reference_golden(name):
     g = load_golden("lightglue.npz")
-    dim, scale, seed = (int(v) for v in g[name + ".cfg"])
-    dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale)
+    dim, scale, seed, n0, n1 = (int(v) for v in g[name + ".cfg"])
+    dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale, n0=n0, n1=n1)
     m = _matcher(seed, dim, scale, str(g[name + ".variant"]))
     T = lambda a: torch.from_numpy(a).to(DEV)
     pairs, scores, stop = m.match_indices(T(p0), T(p1), T(dm0), T(dm1), {"w": 320, "h": 240})
