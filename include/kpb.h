@@ -207,6 +207,28 @@ int kpb_find_homography(kpb_ctx* ctx, const float* m0_dev, int cols0, const floa
                         const int32_t* k_dev, const float* scale_dev, const uint32_t* seed_dev, uint32_t seed,
                         const kpb_ransac_params* params, double* out_h_dev, uint8_t* out_mask_dev, int32_t* out_info_dev);
 
+/* ---- 8(f)3: relative pose, cv2.findEssentialMat(k0, k1, eye(3), threshold, prob, RANSAC) + cv2.recoverPose as called at
+ * tasks/AUC.py:50-64 -- PARITY UNPINNED, like kpb_find_homography (OpenCV absent; restated: Nister's five-point solver inside
+ * RANSAC with maxIters 1000 and Sampson error, the winning model unrefined; recoverPose = the decomposition with the most
+ * masked points in front of both cameras).
+ * m0_dev / m1_dev / k_dev / scale_dev / seed_dev / seed: as kpb_find_homography (AUC.py:125-126 scales side 0 with image 0's
+ * (w-1, h-1) and side 1 with image 1's).  cam_dev [batch][8] float64 = (cx0, cy0, fx0, fy0, cx1, cy1, fx1, fy1): pixels are
+ * normalised as (p - c) / f (AUC.py:47-48) -- in float32 when cam_f32 != 0 (the datasets hand float32 intrinsics over and
+ * numpy then stays in float32), in float64 otherwise; thr_dev [batch] float64 = thresh / f_mean (AUC.py:44-45).
+ * max_k <= 1024.  out_e_dev [batch][9] float64 (Frobenius norm 1; zeros when nothing was found), out_mask_dev [batch][max_k]
+ * inliers of that model, out_info_dev [batch][4] = (found, inliers, hypotheses evaluated, 0), out_pts_dev [batch][max_k][4]
+ * float64 = the normalised coordinates (u0, v0, u1, v1), input of kpb_recover_pose. */
+int kpb_find_essential(kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k,
+                       const int32_t* k_dev, const float* scale_dev, const double* cam_dev, int cam_f32, const double* thr_dev,
+                       const uint32_t* seed_dev, uint32_t seed, double prob, int max_iters, double* out_e_dev,
+                       uint8_t* out_mask_dev, int32_t* out_info_dev, double* out_pts_dev);
+/* e_dev / pts_dev / mask_dev / info_dev: outputs of kpb_find_essential; dist: recoverPose's distanceThresh (1e9 at AUC.py:60).
+ * out_rt_dev [batch][12] float64 = R row-major then t; out_mask_dev [batch][max_k]: masked points in front of both cameras
+ * for the chosen (R, t) (what cv2 leaves in `mask`); out_good_dev [batch]: their number (0: no pose). */
+int kpb_recover_pose(kpb_ctx* ctx, const double* e_dev, const double* pts_dev, const uint8_t* mask_dev, int batch, int max_k,
+                     const int32_t* k_dev, const int32_t* info_dev, double dist, double* out_rt_dev, uint8_t* out_mask_dev,
+                     int32_t* out_good_dev);
+
 /* ---- 8(f)2: per-image input transform after decoding, datasets/hpatches.py:47-69 --------------------
  * src_dev [batch][Hs][Ws][3] uint8 as decoded (BGR from cv2.imread with swap_rb = 1, RGB with 0);
  * out_dev [batch][3][Hd][Wd] fp32 = cv2.resize(src / 255, (Wd, Hd)) (INTER_LINEAR), channels first.

@@ -496,3 +496,485 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_homography(
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
+
+// ================================================================================================ RANSAC essential matrix
+// cv2.findEssentialMat(k0, k1, eye(3), threshold, prob, RANSAC) + cv2.recoverPose as tasks/AUC.py:50-64 calls them (maxIters
+// 1000, five-point samples, Sampson error, no refinement of the winning model), restated from the published algorithm --
+// PARITY UNPINNED, numpy restatement in oracle/geometry_ref.py (same sampler, same elimination order, same root finder).
+// One 256-thread workgroup per pair, one hypothesis per thread and round; a hypothesis is Nister's five-point solver:
+// null space of the 5 x 9 constraints by Gauss-Jordan, the ten cubic constraints expanded by polynomial arithmetic
+// (tables below), Gauss-Jordan on the ten leading monomials, det B(z) (degree 10), its roots by Aberth-Ehrlich iteration,
+// up to ten candidate matrices, each scored against ALL matches (LDS broadcast reads).  The solver's small matrices are
+// thread-private (scratch): this stage is a few milliseconds per 256 pairs next to a 30 ms extraction step.
+namespace {
+
+// products of the monomial bases: linear (x, y, z, 1) x linear -> quadratic DEG2; quadratic x linear -> MONO (Nister's order:
+// x3 y3 x2y xy2 x2z x2 y2z y2 xyz xy | xz2 xz x yz2 yz y z3 z2 z 1)
+__constant__ int8_t E_MUL11[4][4] = {{0, 1, 2, 6}, {1, 3, 4, 7}, {2, 4, 5, 8}, {6, 7, 8, 9}};
+__constant__ int8_t E_MUL21[10][4] = {{0, 2, 4, 5},   {2, 3, 8, 9},   {4, 8, 10, 11}, {3, 1, 6, 7},   {8, 6, 13, 14},
+                                      {10, 13, 16, 17}, {5, 9, 11, 12}, {9, 7, 14, 15}, {11, 14, 17, 18}, {12, 15, 18, 19}};
+
+__device__ void pmul11_acc(double* out, const double* a, const double* b, double s)
+{
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) out[E_MUL11[i][j]] += s * a[i] * b[j];
+}
+
+__device__ void pmul21_acc(double* out, const double* a, const double* b, double s)
+{
+    for (int i = 0; i < 10; ++i)
+        for (int j = 0; j < 4; ++j) out[E_MUL21[i][j]] += s * a[i] * b[j];
+}
+
+// Reduces the first ncol columns of the r x c matrix to the identity (row pivoting, first maximum).  false: singular.
+__device__ bool gauss_jordan(double* M, int r, int c, int ncol)
+{
+    for (int col = 0; col < ncol; ++col) {
+        int piv = col;
+        double best = fabs(M[col * c + col]);
+        for (int rr = col + 1; rr < r; ++rr) if (fabs(M[rr * c + col]) > best) { best = fabs(M[rr * c + col]); piv = rr; }
+        if (piv != col) for (int k = 0; k < c; ++k) { const double t = M[col * c + k]; M[col * c + k] = M[piv * c + k]; M[piv * c + k] = t; }
+        const double d = M[col * c + col];
+        if (!(fabs(d) > 1e-300)) return false;
+        for (int k = 0; k < c; ++k) M[col * c + k] = M[col * c + k] / d;
+        for (int rr = 0; rr < r; ++rr) {
+            if (rr == col) continue;
+            const double f = M[rr * c + col];
+            for (int k = 0; k < c; ++k) M[rr * c + k] = M[rr * c + k] - f * M[col * c + k];
+        }
+    }
+    return true;
+}
+
+__device__ void polymul_acc(double* out, const double* a, int na, const double* b, int nb, double s)
+{
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) out[i + j] += s * a[i] * b[j];
+}
+
+__device__ __forceinline__ double polyval_r(const double* c, int n, double z)
+{
+    double v = c[n - 1];
+    for (int i = n - 2; i >= 0; --i) v = v * z + c[i];
+    return v;
+}
+
+struct Cx { double re, im; };
+__device__ __forceinline__ Cx cmul(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cx cdiv(Cx a, Cx b)
+{
+    const double d = b.re * b.re + b.im * b.im;
+    return {(a.re * b.re + a.im * b.im) / d, (a.im * b.re - a.re * b.im) / d};
+}
+
+// all roots of the degree-10 polynomial cn (ascending, cn[10] = 1) by Aberth-Ehrlich from a fixed start circle
+__device__ void aberth10(const double* cn, Cx* z)
+{
+    double rad = pow(fabs(cn[0]), 0.1);
+    if (!(rad > 0.0) || !isfinite(rad)) rad = 1.0;
+    rad = fmin(fmax(rad, 1e-3), 1e3);
+    for (int k = 0; k < 10; ++k) { const double a = 2.0 * 3.141592653589793 * k / 10.0 + 0.4; z[k] = {rad * cos(a), rad * sin(a)}; }
+    double dc[10];
+    for (int i = 0; i < 10; ++i) dc[i] = cn[i + 1] * (double)(i + 1);
+    for (int it = 0; it < 40; ++it) {
+        Cx zn[10];
+        for (int k = 0; k < 10; ++k) {
+            Cx p = {cn[10], 0.0}, dp = {dc[9], 0.0};
+            for (int i = 9; i >= 0; --i) { p = cmul(p, z[k]); p.re += cn[i]; }
+            for (int i = 8; i >= 0; --i) { dp = cmul(dp, z[k]); dp.re += dc[i]; }
+            if (dp.re == 0.0 && dp.im == 0.0) dp.re = 1e-300;
+            const Cx ratio = cdiv(p, dp);
+            Cx s = {0.0, 0.0};
+            for (int j = 0; j < 10; ++j) {
+                if (j == k) continue;
+                Cx d = {z[k].re - z[j].re, z[k].im - z[j].im};
+                if (d.re == 0.0 && d.im == 0.0) d.re = 1e-300;
+                const Cx inv = cdiv({1.0, 0.0}, d);
+                s.re += inv.re; s.im += inv.im;
+            }
+            const Cx rs = cmul(ratio, s);
+            const Cx upd = cdiv(ratio, {1.0 - rs.re, -rs.im});
+            zn[k] = {z[k].re - upd.re, z[k].im - upd.im};
+        }
+        for (int k = 0; k < 10; ++k) z[k] = zn[k];      // Jacobi-style update: every root moves on the previous iterate
+    }
+}
+
+// Five-point solver.  x1 / x2: the sample's five normalised points (u, v interleaved).  E: up to ten candidates (row-major,
+// Frobenius norm 1), valid[s] says which slots hold one.  Returns the number of valid slots.
+__device__ int essential_5pt(const double* x1, const double* x2, double (*E)[9], bool* valid)
+{
+    for (int s = 0; s < 10; ++s) valid[s] = false;
+    double Q[5 * 9];
+    for (int i = 0; i < 5; ++i) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        double* q = Q + 9 * i;
+        q[0] = u2 * u1; q[1] = u2 * v1; q[2] = u2; q[3] = v2 * u1; q[4] = v2 * v1; q[5] = v2; q[6] = u1; q[7] = v1; q[8] = 1.0;
+    }
+    bool ok = gauss_jordan(Q, 5, 9, 5);
+    // basis row j = (-C[:, j], e_j); entry e of E as a linear polynomial over (x, y, z, 1): Ep[e][k] = basis[k][e]
+    double Ep[9][4];
+    for (int e = 0; e < 9; ++e)
+        for (int k = 0; k < 4; ++k) Ep[e][k] = e < 5 ? -Q[e * 9 + 5 + k] : (e - 5 == k ? 1.0 : 0.0);
+    double EEt[9][10];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double* o = EEt[3 * i + j];
+            for (int m = 0; m < 10; ++m) o[m] = 0.0;
+            for (int k = 0; k < 3; ++k) pmul11_acc(o, Ep[3 * i + k], Ep[3 * j + k], 1.0);
+        }
+    double tr[10];
+    for (int m = 0; m < 10; ++m) tr[m] = EEt[0][m] + EEt[4][m] + EEt[8][m];
+    double M[10 * 20];
+    for (int m = 0; m < 200; ++m) M[m] = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double* row = M + 20 * (3 * i + j);
+            for (int k = 0; k < 3; ++k) pmul21_acc(row, EEt[3 * i + k], Ep[3 * k + j], 2.0);
+            pmul21_acc(row, tr, Ep[3 * i + j], -1.0);
+        }
+    {
+        double m01[10], m02[10], m03[10];
+        for (int m = 0; m < 10; ++m) { m01[m] = 0.0; m02[m] = 0.0; m03[m] = 0.0; }
+        pmul11_acc(m01, Ep[4], Ep[8], 1.0); pmul11_acc(m01, Ep[5], Ep[7], -1.0);
+        pmul11_acc(m02, Ep[5], Ep[6], 1.0); pmul11_acc(m02, Ep[3], Ep[8], -1.0);
+        pmul11_acc(m03, Ep[3], Ep[7], 1.0); pmul11_acc(m03, Ep[4], Ep[6], -1.0);
+        double* row = M + 20 * 9;
+        pmul21_acc(row, m01, Ep[0], 1.0); pmul21_acc(row, m02, Ep[1], 1.0); pmul21_acc(row, m03, Ep[2], 1.0);
+    }
+    ok = gauss_jordan(M, 10, 20, 10) && ok;
+    // rows <a> - z <b> over the trailing monomials [xz2 xz x yz2 yz y z3 z2 z 1]: (x, y, 1) parts as polynomials in z, ascending
+    double Bx[3][4], By[3][4], B1[3][5];
+    for (int r = 0; r < 3; ++r) {
+        const double* a = M + 20 * (4 + 2 * r) + 10;
+        const double* b = M + 20 * (5 + 2 * r) + 10;
+        Bx[r][0] = a[2]; Bx[r][1] = a[1] - b[2]; Bx[r][2] = a[0] - b[1]; Bx[r][3] = -b[0];
+        By[r][0] = a[5]; By[r][1] = a[4] - b[5]; By[r][2] = a[3] - b[4]; By[r][3] = -b[3];
+        B1[r][0] = a[9]; B1[r][1] = a[8] - b[9]; B1[r][2] = a[7] - b[8]; B1[r][3] = a[6] - b[7]; B1[r][4] = -b[6];
+    }
+    double det[11];
+    for (int i = 0; i < 11; ++i) det[i] = 0.0;
+    {
+        double t7[7];
+        // (Bx0 By1 - By0 Bx1) B1_2
+        for (int i = 0; i < 7; ++i) t7[i] = 0.0;
+        polymul_acc(t7, Bx[0], 4, By[1], 4, 1.0); polymul_acc(t7, By[0], 4, Bx[1], 4, -1.0);
+        polymul_acc(det, t7, 7, B1[2], 5, 1.0);
+        // (By0 B1_1 - B1_0 By1) Bx2   (8 coefficients, times 4)
+        double t8[8];
+        for (int i = 0; i < 8; ++i) t8[i] = 0.0;
+        polymul_acc(t8, By[0], 4, B1[1], 5, 1.0); polymul_acc(t8, B1[0], 5, By[1], 4, -1.0);
+        polymul_acc(det, t8, 8, Bx[2], 4, 1.0);
+        // (B1_0 Bx1 - Bx0 B1_1) By2
+        for (int i = 0; i < 8; ++i) t8[i] = 0.0;
+        polymul_acc(t8, B1[0], 5, Bx[1], 4, 1.0); polymul_acc(t8, Bx[0], 4, B1[1], 5, -1.0);
+        polymul_acc(det, t8, 8, By[2], 4, 1.0);
+    }
+    bool fin = true;
+    for (int i = 0; i < 11; ++i) fin = fin && isfinite(det[i]);
+    ok = ok && fin && fabs(det[10]) > 1e-300;
+    if (!ok) return 0;
+    double cn[11], dc[10];
+    for (int i = 0; i < 11; ++i) cn[i] = det[i] / det[10];
+    for (int i = 0; i < 10; ++i) dc[i] = cn[i + 1] * (double)(i + 1);
+    Cx roots[10];
+    aberth10(cn, roots);
+    int nvalid = 0;
+    for (int s = 0; s < 10; ++s) {
+        double zr = roots[s].re;
+        for (int it = 0; it < 3; ++it) {                // Newton polish on the real axis
+            const double p = polyval_r(cn, 11, zr);
+            double dp = polyval_r(dc, 10, zr);
+            if (dp == 0.0) dp = 1e-300;
+            zr = zr - p / dp;
+        }
+        bool real = fabs(roots[s].im) < 1e-6 * (1.0 + fabs(roots[s].re)) && isfinite(zr);
+        {
+            double pabs = fabs(cn[10]);
+            const double az = fabs(zr);
+            for (int i = 9; i >= 0; --i) pabs = pabs * az + fabs(cn[i]);
+            real = real && fabs(polyval_r(cn, 11, zr)) < 1e-6 * (1.0 + pabs);
+        }
+        const double b00 = polyval_r(Bx[0], 4, zr), b01 = polyval_r(By[0], 4, zr), b02 = polyval_r(B1[0], 5, zr);
+        const double b10 = polyval_r(Bx[1], 4, zr), b11 = polyval_r(By[1], 4, zr), b12 = polyval_r(B1[1], 5, zr);
+        const double cx = b01 * b12 - b02 * b11, cy = b02 * b10 - b00 * b12;
+        double cw = b00 * b11 - b01 * b10;
+        real = real && fabs(cw) > 1e-300;
+        if (!(fabs(cw) > 1e-300)) cw = 1.0;
+        const double cf[4] = {cx / cw, cy / cw, zr, 1.0};
+        double nrm = 0.0;
+        for (int e = 0; e < 9; ++e) {
+            double v = 0.0;
+            for (int k = 0; k < 4; ++k) v += cf[k] * Ep[e][k];
+            E[s][e] = v;
+            nrm += v * v;
+        }
+        nrm = sqrt(nrm);
+        real = real && isfinite(nrm) && nrm > 0.0;
+        if (real) { for (int e = 0; e < 9; ++e) E[s][e] = E[s][e] / nrm; ++nvalid; }
+        valid[s] = real;
+    }
+    return nvalid;
+}
+
+// OpenCV's EMEstimatorCallback::computeError (Sampson distance) of one correspondence
+__device__ __forceinline__ double sampson_err(const double* E, double u1, double v1, double u2, double v2)
+{
+    const double a0 = E[0] * u1 + E[1] * v1 + E[2], a1 = E[3] * u1 + E[4] * v1 + E[5], a2 = E[6] * u1 + E[7] * v1 + E[8];       // E x1
+    const double b0 = E[0] * u2 + E[3] * v2 + E[6], b1 = E[1] * u2 + E[4] * v2 + E[7];                                           // E^T x2
+    const double x2tEx1 = a0 * u2 + a1 * v2 + a2;
+    double den = a0 * a0 + a1 * a1 + b0 * b0 + b1 * b1;
+    if (den == 0.0) den = 1e-300;
+    return x2tEx1 * x2tEx1 / den;
+}
+
+struct EssArgs {
+    const float* m0; int cols0; const float* m1; int cols1;
+    int max_k; const int32_t* k_dev;
+    const float* scale;       // [B][4]: normalised (x, y) -> pixels, fp32 as AUC.py:125-126
+    const double* cam;        // [B][8]: cx0 cy0 fx0 fy0 cx1 cy1 fx1 fy1 (AUC.py:47-48: (k - c) / f)
+    int cam_f32;              // the intrinsics are float32 (datasets/megadepth.py:341-342): numpy then normalises in float32
+    const double* thr;        // [B]: norm_thresh = thresh / f_mean
+    const uint32_t* seed_dev; uint32_t seed;
+    double prob; int max_iters;
+    double* E; uint8_t* mask; int32_t* info;      // [B][9], [B][max_k], [B][4] = (found, inliers, hypotheses, 0)
+    double* pts;                                   // [B][max_k][4] normalised coordinates (u1 v1 u2 v2), kept for kpb_recover_pose
+};
+
+__global__ __launch_bounds__(RS_THREADS) void ransac_essential(EssArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* P = reinterpret_cast<double*>(smem);                     // [n][4]
+    __shared__ double bestE[9];
+    __shared__ unsigned long long wkey[RS_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.k_dev ? min(a.k_dev[b], a.max_k) : a.max_k;
+    const uint32_t seed = a.seed_dev ? a.seed_dev[b] : a.seed;
+    const float* sc = a.scale + 4 * b;
+    const double* cam = a.cam + 8 * b;
+    double* gp = a.pts + (size_t)b * a.max_k * 4;
+    for (int i = tid; i < n; i += RS_THREADS) {
+        const float* p0 = a.m0 + ((size_t)b * a.max_k + i) * a.cols0;
+        const float* p1 = a.m1 + ((size_t)b * a.max_k + i) * a.cols1;
+        const float x0 = p0[0] * sc[0], y0 = p0[1] * sc[1], x1 = p1[0] * sc[2], y1 = p1[1] * sc[3];      // fp32 pixel products (AUC.py:125-126)
+        double u1, v1, u2, v2;
+        if (a.cam_f32) {
+            u1 = (double)__fdiv_rn(x0 - (float)cam[0], (float)cam[2]); v1 = (double)__fdiv_rn(y0 - (float)cam[1], (float)cam[3]);
+            u2 = (double)__fdiv_rn(x1 - (float)cam[4], (float)cam[6]); v2 = (double)__fdiv_rn(y1 - (float)cam[5], (float)cam[7]);
+        } else {
+            u1 = ((double)x0 - cam[0]) / cam[2]; v1 = ((double)y0 - cam[1]) / cam[3];
+            u2 = ((double)x1 - cam[4]) / cam[6]; v2 = ((double)y1 - cam[5]) / cam[7];
+        }
+        P[4 * i] = u1; P[4 * i + 1] = v1; P[4 * i + 2] = u2; P[4 * i + 3] = v2;
+        gp[4 * i] = u1; gp[4 * i + 1] = v1; gp[4 * i + 2] = u2; gp[4 * i + 3] = v2;
+    }
+    uint8_t* mask = a.mask + (size_t)b * a.max_k;
+    for (int i = tid; i < a.max_k; i += RS_THREADS) mask[i] = 0;
+    __syncthreads();
+    int32_t* info = a.info + 4 * b;
+    double* Eout = a.E + 9 * b;
+    if (n < 5) {
+        if (tid < 9) Eout[tid] = 0.0;
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = 0; info[3] = 0; }
+        return;
+    }
+    const double t2 = a.thr[b] * a.thr[b];
+    int done = 0, niters = a.max_iters, best = 0;
+    while (done < niters) {
+        const uint32_t it = (uint32_t)(done + tid);
+        int idx[5] = {0, 0, 0, 0, 0};
+        const bool ok = draw_samples<5>(seed, it, n, idx) && (int)it < a.max_iters;
+        double x1[10], x2[10];
+        for (int j = 0; j < 5; ++j) { x1[2 * j] = P[4 * idx[j]]; x1[2 * j + 1] = P[4 * idx[j] + 1]; x2[2 * j] = P[4 * idx[j] + 2]; x2[2 * j + 1] = P[4 * idx[j] + 3]; }
+        double E[10][9];
+        bool valid[10];
+        int nv = 0;
+        if (ok) nv = essential_5pt(x1, x2, E, valid);
+        int bcnt = 0, bslot = 0;
+        if (nv) {
+            for (int s = 0; s < 10; ++s) {
+                if (!valid[s]) continue;
+                int cnt = 0;
+                for (int i = 0; i < n; ++i) cnt += sampson_err(E[s], P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) <= t2;
+                if (cnt > bcnt) { bcnt = cnt; bslot = s; }          // first maximum: the lowest root slot
+            }
+        }
+        // workgroup arg-max: more inliers, then the lower iteration, then the lower root slot
+        const unsigned low = (0x0FFFFFFFu - it) * 16u + (15u - (unsigned)bslot);
+        const unsigned long long key = ((unsigned long long)(unsigned)bcnt << 32) | low;
+        unsigned long long kmax = key;
+        for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_down(kmax, o); kmax = t > kmax ? t : kmax; }
+        if ((tid & 63) == 0) wkey[tid >> 6] = kmax;
+        __syncthreads();
+        kmax = wkey[0];
+        for (int w = 1; w < RS_THREADS / 64; ++w) kmax = wkey[w] > kmax ? wkey[w] : kmax;
+        const int top = (int)(kmax >> 32);
+        if (top > max(best, 4)) {
+            best = top;
+            if (key == kmax) for (int e = 0; e < 9; ++e) bestE[e] = E[bslot][e];
+        }
+        __syncthreads();
+        done += RS_THREADS;
+        niters = best ? update_iters(a.prob, (double)(n - best) / n, 5, a.max_iters) : a.max_iters;
+    }
+    if (best == 0) {
+        if (tid < 9) Eout[tid] = 0.0;
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = done; info[3] = 0; }
+        return;
+    }
+    double Eb[9];
+    for (int e = 0; e < 9; ++e) Eb[e] = bestE[e];
+    for (int i = tid; i < n; i += RS_THREADS) mask[i] = sampson_err(Eb, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) <= t2;
+    if (tid < 9) Eout[tid] = Eb[tid];
+    if (tid == 0) { info[0] = 1; info[1] = best; info[2] = done; info[3] = 0; }
+}
+
+// ---- recoverPose: SVD of E (Jacobi on E^T E), the four (R, t), depth signs of the masked points, the best combination
+__device__ void jacobi3(double* A /* symmetric 3x3, destroyed */, double* V)
+{
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                const double apq = A[3 * p + q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[3 * q + q] - A[3 * p + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[3 * k + p], akq = A[3 * k + q];
+                    A[3 * k + p] = c * akp - s * akq; A[3 * k + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[3 * p + k], aqk = A[3 * q + k];
+                    A[3 * p + k] = c * apk - s * aqk; A[3 * q + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+                    V[3 * k + p] = c * vkp - s * vkq; V[3 * k + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ double det3(const double* m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+struct PoseArgs {
+    const double* E; const double* pts; const uint8_t* mask_in; int max_k; const int32_t* k_dev; const int32_t* info;
+    double dist; double* Rt; uint8_t* mask_out; int32_t* good;       // Rt [B][12] = R row-major, t; good [B]
+};
+
+__global__ __launch_bounds__(RS_THREADS) void recover_pose(PoseArgs a)
+{
+    __shared__ double Rs[2][9], ts[3];
+    __shared__ double scratch[(RS_THREADS / 64 + 1) * 5];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.k_dev ? min(a.k_dev[b], a.max_k) : a.max_k;
+    const uint8_t* min_ = a.mask_in + (size_t)b * a.max_k;
+    uint8_t* mout = a.mask_out + (size_t)b * a.max_k;
+    for (int i = tid; i < a.max_k; i += RS_THREADS) mout[i] = 0;
+    if (a.info[4 * b] == 0) {
+        if (tid < 12) a.Rt[12 * b + tid] = 0.0;
+        if (tid == 0) a.good[b] = 0;
+        return;
+    }
+    if (tid == 0) {
+        const double* E = a.E + 9 * b;
+        double AtA[9], V[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += E[3 * k + i] * E[3 * k + j]; AtA[3 * i + j] = s; }
+        jacobi3(AtA, V);
+        // order the eigenvalues descending: singular values s0 >= s1 >= s2 (~0)
+        int o[3] = {0, 1, 2};
+        for (int i = 0; i < 2; ++i) for (int j = i + 1; j < 3; ++j) if (AtA[4 * o[j]] > AtA[4 * o[i]]) { const int t = o[i]; o[i] = o[j]; o[j] = t; }
+        double Vs[9], U[9];
+        for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) Vs[3 * r + c] = V[3 * r + o[c]];
+        for (int c = 0; c < 2; ++c) {
+            double u[3], nn = 0.0;
+            for (int r = 0; r < 3; ++r) { u[r] = E[3 * r] * Vs[c] + E[3 * r + 1] * Vs[3 + c] + E[3 * r + 2] * Vs[6 + c]; nn += u[r] * u[r]; }
+            nn = sqrt(nn);
+            for (int r = 0; r < 3; ++r) U[3 * r + c] = u[r] / (nn > 0 ? nn : 1.0);
+        }
+        U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];      // u2 = u0 x u1
+        double Vt[9];
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Vt[3 * r + c] = Vs[3 * c + r];
+        if (det3(U) < 0) for (int i = 0; i < 9; ++i) U[i] = -U[i];
+        if (det3(Vt) < 0) for (int i = 0; i < 9; ++i) Vt[i] = -Vt[i];
+        const double W[9] = {0, 1, 0, -1, 0, 0, 0, 0, 1};
+        for (int which = 0; which < 2; ++which) {
+            double T[9];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += U[3 * i + k] * (which ? W[3 * j + k] : W[3 * k + j]); T[3 * i + j] = s; }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += T[3 * i + k] * Vt[3 * k + j]; Rs[which][3 * i + j] = s; }
+        }
+        ts[0] = U[2]; ts[1] = U[5]; ts[2] = U[8];
+    }
+    __syncthreads();
+    // depth signs for the four combinations (R1, t), (R2, t), (R1, -t), (R2, -t): z1 R x1 + t = z2 x2 in least squares
+    const double* P = a.pts + (size_t)b * a.max_k * 4;
+    double cnt[4] = {0, 0, 0, 0};
+    unsigned flags_local[4] = {0, 0, 0, 0};       // up to 4 points per thread (max_k <= 1024): bit c of entry j
+    int j = 0;
+    for (int i = tid; i < n; i += RS_THREADS, ++j) {
+        if (!min_[i]) continue;
+        const double u1 = P[4 * i], v1 = P[4 * i + 1], u2 = P[4 * i + 2], v2 = P[4 * i + 3];
+        for (int c = 0; c < 4; ++c) {
+            const double* R = Rs[c & 1];
+            const double sg = c < 2 ? 1.0 : -1.0;
+            const double ax = R[0] * u1 + R[1] * v1 + R[2], ay = R[3] * u1 + R[4] * v1 + R[5], az = R[6] * u1 + R[7] * v1 + R[8];
+            const double tx = sg * ts[0], ty = sg * ts[1], tz = sg * ts[2];
+            const double aa = ax * ax + ay * ay + az * az, ab = -(ax * u2 + ay * v2 + az), bb = u2 * u2 + v2 * v2 + 1.0;
+            const double ra = -(ax * tx + ay * ty + az * tz), rb = u2 * tx + v2 * ty + tz;
+            double det = aa * bb - ab * ab;
+            if (!(fabs(det) > 1e-300)) det = 1e-300;
+            const double z1 = (ra * bb - ab * rb) / det, z2 = (aa * rb - ab * ra) / det;
+            const bool good = z1 > 0 && z1 < a.dist && z2 > 0 && z2 < a.dist;
+            if (good) { cnt[c] += 1.0; if (j < 4) flags_local[j] |= 1u << c; }
+        }
+    }
+    block_sum_n<4>(cnt, scratch);
+    int bestc = 0;
+    for (int c = 1; c < 4; ++c) if (cnt[c] > cnt[bestc]) bestc = c;       // ties keep the earlier combination
+    j = 0;
+    for (int i = tid; i < n; i += RS_THREADS, ++j) if (j < 4 && (flags_local[j] >> bestc) & 1u) mout[i] = 1;
+    if (tid < 9) a.Rt[12 * b + tid] = Rs[bestc & 1][tid];
+    if (tid < 3) a.Rt[12 * b + 9 + tid] = (bestc < 2 ? 1.0 : -1.0) * ts[tid];
+    if (tid == 0) a.good[b] = (int)cnt[bestc];
+}
+
+}  // namespace
+
+extern "C" __attribute__((visibility("default"))) int kpb_find_essential(
+    kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k, const int32_t* k_dev,
+    const float* scale_dev, const double* cam_dev, int cam_f32, const double* thr_dev, const uint32_t* seed_dev, uint32_t seed, double prob, int max_iters,
+    double* out_e_dev, uint8_t* out_mask_dev, int32_t* out_info_dev, double* out_pts_dev)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_find_essential: null context");
+    if (batch <= 0 || max_k < 0 || cols0 < 2 || cols1 < 2 || !scale_dev || !cam_dev || !thr_dev || !out_e_dev || !out_info_dev ||
+        (max_k && (!m0_dev || !m1_dev || !out_mask_dev || !out_pts_dev)) || max_iters < 1)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: bad argument");
+    if (max_k > 1024) return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: at most 1024 matches per pair");
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    EssArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, cam_dev, cam_f32, thr_dev, seed_dev, seed, prob, max_iters, out_e_dev, out_mask_dev,
+              out_info_dev, out_pts_dev};
+    KPB_LAUNCH(ctx, "ransac_essential", ransac_essential, dim3(batch), dim3(RS_THREADS), (size_t)max_k * 4 * sizeof(double), ctx->stream, a);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_recover_pose(
+    kpb_ctx* ctx, const double* e_dev, const double* pts_dev, const uint8_t* mask_dev, int batch, int max_k, const int32_t* k_dev,
+    const int32_t* info_dev, double dist, double* out_rt_dev, uint8_t* out_mask_dev, int32_t* out_good_dev)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_recover_pose: null context");
+    if (batch <= 0 || max_k < 0 || max_k > 1024 || !e_dev || !info_dev || !out_rt_dev || !out_good_dev || (max_k && (!pts_dev || !mask_dev || !out_mask_dev)))
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_recover_pose: bad argument");
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    PoseArgs a{e_dev, pts_dev, mask_dev, max_k, k_dev, info_dev, dist, out_rt_dev, out_mask_dev, out_good_dev};
+    KPB_LAUNCH(ctx, "recover_pose", recover_pose, dim3(batch), dim3(RS_THREADS), 0, ctx->stream, a);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}

@@ -196,6 +196,13 @@ def mha_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, param
     return [float(v) for v in mha(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params)]
 
 
+def auc_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
+    """model_interface.py:254-259: [max(err_t, err_R), inliers] (tasks/AUC.py:151-154)."""
+    from .tasks.AUC import auc
+    r = auc(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params)
+    return [float(r["AUC"]), float(r["inliers"])]
+
+
 def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params):
     from .utils.extracter import detection
     from .utils.matcher import brute_force_matcher
@@ -205,7 +212,7 @@ def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, p
     return [k0.shape[0], k1.shape[0], m0.shape[0]]
 
 
-TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "match_stats": match_stats}
+TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "AUC": auc_row, "match_stats": match_stats}
 
 
 # ---- the same tasks over a whole PairPipeline batch (rows equal to the single-pair functions above)
@@ -229,6 +236,11 @@ def _batched_mha(pipe, items, params, indices=None):
     return mha_batch(pipe, items, params, indices)
 
 
+def _batched_auc(pipe, items, params, indices=None):
+    from .tasks.AUC import auc_batch
+    return auc_batch(pipe, items, params, indices)
+
+
 def _covis_tables(items, B, dev):
     """(hmat [2B,9], wh [2B,2]) of the MHA flow: rows 0..B-1 warp01 of each pair, B..2B-1 warp10 (padded by repetition)."""
     from .tasks.repeatability import homography_tables
@@ -240,7 +252,7 @@ def _covis_tables(items, B, dev):
 
 # task -> (rows function, pipeline needs the match stage, keypoints are covisibility-filtered before matching)
 BATCHED_TASKS = {"match_stats": (_batched_match_stats, True, False), "repeatability": (_batched_repeatability, False, False),
-                 "MHA": (_batched_mha, True, True)}
+                 "MHA": (_batched_mha, True, True), "AUC": (_batched_auc, True, False)}
 
 
 def _homo_only(item):
@@ -354,7 +366,7 @@ class PairRunner:
 
         for i in indices:
             item = dataset[i]
-            if not batched or not _homo_only(item):
+            if not batched or (task_type != "AUC" and not _homo_only(item)):
                 flush()
                 out[i] = self.test_step(item, i)
                 continue

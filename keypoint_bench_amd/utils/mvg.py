@@ -40,3 +40,51 @@ def find_homography(m0, m1, scale, k_dev=None, seeds=None, seed=0, threshold=3.0
     ctx.check(ctx.lib.kpb_find_homography(ctx.handle, ptr(a), a.shape[2], ptr(b), b.shape[2], B, K, ptr(k_dev), ptr(sc), ptr(sd),
                                           ctypes.c_uint32(int(seed) & 0xFFFFFFFF), ctypes.byref(prm), ptr(H), ptr(mask), ptr(info)))
     return H, mask[:, :K], info
+
+
+def _seeds(seeds, B, dev):
+    if seeds is None:
+        return None
+    return torch.from_numpy((np.asarray(seeds, np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(B).copy()).to(dev)
+
+
+def estimate_pose(m0, m1, scale, K0, K1, thresh=1.0, conf=0.99999, k_dev=None, seeds=None, seed=0, max_iters=1000):
+    """tasks/AUC.py:40-64 (`estimate_pose`) for B pairs in two launches: cv2.findEssentialMat(RANSAC) + cv2.recoverPose restated
+    (PARITY UNPINNED, see the module docstring).  m0, m1 [B, K, c>=2] matched rows, normalised; scale [B, 4] -> pixels;
+    K0, K1 [B, 3, 3] (or [3, 3]) intrinsics.  Returns (Rt [B, 12] float64 = R row-major, t; mask [B, K] uint8 = cv2's `mask`
+    after recoverPose; good [B] int32 = recoverPose's count (0: no pose); info [B, 4] = found, RANSAC inliers, hypotheses, 0)."""
+    a = m0.detach().to(torch.float32).contiguous()
+    b = m1.detach().to(torch.float32).contiguous()
+    if a.dim() == 2:
+        a, b = a[None], b[None]
+    if not a.is_cuda:
+        raise RuntimeError("keypoint_bench_amd needs CUDA/HIP tensors; there is no CPU path")
+    dev = a.device
+    B, K = a.shape[0], a.shape[1]
+    sc = torch.as_tensor(scale, dtype=torch.float32).reshape(-1, 4)
+    sc = (sc.expand(B, 4) if sc.shape[0] == 1 else sc).contiguous().to(dev)
+    k0 = torch.as_tensor(K0).detach().cpu().numpy()
+    k1 = torch.as_tensor(K1).detach().cpu().numpy()
+    f32 = k0.dtype == np.float32 and k1.dtype == np.float32         # numpy keeps float32 keypoints / float32 K in float32 (AUC.py:44-48)
+    if not f32:
+        k0, k1 = k0.astype(np.float64), k1.astype(np.float64)
+    k0 = np.broadcast_to(k0.reshape(-1, 3, 3), (B, 3, 3))
+    k1 = np.broadcast_to(k1.reshape(-1, 3, 3), (B, 3, 3))
+    cam = np.stack([k0[:, 0, 2], k0[:, 1, 2], k0[:, 0, 0], k0[:, 1, 1], k1[:, 0, 2], k1[:, 1, 2], k1[:, 0, 0], k1[:, 1, 1]], 1)
+    f_mean = np.mean(np.stack([k0[:, 0, 0], k1[:, 1, 1], k0[:, 0, 0], k1[:, 1, 1]], 1), axis=1)              # AUC.py:44 (as written there), in K's dtype
+    thr = (thresh / f_mean).astype(np.float64)
+    cam_d = torch.from_numpy(np.ascontiguousarray(cam, np.float64)).to(dev)
+    thr_d = torch.from_numpy(np.ascontiguousarray(thr)).to(dev)
+    E = torch.zeros((B, 9), dtype=torch.float64, device=dev)
+    mask = torch.zeros((B, max(K, 1)), dtype=torch.uint8, device=dev)
+    mask2 = torch.zeros((B, max(K, 1)), dtype=torch.uint8, device=dev)
+    info = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    pts = torch.empty((B, max(K, 1), 4), dtype=torch.float64, device=dev)
+    rt = torch.zeros((B, 12), dtype=torch.float64, device=dev)
+    good = torch.zeros((B,), dtype=torch.int32, device=dev)
+    ctx = Context.get(dev)
+    ctx.check(ctx.lib.kpb_find_essential(ctx.handle, ptr(a), a.shape[2], ptr(b), b.shape[2], B, K, ptr(k_dev), ptr(sc), ptr(cam_d), 1 if f32 else 0, ptr(thr_d),
+                                         ptr(_seeds(seeds, B, dev)), ctypes.c_uint32(int(seed) & 0xFFFFFFFF), float(conf), int(max_iters), ptr(E),
+                                         ptr(mask), ptr(info), ptr(pts)))
+    ctx.check(ctx.lib.kpb_recover_pose(ctx.handle, ptr(E), ptr(pts), ptr(mask), B, K, ptr(k_dev), ptr(info), 1e9, ptr(rt), ptr(mask2), ptr(good)))
+    return rt, mask2[:, :K], good, info

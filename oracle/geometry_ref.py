@@ -263,3 +263,301 @@ def mha_corner_error(H, real_H, h, w, resize_h, resize_w):
     real = real * np.array([resize_h / h, resize_w / w])
     est = est * np.array([resize_h / h, resize_w / w])
     return np.mean(np.linalg.norm(real - est, axis=1))
+
+
+# ================================================================================================ essential matrix
+# cv2.findEssentialMat(k0, k1, eye(3), threshold, prob, RANSAC) + cv2.recoverPose as tasks/AUC.py:50-64 calls them, restated
+# from the published algorithm (Nister's five-point solver, as OpenCV implements it) -- PARITY UNPINNED, see the module
+# docstring.  Defaults of the call: maxIters 1000, 5-point samples, Sampson error against threshold^2, no refinement of
+# the winning model; recoverPose: the (R, t) of the four decompositions with the most points in front of both cameras.
+#
+# Five-point solver, per sample:
+#   1. the 5 x 9 epipolar constraints; their 4-dimensional null space by Gauss-Jordan elimination with row pivoting
+#      (basis rows X, Y, Z, W; E = x X + y Y + z Z + W);
+#   2. det(E) = 0 and 2 E E^T E - tr(E E^T) E = 0: ten cubics in (x, y, z), expanded by polynomial arithmetic into a
+#      10 x 20 matrix over the monomials MONO (Nister's order);
+#   3. Gauss-Jordan on the ten leading monomials; rows e - z f, g - z h, i - z j form a 3 x 3 matrix B(z) of polynomials
+#      (degrees 3, 3, 4) acting on (x, y, 1); det B(z) is the tenth-degree polynomial;
+#   4. its roots by Aberth-Ehrlich iteration from a fixed start; real ones polished by Newton on the real polynomial;
+#   5. (x, y) from the null vector of B(z), E from the basis.
+E_MAX_ITERS = 1000
+E_MODEL_POINTS = 5
+ABERTH_ITERS = 40
+
+# exponents (i, j, k) of x^i y^j z^k, Nister's order: ten leading monomials, then the ten of the quotient ring
+MONO = [(3, 0, 0), (0, 3, 0), (2, 1, 0), (1, 2, 0), (2, 0, 1), (2, 0, 0), (0, 2, 1), (0, 2, 0), (1, 1, 1), (1, 1, 0),
+        (1, 0, 2), (1, 0, 1), (1, 0, 0), (0, 1, 2), (0, 1, 1), (0, 1, 0), (0, 0, 3), (0, 0, 2), (0, 0, 1), (0, 0, 0)]
+_MIDX = {m: i for i, m in enumerate(MONO)}
+_LIN = [(1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)]                      # x, y, z, 1: how an entry of E is stored
+_DEG2 = [(2, 0, 0), (1, 1, 0), (1, 0, 1), (0, 2, 0), (0, 1, 1), (0, 0, 2), (1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)]
+_D2IDX = {m: i for i, m in enumerate(_DEG2)}
+# product tables: (deg-1 index, deg-1 index) -> deg-2 index; (deg-2 index, deg-1 index) -> MONO index
+MUL11 = np.array([[_D2IDX[tuple(a + b for a, b in zip(p, q))] for q in _LIN] for p in _LIN])
+MUL21 = np.array([[_MIDX[tuple(a + b for a, b in zip(p, q))] for q in _LIN] for p in _DEG2])
+D2_TO_MONO = np.array([_MIDX[m] for m in _DEG2])
+
+
+def _pmul11(a, b):
+    """[T,4] x [T,4] linear polynomials -> [T,10] quadratic."""
+    out = np.zeros(a.shape[:-1] + (10,))
+    for i in range(4):
+        for j in range(4):
+            out[..., MUL11[i, j]] += a[..., i] * b[..., j]
+    return out
+
+
+def _pmul21(a, b):
+    """[T,10] quadratic x [T,4] linear -> [T,20] cubic over MONO."""
+    out = np.zeros(a.shape[:-1] + (20,))
+    for i in range(10):
+        for j in range(4):
+            out[..., MUL21[i, j]] += a[..., i] * b[..., j]
+    return out
+
+
+def _gauss_jordan(M, ncol):
+    """Reduces the first `ncol` columns of each [T, r, c] matrix to the identity (row pivoting).  Returns (M, ok)."""
+    M = M.copy()
+    T, r, _ = M.shape
+    ok = np.ones(T, bool)
+    ar = np.arange(T)
+    for c in range(ncol):
+        piv = c + np.argmax(np.abs(M[:, c:, c]), axis=1)
+        tmp = M[ar, c].copy()
+        M[ar, c] = M[ar, piv]
+        M[ar, piv] = tmp
+        d = M[:, c, c]
+        good = np.abs(d) > 1e-300
+        ok &= good
+        M[:, c] = M[:, c] / np.where(good, d, 1.0)[:, None]
+        for rr in range(r):
+            if rr != c:
+                M[:, rr] = M[:, rr] - M[:, rr, c][:, None] * M[:, c]
+    return M, ok
+
+
+def _polymul(a, b):
+    """Coefficient arrays, ascending powers: [T, na] * [T, nb] -> [T, na + nb - 1]."""
+    out = np.zeros((a.shape[0], a.shape[1] + b.shape[1] - 1))
+    for i in range(a.shape[1]):
+        out[:, i:i + b.shape[1]] += a[:, i:i + 1] * b
+    return out
+
+
+def _polyval(c, z):
+    """c [T, n] ascending, z [T, ...] (real or complex) -> values."""
+    v = np.zeros_like(z) + c[:, -1].reshape((-1,) + (1,) * (z.ndim - 1))
+    for i in range(c.shape[1] - 2, -1, -1):
+        v = v * z + c[:, i].reshape((-1,) + (1,) * (z.ndim - 1))
+    return v
+
+
+def aberth_roots(c, iters=ABERTH_ITERS):
+    """All complex roots of the degree-10 polynomials c [T, 11] (ascending powers) by Aberth-Ehrlich iteration from a
+    fixed circle of starting points scaled by the Cauchy bound.  Returns [T, 10] complex."""
+    T, n1 = c.shape
+    n = n1 - 1
+    lead = c[:, -1]
+    cn = c / np.where(lead == 0, 1.0, lead)[:, None]
+    # start on a circle whose radius is the geometric mean of the root moduli, |c0 / cn|^(1/n)
+    rad = np.abs(cn[:, 0]) ** (1.0 / n)
+    rad = np.clip(np.where(np.isfinite(rad) & (rad > 0), rad, 1.0), 1e-3, 1e3)
+    k = np.arange(n)
+    z = rad[:, None] * np.exp(1j * (2 * np.pi * k / n + 0.4))[None]
+    dc = cn[:, 1:] * np.arange(1, n1)[None]
+    for _ in range(iters):
+        p = _polyval(cn.astype(complex), z)
+        dp = _polyval(dc.astype(complex), z)
+        ratio = p / np.where(dp == 0, 1e-300, dp)
+        diff = z[:, :, None] - z[:, None, :]
+        diff[:, k, k] = 1.0
+        inv = 1.0 / np.where(diff == 0, 1e-300, diff)
+        inv[:, k, k] = 0.0
+        s = inv.sum(2)
+        z = z - ratio / (1.0 - ratio * s)
+    return z
+
+
+def essential_5pt(x1, x2):
+    """Five-point solver for T samples: x1, x2 [T, 5, 2] normalised image points (x2^T E x1 = 0).
+    Returns (E [T, 10, 3, 3], valid [T, 10]): up to ten candidates per sample, Frobenius norm 1."""
+    T = x1.shape[0]
+    u1, v1, u2, v2 = x1[..., 0], x1[..., 1], x2[..., 0], x2[..., 1]
+    Q = np.stack([u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, np.ones_like(u1)], -1)        # [T, 5, 9]
+    Qr, ok = _gauss_jordan(Q, 5)                       # [I | C]: null space rows n_j = (-C[:, j], e_j), j = 0..3
+    basis = np.zeros((T, 4, 9))
+    basis[:, :, :5] = -np.swapaxes(Qr[:, :, 5:], 1, 2)
+    basis[:, np.arange(4), 5 + np.arange(4)] = 1.0
+    Ep = np.swapaxes(basis, 1, 2).reshape(T, 3, 3, 4)  # entry (r, c) as a linear polynomial over (x, y, z, 1)
+    # E E^T (quadratic entries), its trace, det E, and the nine cubics of 2 E E^T E - tr(E E^T) E
+    EEt = np.zeros((T, 3, 3, 10))
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                EEt[:, i, j] += _pmul11(Ep[:, i, k], Ep[:, j, k])
+    tr = EEt[:, 0, 0] + EEt[:, 1, 1] + EEt[:, 2, 2]
+    M = np.zeros((T, 10, 20))
+    r = 0
+    for i in range(3):
+        for j in range(3):
+            acc = np.zeros((T, 20))
+            for k in range(3):
+                acc += 2.0 * _pmul21(EEt[:, i, k], Ep[:, k, j])
+            acc -= _pmul21(tr, Ep[:, i, j])
+            M[:, r] = acc
+            r += 1
+    m01 = _pmul11(Ep[:, 1, 1], Ep[:, 2, 2]) - _pmul11(Ep[:, 1, 2], Ep[:, 2, 1])
+    m02 = _pmul11(Ep[:, 1, 2], Ep[:, 2, 0]) - _pmul11(Ep[:, 1, 0], Ep[:, 2, 2])
+    m03 = _pmul11(Ep[:, 1, 0], Ep[:, 2, 1]) - _pmul11(Ep[:, 1, 1], Ep[:, 2, 0])
+    M[:, 9] = _pmul21(m01, Ep[:, 0, 0]) + _pmul21(m02, Ep[:, 0, 1]) + _pmul21(m03, Ep[:, 0, 2])
+    Mr, ok2 = _gauss_jordan(M, 10)
+    ok &= ok2
+    R = Mr[:, :, 10:]                                  # trailing coefficients over [xz2, xz, x, yz2, yz, y, z3, z2, z, 1]
+
+    def row_polys(a, b):                               # <a> - z <b>: the (x, y, 1) parts as polynomials in z, ascending
+        px = np.stack([a[:, 2], a[:, 1] - b[:, 2], a[:, 0] - b[:, 1], -b[:, 0]], 1)
+        py = np.stack([a[:, 5], a[:, 4] - b[:, 5], a[:, 3] - b[:, 4], -b[:, 3]], 1)
+        p1 = np.stack([a[:, 9], a[:, 8] - b[:, 9], a[:, 7] - b[:, 8], a[:, 6] - b[:, 7], -b[:, 6]], 1)
+        return px, py, p1
+
+    B = [row_polys(R[:, 4], R[:, 5]), row_polys(R[:, 6], R[:, 7]), row_polys(R[:, 8], R[:, 9])]
+    det = (_polymul(_polymul(B[0][0], B[1][1]) - _polymul(B[0][1], B[1][0]), B[2][2])
+           + _polymul(_polymul(B[0][1], B[1][2]), B[2][0]) - _polymul(_polymul(B[0][2], B[1][1]), B[2][0])
+           + _polymul(_polymul(B[0][2], B[1][0]), B[2][1]) - _polymul(_polymul(B[0][0], B[1][2]), B[2][1]))      # [T, 11]
+    ok &= np.isfinite(det).all(1) & (np.abs(det[:, -1]) > 1e-300)
+    det = np.where(ok[:, None], det, np.r_[np.zeros(10), 1.0][None] + np.r_[-1.0, np.zeros(10)][None])   # z^10 - 1 for void samples
+    roots = aberth_roots(det)
+    zr = roots.real
+    cn = det / det[:, -1:]
+    dc = cn[:, 1:] * np.arange(1, 11)[None]
+    for _ in range(3):                                 # Newton polish on the real axis
+        p, dp = _polyval(cn, zr), _polyval(dc, zr)
+        zr = zr - p / np.where(dp == 0, 1e-300, dp)
+    real = (np.abs(roots.imag) < 1e-6 * (1.0 + np.abs(roots.real))) & np.isfinite(zr) & ok[:, None]
+    real &= np.abs(_polyval(cn, zr)) < 1e-6 * (1.0 + np.abs(_polyval(np.abs(cn), np.abs(zr))))
+    # (x, y, 1) = null vector of B(z): cross product of its first two rows
+    def ev(pz):
+        return _polyval(pz, zr)
+    b00, b01, b02 = ev(B[0][0]), ev(B[0][1]), ev(B[0][2])
+    b10, b11, b12 = ev(B[1][0]), ev(B[1][1]), ev(B[1][2])
+    cx, cy, cw = b01 * b12 - b02 * b11, b02 * b10 - b00 * b12, b00 * b11 - b01 * b10
+    real &= np.abs(cw) > 1e-300
+    cw = np.where(np.abs(cw) > 1e-300, cw, 1.0)
+    x, y = cx / cw, cy / cw
+    coef = np.stack([x, y, zr, np.ones_like(x)], -1)                   # [T, 10, 4]
+    E = np.einsum("tsk,tkn->tsn", coef, basis).reshape(T, 10, 3, 3)
+    nrm = np.sqrt((E * E).sum((2, 3)))
+    real &= np.isfinite(nrm) & (nrm > 0)
+    E = E / np.where(real, nrm, 1.0)[:, :, None, None]
+    return E, real
+
+
+def sampson_err(E, x1, x2):
+    """OpenCV's EMEstimatorCallback::computeError: E [..., 3, 3], x1 / x2 [N, 2] -> [..., N]."""
+    X1 = np.concatenate([x1, np.ones((len(x1), 1))], 1)
+    X2 = np.concatenate([x2, np.ones((len(x2), 1))], 1)
+    Ex1 = np.einsum("...ij,nj->...ni", E, X1)
+    Etx2 = np.einsum("...ji,nj->...ni", E, X2)
+    x2tEx1 = (Ex1 * X2).sum(-1)
+    den = Ex1[..., 0] ** 2 + Ex1[..., 1] ** 2 + Etx2[..., 0] ** 2 + Etx2[..., 1] ** 2
+    return x2tEx1 * x2tEx1 / np.where(den == 0, 1e-300, den)
+
+
+def find_essential_ransac(x1, x2, seed=0, threshold=1.0, prob=0.99999, max_iters=E_MAX_ITERS):
+    """cv2.findEssentialMat(x1, x2, eye(3), threshold, prob, RANSAC) restated.  x1, x2 [N, 2] normalised coordinates.
+    Returns (E [3,3] or None, mask [N] uint8, info)."""
+    x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
+    n = len(x1)
+    mask = np.zeros(n, np.uint8)
+    if n < 5:
+        return None, mask, dict(iters=0, inliers=0)
+    t2 = threshold * threshold
+    best_cnt, best_E, niters, done = 0, None, max_iters, 0
+    while done < niters:
+        its = np.arange(done, done + ROUND)
+        idx, ok = draw_samples(seed, its, n, 5)
+        E, valid = essential_5pt(x1[idx], x2[idx])
+        valid &= (ok & (its < max_iters))[:, None]
+        cnt = (sampson_err(E, x1, x2) <= t2).sum(-1)
+        cnt = np.where(valid, cnt, 0)                                   # [ROUND, 10]
+        flat = cnt.reshape(-1)
+        j = int(np.argmax(flat))                                       # first maximum: lowest iteration, then lowest root slot
+        if flat[j] > max(best_cnt, 4):
+            best_cnt, best_E = int(flat[j]), E[j // 10, j % 10]
+        done += ROUND
+        niters = update_iters(prob, (n - best_cnt) / n, 5, max_iters) if best_cnt else max_iters
+    if best_E is None:
+        return None, mask, dict(iters=done, inliers=0)
+    mask[sampson_err(best_E, x1, x2) <= t2] = 1
+    return best_E, mask, dict(iters=done, inliers=int(best_cnt))
+
+
+def decompose_essential(E):
+    """cv2.decomposeEssentialMat: R1 = U W Vt, R2 = U W^T Vt, t = U[:, 2] with det(U), det(Vt) forced positive."""
+    U, _, Vt = np.linalg.svd(E)
+    if np.linalg.det(U) < 0:
+        U = -U
+    if np.linalg.det(Vt) < 0:
+        Vt = -Vt
+    Wm = np.array([[0.0, 1, 0], [-1, 0, 0], [0, 0, 1]])
+    return U @ Wm @ Vt, U @ Wm.T @ Vt, U[:, 2]
+
+
+def recover_pose(E, x1, x2, mask, dist=1e9):
+    """cv2.recoverPose(E, x1, x2, eye(3), dist, mask): the decomposition with the most masked points in front of both
+    cameras (depths from the two-ray least-squares triangulation z1 R x1 + t = z2 x2; OpenCV triangulates by DLT -- the
+    depth SIGNS, which is all the count uses, agree except for points at infinity).  Returns (n, R, t, mask_new)."""
+    R1, R2, t = decompose_essential(E)
+    X1 = np.concatenate([x1, np.ones((len(x1), 1))], 1)
+    X2 = np.concatenate([x2, np.ones((len(x2), 1))], 1)
+    best = None
+    for R, tt in ((R1, t), (R2, t), (R1, -t), (R2, -t)):                # OpenCV's order; ties keep the earlier one
+        a = X1 @ R.T                                                    # R x1
+        # [a, -X2] [z1, z2]^T = -t  (least squares, 2 x 2 normal equations per point)
+        aa, ab, bb = (a * a).sum(1), -(a * X2).sum(1), (X2 * X2).sum(1)
+        ra, rb = -(a @ tt), (X2 @ tt)
+        det = aa * bb - ab * ab
+        det = np.where(np.abs(det) > 1e-300, det, 1e-300)
+        z1 = (ra * bb - ab * rb) / det
+        z2 = (aa * rb - ab * ra) / det
+        good = (z1 > 0) & (z1 < dist) & (z2 > 0) & (z2 < dist) & (mask > 0)
+        if best is None or good.sum() > best[0]:
+            best = (int(good.sum()), R, tt, good.astype(np.uint8))
+    return best
+
+
+def angle_error_mat(R1, R2):
+    """tasks/AUC.py:66-69."""
+    cos = (np.trace(np.dot(R1.T, R2)) - 1) / 2
+    cos = np.clip(cos, -1.0, 1.0)
+    return np.rad2deg(np.abs(np.arccos(cos)))
+
+
+def angle_error_vec(v1, v2):
+    """tasks/AUC.py:72-74."""
+    n = np.linalg.norm(v1) * np.linalg.norm(v2)
+    return np.rad2deg(np.arccos(np.clip(np.dot(v1, v2) / n, -1.0, 1.0)))
+
+
+def compute_pose_error(T_0to1, R, t):
+    """tasks/AUC.py:77-84."""
+    R_gt, t_gt = T_0to1[:3, :3], T_0to1[:3, 3]
+    error_t = angle_error_vec(t, t_gt)
+    error_t = np.minimum(error_t, 180 - error_t)
+    return error_t, angle_error_mat(R, R_gt)
+
+
+def estimate_pose(kpts0, kpts1, K0, K1, thresh, conf=0.99999, seed=0):
+    """tasks/AUC.py:40-64 with the two cv2 calls answered by the restatements above."""
+    if len(kpts0) < 5:
+        return None
+    f_mean = np.mean([K0[0, 0], K1[1, 1], K0[0, 0], K1[1, 1]])
+    norm_thresh = thresh / f_mean
+    k0 = (kpts0 - K0[[0, 1], [2, 2]][None]) / K0[[0, 1], [0, 1]][None]
+    k1 = (kpts1 - K1[[0, 1], [2, 2]][None]) / K1[[0, 1], [0, 1]][None]
+    E, mask, _ = find_essential_ransac(k0, k1, seed=seed, threshold=norm_thresh, prob=conf)
+    assert E is not None
+    n, R, t, mask_new = recover_pose(E, k0, k1, mask)
+    if n > 0:
+        return R, t, mask_new > 0
+    return None

@@ -101,3 +101,92 @@ def test_runner_mha_batched_equals_single_pair_rows():
     assert np.array_equal(rows1, rowsb)
     assert rows1[:, 2].mean() > 0.8, rows1            # a translation pair: the homography is found to well under 3 px
     assert aggb["MHA"] == agg1["MHA"] and len(aggb["MHA"]) == 5
+
+
+# ------------------------------------------------------------------------------------------------ essential matrix / AUC
+def test_batched_essential_and_pose_equal_oracle_and_ground_truth():
+    from keypoint_bench_amd.utils.mvg import estimate_pose
+    from test_oracle_geometry import scene
+    cases = [(800, 0.7, 0.5), (300, 0.5, 0.5), (1000, 0.9, 0.0), (6, 1.0, 0.0), (4, 1.0, 0.0), (120, 0.6, 0.3)]
+    B, K = len(cases), 1000
+    W, H, f = 640, 480, 500.0
+    Kc = np.array([[f, 0, 319.5], [0, f, 239.5], [0, 0, 1.0]])               # float64 intrinsics: numpy normalises in float64
+    m0, m1 = np.zeros((B, K, 3), np.float32), np.zeros((B, K, 3), np.float32)
+    kk = np.zeros(B, np.int32)
+    gt = []
+    for b, (n, share, noise) in enumerate(cases):
+        x1, x2, R, t, inl = scene(n, share, noise, 300 + b)
+        px1, px2 = x1 * f + [319.5, 239.5], x2 * f + [319.5, 239.5]
+        m0[b, :n, :2] = (px1 / [W - 1, H - 1]).astype(np.float32)
+        m1[b, :n, :2] = (px2 / [W - 1, H - 1]).astype(np.float32)
+        kk[b] = n
+        gt.append((R, t, inl))
+    seeds = np.arange(B) * 104729 + 11
+    t_ = lambda a: torch.from_numpy(a).to(DEV)
+    scale = np.array([W - 1, H - 1, W - 1, H - 1], np.float32)
+    rt, mask, good, info = estimate_pose(t_(m0), t_(m1), scale, Kc, Kc, thresh=1.0, k_dev=t_(kk), seeds=seeds)
+    rt, mask, good, info = rt.cpu().numpy(), mask.cpu().numpy(), good.cpu().numpy(), info.cpu().numpy()
+    for b, (n, share, noise) in enumerate(cases):
+        px0 = (m0[b, :n, :2] * scale[:2]).astype(np.float32)
+        px1 = (m1[b, :n, :2] * scale[2:]).astype(np.float32)
+        if n < 5:
+            assert info[b, 0] == 0 and good[b] == 0
+            continue
+        k0 = (px0 - Kc[[0, 1], [2, 2]][None]) / Kc[[0, 1], [0, 1]][None]
+        k1 = (px1 - Kc[[0, 1], [2, 2]][None]) / Kc[[0, 1], [0, 1]][None]
+        E, me, ie = g.find_essential_ransac(k0, k1, seed=int(seeds[b]), threshold=1.0 / f)
+        assert info[b, 0] == 1 and info[b, 2] == ie["iters"], (b, info[b], ie)
+        # same sampler and solver: the same winning hypothesis unless two hypotheses tie within rounding of a Sampson error
+        assert abs(int(info[b, 1]) - ie["inliers"]) <= 1, (b, info[b], ie)
+        nn, Rr, tt, mnew = g.recover_pose(E, k0, k1, me)
+        R, t = rt[b, :9].reshape(3, 3), rt[b, 9:]
+        if info[b, 1] == ie["inliers"]:
+            np.testing.assert_allclose(R, Rr, atol=1e-6, err_msg=str(b))
+            np.testing.assert_allclose(t, tt, atol=1e-6, err_msg=str(b))
+            assert abs(int(good[b]) - nn) <= 1 and (mask[b, :n] != mnew).sum() <= 2
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = gt[b][0], gt[b][1]
+        et, eR = g.compute_pose_error(T, R, t)
+        assert abs(np.linalg.det(R) - 1) < 1e-9 and et < 6.0 and eR < 2.5, (b, et, eR)
+
+
+@pytest.mark.parametrize("case", range(4))
+def test_auc_task_against_reference_fixture(case):
+    """Same inputs as the reference's auc saw; the estimator inside is this library's (seed = pair index on both sides)."""
+    from keypoint_bench_amd.tasks.AUC import auc
+    from test_oracle_geometry import auc_params
+    f = load_golden("auc.npz")
+    p = "c%d_" % case
+    prm = auc_params()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    w01 = {"intrinsics0": torch.from_numpy(f[p + "K"]), "intrinsics1": torch.from_numpy(f[p + "K"]), "pose01": torch.from_numpy(f[p + "T01"])}
+    Hs, Ws = f[p + "score0"].shape
+    img = torch.zeros((1, 3, Hs, Ws), device=DEV)
+    res = auc(case, img, t(f[p + "score0"])[None, None], t(f[p + "desc0"]), img, t(f[p + "score1"])[None, None], t(f[p + "desc1"]), w01, {}, prm)
+    want = f[p + "result"]
+    assert float(res["inliers"]) == want[1]
+    np.testing.assert_allclose(float(res["AUC"]), want[0], rtol=1e-6, atol=1e-6)
+
+
+def test_runner_auc_batched_equals_single_pair_rows():
+    from keypoint_bench_amd import runner, synthetic
+    EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=300, min_score=0.0)
+    prm = {"model_type": "Alike", "task_type": "AUC", "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64), "extractor_params": EP,
+           "matcher_params": {"type": "brute_force", "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
+           "AUC_params": {"th": [5, 10, 20], "output": "/tmp"}}
+    K = np.array([[120.0, 0, 63.5], [0, 120.0, 47.5], [0, 0, 1]], np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3] = 1.0               # the synthetic views differ by an image-plane shift: a sideways translation of a fronto-parallel plane
+    ds = []
+    for i in range(6):
+        v0, v1 = synthetic.image_pair(800 + i, 96, 128)
+        w = dict(mode="se3", intrinsics0=torch.from_numpy(K), intrinsics1=torch.from_numpy(K), pose01=torch.from_numpy(T))
+        ds.append({"image0": v0, "image1": v1, "dataset": "megaDepth", "warp01_params": w, "warp10_params": w})
+    single = runner.PairRunner(prm, device=DEV, batch=1)
+    agg1, rows1 = single.run(ds)
+    batched = runner.PairRunner(prm, device=DEV, batch=4)
+    aggb, rowsb = batched.run(ds)
+    assert single.batched_pairs == 0 and batched.batched_pairs == 6
+    assert np.array_equal(rows1, rowsb), (rows1, rowsb)
+    assert (rows1[:, 1] > 20).all()                    # inliers: the pose is supported by many matches
+    assert aggb["AUC"] == agg1["AUC"] and len(aggb["AUC"]) == 3
