@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--host", action="store_true")
     ap.add_argument("--dense", action="store_true")
-    ap.add_argument("--tasks", nargs="+", default=["match_stats", "repeatability", "MHA"])
+    ap.add_argument("--tasks", nargs="+", default=["match_stats", "repeatability", "MHA", "AUC"])
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -36,10 +36,13 @@ def main():
     if not args.host:
         views = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in views]
     ds = []
+    K = np.array([[500.0, 0, 319.5], [0, 500.0, 239.5], [0, 0, 1]], np.float32)
+    T01 = np.eye(4, dtype=np.float32)
+    T01[0, 3] = 1.0
     for i in range(args.pairs):
         v0, v1 = views[i % args.distinct]
         ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
-                   "warp01_params": dict(mode="homo", homography_matrix=h01, width=W, height=H),
+                   "warp01_params": dict(mode="homo", homography_matrix=h01, width=W, height=H, intrinsics0=K, intrinsics1=K, pose01=T01),
                    "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(h01).astype(np.float32), width=W, height=H)})
     out = {"pairs": args.pairs, "batch": args.batch, "items": "host numpy" if args.host else "device tensors",
            "descriptors": "dense-map" if args.dense else "keypoint-only"}
@@ -47,7 +50,7 @@ def main():
         params = {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),
                   "extractor_params": dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0),
                   "matcher_params": {"type": "brute_force", "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
-                  "repeatability_params": {"th": 3}, "MHA_params": {"th": [3, 5, 7]}}
+                  "repeatability_params": {"th": 3}, "MHA_params": {"th": [3, 5, 7]}, "AUC_params": {"th": [5, 10, 20]}}
         r = runner.PairRunner(params, device=dev, batch=args.batch, dense_descriptors=args.dense)
         try:
             agg, _ = r.run(ds)            # warm-up: allocations, first-shape workspaces
