@@ -20,6 +20,21 @@
 
 namespace {
 
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));     // one f16 MFMA operand (four VGPRs)
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float relu(float v);
+
+// fp32 x 4 -> (hi, lo) half-precision pairs: hi = f16(x) toward zero, lo = f16(x - hi) (x - hi is exact in fp32)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
+{
+    const h2v a = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)), b = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+    const h2v c = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x - (float)a[0], v.y - (float)a[1]));
+    const h2v d = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z - (float)b[0], v.w - (float)b[1]));
+    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
 
 // ------------------------------------------------------------------------------------------------ block1
 constexpr int B1_TH = 32, B1_TW = 32;
@@ -176,6 +191,166 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ block1, conv2 on the matrix cores
+// Same fusion as alike_block1 (3 -> 8 -> 8 through LDS), with the second convolution -- 73 % of the block's multiply-adds --
+// moved from the fp32 vector ALUs to v_mfma_f32_16x16x32_f16 on split operands (x = hi + lo halves, three MFMAs per
+// product: conv3x3_h16 has the numerics).  N = 8 output channels would waste half of a 16-wide MFMA, so one accumulator
+// row stands for a PAIR of horizontally adjacent pixels: N = (pixel of the pair s, output channel), and K runs over the
+// 3 x 4 input window the pair shares, 12 pieces of 8 channels = exactly three 32-deep k-blocks (kb = window row, lane
+// group g = window column); the weight of piece (ky, kx) for pixel s is w[ky][kx - s], zero outside the 3 x 3 kernel.
+// The intermediate map is written to LDS by conv1 already split, in planes [hi | lo][column parity][row][column / 2]
+// of 16-byte slots, so the 16 lanes of a read group hit 16 consecutive slots.  Rows go to global memory straight from
+// the accumulators: with pi(4 g + r) = g + 4 r one store instruction covers 8 adjacent pixels x 8 channels = 256 B; the
+// 2 x 2 max-pool block 2 starts with (ALike.py:139) is one lane swap (the pair) and one register kept per row pair.
+struct Block1HArgs {
+    Block1Args b;
+    const uint4* w2pk;   // [3 kb][hi / lo][64 lanes] fragments of conv2 (pack_b1c2_pairs)
+};
+
+__global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
+{
+    const Block1Args& a = ha.b;
+    constexpr int IH = B1_TH + 4, IW = B1_TW + 4, MH = B1_TH + 2, MW = B1_TW + 2, HW = MW / 2;        // HW: slots per row and parity
+    constexpr int PLANE = MH * HW, REGION = 2 * PLANE;
+    __shared__ float in[3][IH][IW];
+    __shared__ __attribute__((aligned(16))) uint4 mid[2 * REGION];          // [hi | lo][parity][row][column / 2]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
+    const int ty0 = blockIdx.y * B1_TH, tx0 = blockIdx.x * B1_TW;
+    const size_t P = (size_t)a.H * a.W;
+    const float* img = a.img + (size_t)b * 3 * P;
+    h8v bhi[3], blo[3];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        bhi[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 0) * 64 + lane]);
+        blo[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 1) * 64 + lane]);
+    }
+    {   // all of a thread's loads are issued before the first LDS store (one memory latency, not sixteen)
+        constexpr int N = 3 * IH * IW, PER = (N + 255) / 256;
+        float buf[PER];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * 256;
+            const int c = i / (IH * IW), rem = i - c * IH * IW;
+            const int y = rem / IW, x = rem - y * IW;
+            const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
+            buf[k] = 0.0f;
+            if (i < N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) buf[k] = img[c * P + (size_t)gy * a.W + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * 256;
+            if (i < N) (&in[0][0][0])[i] = buf[k];
+        }
+    }
+    __syncthreads();
+    // conv1 + ReLU on MH x MW positions, two per item (fp32 VALU: K = 27), written split into the parity planes
+    for (int it = tid; it < MH * (MW / 2); it += 256) {
+        const int my = it / (MW / 2), mx = (it - my * (MW / 2)) * 2;
+        float acc[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[q][j] = a.b1[j];
+#pragma unroll 1
+        for (int cky = 0; cky < 9; ++cky) {   // rolled: 24 scalar-loaded weights live per trip, no SGPR spills
+                const int c = cky / 3, ky = cky - 3 * c;
+                float v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = in[c][my + ky][mx + k];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float w = a.w1[((c * 3 + ky) * 3 + kx) * 8 + j];
+                        acc[0][j] = fmaf(v[kx], w, acc[0][j]);
+                        acc[1][j] = fmaf(v[kx + 1], w, acc[1][j]);
+                    }
+            }
+        const int gy = ty0 - 1 + my;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int gx = tx0 - 1 + mx + q;
+            // conv2 pads its INPUT (the ReLU'd map) with zeros outside the image
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = inside ? relu(acc[q][j]) : 0.0f;
+            uint2 h0, l0, h1, l1;
+            split4(make_float4(f[0], f[1], f[2], f[3]), h0, l0);
+            split4(make_float4(f[4], f[5], f[6], f[7]), h1, l1);
+            const int slot = q * PLANE + my * HW + (mx >> 1);          // mx is even: pixel mx + q has parity q
+            mid[slot] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            mid[REGION + slot] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    }
+    __syncthreads();
+    // conv2 + ReLU on the matrix cores: a wave owns rows 8 wv .. 8 wv + 7 of the tile, one 32-pixel row = 16 pairs per MFMA group
+    const int i16 = lane & 15, g = lane >> 4;
+    const int pr = (i16 >> 2) + 4 * (i16 & 3);                        // pi(i): the pixel pair this lane's A row stands for
+    // piece (ky = kb, kx = g) of pair pr: tile column 2 pr + g of row + kb -> parity g & 1, slot pr + (g >> 1)
+    const int abase = (g & 1) * PLANE + pr + (g >> 1);
+    const int sN = i16 >> 3, co = i16 & 7;                            // this lane's output: pixel s of the pair, channel co
+    const float bias = a.b2[co];
+    const int H2 = a.H / 2, W2 = a.W / 2;
+    float keep[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int rr = 0; rr < 8; ++rr) {
+        const int row = 8 * wv + rr;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            const int at = abase + (row + kb) * HW;
+            const h8v ahi = __builtin_bit_cast(h8v, mid[at]);
+            const h8v alo = __builtin_bit_cast(h8v, mid[REGION + at]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[kb], acc, 0, 0, 0);      // small terms first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[kb], acc, 0, 0, 0);
+        }
+        const int gy = ty0 + row;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r] = relu(acc[r] + bias);
+            const int gx = tx0 + 2 * (g + 4 * r) + sN;                 // pair pi(4 g + r) = g + 4 r
+            if (gy < a.H && gx < a.W) a.x1[((size_t)b * P + (size_t)gy * a.W + gx) * 8 + co] = v[r];
+        }
+        if ((rr & 1) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = v[r];
+        } else {        // max_pool2d(x1, 2, 2): the row pair in registers, the pixel pair one lane swap away
+            const int py = gy >> 1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m = fmaxf(keep[r], v[r]);
+                m = fmaxf(m, __shfl_xor(m, 8, 64));
+                const int pxl = (tx0 >> 1) + g + 4 * r;
+                if (sN == 0 && py < H2 && pxl < W2) a.p1[(((size_t)b * H2 + py) * W2 + pxl) * 8 + co] = m;
+            }
+        }
+    }
+}
+
+// conv2 of block 1, OIHW [8][8][3][3] -> alike_block1_h fragments [3 kb = ky][hi / lo][64 lanes][8 halves = cin]:
+// lane (n = (s, cout), g = kx of the 3 x 4 window) holds w[cout][cin][ky][kx - s] (zero outside the kernel)
+std::vector<float> pack_b1c2_pairs(const float* w)
+{
+    std::vector<uint16_t> hl((size_t)3 * 2 * 64 * 8, 0);
+    for (int kb = 0; kb < 3; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int n = l & 15, g = l >> 4, s2 = n >> 3, co = n & 7, kx = g - s2;
+                const float v = (kx >= 0 && kx <= 2) ? w[((size_t)co * 8 + j) * 9 + kb * 3 + kx] : 0.0f;
+                _Float16 hi = (_Float16)v;
+                if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                memcpy(&hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j], &hi, 2);
+                memcpy(&hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j], &lo, 2);
+            }
+    std::vector<float> out(hl.size() / 2);
+    memcpy(out.data(), hl.data(), hl.size() * 2);
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------------ conv3x3
 struct ConvArgs {
     const float* in;     // [B][H*POOL][W*POOL][CIN]
@@ -309,6 +484,144 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
         if (RELU) { v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w); }
         *reinterpret_cast<float4*>(o + 4 * q) = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ conv3x3, split-f16 MFMA
+// The 3x3 convolutions of block 2 (8 -> 16 and 16 -> 16 at H/2) as implicit GEMMs on v_mfma_f32_16x16x32_f16 with every fp32
+// operand split into two half-precision terms (x = hi + lo, hi = f16(x) toward zero, lo = f16(x - hi); three MFMAs per
+// product, the lo.lo term dropped: relative 2^-22 per product, fp32 accumulation -- see alike_head_f16).  fp32 MFMA and the
+// fp32 VALU share one rate on gfx950 (157 TFLOP/s); the f16 matrix rate is 16x that, so even at three MFMAs per product
+// these layers leave the arithmetic roofline and become HBM-bound.
+//   M = 16 consecutive pixels of an image row, N = the 16 output channels, K = 32 per MFMA = four 16-byte pieces, piece
+//   kidx = (tap, channel octet): lane (row i, group g) of k-block kb supplies piece 4 kb + g of pixel pi(i).
+//   The input tile sits in LDS already split, as planes of 16-byte slots [hi | lo][octet][position]: a lane's A operand is
+//   ONE ds_read_b128 per plane, 16 consecutive slots per 16 lanes (conflict-free).  The weights of a lane (<= 5 k-blocks x
+//   hi / lo x 16 bytes) stay in registers for the whole kernel.  RES folds the block's identity branch -- the 1x1
+//   convolution of the pooled block input, ALike.py:76-79 -- in as one more 16-byte piece of K (free: K = 152 <= 160).
+//   pi(4 g + r) = g + 4 r: accumulator register r of the four lane groups then holds four ADJACENT pixels, so one store
+//   instruction writes 4 pixels x 16 channels = 256 contiguous bytes.
+struct H16Args {
+    const float* in;      // [B][H][W][CIN]
+    const float* res_in;  // RES: [B][H][W][8]
+    float* out;           // [B][H][W][16]
+    const uint4* wpk;     // [KB][hi / lo][64 lanes] fragments (pack_h16)
+    const float* bias;    // [16] (RES: conv bias + identity-branch bias)
+    int H, W;
+};
+
+
+template <int CIN, bool RES>
+__global__ __launch_bounds__(256) void conv3x3_h16(H16Args a)
+{
+    constexpr int OCT = CIN / 8, TH = 8, TW = 32, LW = TW + 2, NPOS = (TH + 2) * LW;
+    constexpr int NPL = OCT + (RES ? 1 : 0);                  // planes per half: input octets (+ the identity-branch input)
+    constexpr int NK = 9 * OCT + (RES ? 1 : 0), KB = (NK + 3) / 4;
+    constexpr int REGION = NPL * NPOS;                        // slots of the hi half; the lo half follows; then one zero slot
+    __shared__ __attribute__((aligned(16))) uint4 lds[2 * REGION + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const float* in = a.in + (size_t)b * a.H * a.W * CIN;
+
+    // this lane's weight fragments: registers for the whole kernel
+    h8v bhi[KB], blo[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        bhi[kb] = __builtin_bit_cast(h8v, a.wpk[(kb * 2 + 0) * 64 + lane]);
+        blo[kb] = __builtin_bit_cast(h8v, a.wpk[(kb * 2 + 1) * 64 + lane]);
+    }
+    // stage the (TH+2) x (TW+2) input tile, split, zero outside the image (the convolution's padding)
+    for (int i = tid; i < NPOS * (CIN / 4); i += 256) {
+        const int pos = i / (CIN / 4), q = i - pos * (CIN / 4);
+        const int y = pos / LW, x = pos - y * LW;
+        const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.W + gx) * CIN + 4 * q);
+        uint2 hi, lo;
+        split4(v, hi, lo);
+        uint2* dh = reinterpret_cast<uint2*>(&lds[(q >> 1) * NPOS + pos]) + (q & 1);
+        dh[0] = hi;
+        dh[2 * REGION] = lo;            // uint2 units: the lo half starts REGION uint4 slots later
+    }
+    if (RES) {      // the identity branch reads the centre pixels only
+        const float* rin = a.res_in + (size_t)b * a.H * a.W * 8;
+        for (int i = tid; i < TH * TW * 2; i += 256) {
+            const int px = i >> 1, q = i & 1;
+            const int y = px / TW, x = px - y * TW;
+            const int gy = ty0 + y, gx = tx0 + x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < a.H && gx < a.W) v = *reinterpret_cast<const float4*>(rin + ((size_t)gy * a.W + gx) * 8 + 4 * q);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            uint2* dh = reinterpret_cast<uint2*>(&lds[OCT * NPOS + (y + 1) * LW + x + 1]) + q;
+            dh[0] = hi;
+            dh[2 * REGION] = lo;
+        }
+    }
+    if (tid == 0) lds[2 * REGION] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    const int i16 = lane & 15, g = lane >> 4;
+    const int px = (i16 >> 2) + 4 * (i16 & 3);                // pi(i): the pixel of the group this lane's A row stands for
+    int aoff[KB];                                             // slot offset of piece 4 kb + g relative to the group's first pixel; -1: no such piece
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const int kidx = 4 * kb + g;
+        if (kidx < 9 * OCT) {
+            const int tap = kidx / OCT, o = kidx - tap * OCT;
+            aoff[kb] = o * NPOS + (tap / 3) * LW + (tap % 3);
+        } else if (RES && kidx == 9 * OCT) {
+            aoff[kb] = OCT * NPOS + LW + 1;
+        } else {
+            aoff[kb] = -1;
+        }
+    }
+    const float bias = a.bias[i16];
+    float* out = a.out + (size_t)b * a.H * a.W * 16;
+#pragma unroll 1
+    for (int gi = 4 * wv; gi < 4 * wv + 4; ++gi) {            // 16 groups of 16 pixels per tile, four per wave
+        const int row = gi >> 1, col0 = (gi & 1) * 16;
+        const int base = row * LW + col0 + px;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const int at = aoff[kb] >= 0 ? base + aoff[kb] : 2 * REGION;
+            const h8v ahi = __builtin_bit_cast(h8v, lds[at]);
+            const h8v alo = __builtin_bit_cast(h8v, lds[aoff[kb] >= 0 ? at + REGION : 2 * REGION]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[kb], acc, 0, 0, 0);      // small terms first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[kb], acc, 0, 0, 0);
+        }
+        // D: lane holds channel i16 of pixels pi(4 g + r) = g + 4 r
+        const int gy = ty0 + row;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gx = tx0 + col0 + g + 4 * r;
+            if (gy < a.H && gx < a.W) out[((size_t)gy * a.W + gx) * 16 + i16] = relu(acc[r] + bias);
+        }
+    }
+}
+
+// OIHW [16][CIN][3][3] (+ identity-branch [16][8]) -> conv3x3_h16 fragments [KB][hi / lo][64 lanes][8 halves], as floats (bit patterns)
+std::vector<float> pack_h16(const float* w, int CIN, const float* ds_w)
+{
+    const int OCT = CIN / 8, NK = 9 * OCT + (ds_w ? 1 : 0), KB = (NK + 3) / 4;
+    std::vector<uint16_t> hl((size_t)KB * 2 * 64 * 8, 0);
+    for (int kb = 0; kb < KB; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int n = l & 15, g = l >> 4, kidx = 4 * kb + g;
+                float v = 0.0f;
+                if (kidx < 9 * OCT) { const int tap = kidx / OCT, o = kidx - tap * OCT; v = w[((size_t)n * CIN + 8 * o + j) * 9 + tap]; }
+                else if (ds_w && kidx == 9 * OCT) v = ds_w[n * 8 + j];
+                _Float16 hi = (_Float16)v;
+                if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                memcpy(&hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j], &hi, 2);
+                memcpy(&hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j], &lo, 2);
+            }
+    std::vector<float> out(hl.size() / 2);
+    memcpy(out.data(), hl.data(), hl.size() * 2);
+    return out;
 }
 
 // ------------------------------------------------------------------------------------------------ 1x1 + ReLU
@@ -648,9 +961,6 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
 // does not depend on a reduced-precision mode: x - hi is exact in fp32.  The coarse groups' ten tap steps stay on the
 // fp32 MFMA (their B operand is the y-interpolated strip, rebuilt per row; K = 10).
 // Per 32-pixel tile: 12 f16 MFMAs (32 cycles) + 10 fp32 MFMAs (64 cycles) = 1024 matrix cycles instead of 2688.
-typedef _Float16 h8v __attribute__((ext_vector_type(8)));
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
 {
 #pragma unroll
@@ -1061,14 +1371,28 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     hipStream_t st = ctx->stream;
 
     Block1Args b1{img_dev, x1, p1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
+    static const int b1h = kpb_env_int("KPB_BLOCK1_H16", 1);
+    if (b1h) {
+        Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c2.pairs"))};
+        KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, hb);
+    } else
     KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
 
     ConvArgs c;
     // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
     c = ConvArgs{p1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};      // pooled by block1
-    launch_conv<8, 16, 1, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
-    c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), p1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
-    launch_conv<16, 16, 1, true, 8, 1>(ctx, "conv3x3_b2c2", st, c, batch);
+    static const int h16 = kpb_env_int("KPB_CONV_H16", 1);
+    if (h16) {
+        const dim3 grid(cdiv(W / 2, 32), cdiv(H / 2, 8), batch);
+        H16Args h1{p1, nullptr, t2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), wp("b2c1.b"), H / 2, W / 2};
+        KPB_LAUNCH(ctx, "conv3x3_b2c1", (conv3x3_h16<8, false>), grid, dim3(256), 0, st, h1);
+        H16Args h2{t2, p1, x2, reinterpret_cast<const uint4*>(wp("b2c2.h16")), wp("b2c2.bsum"), H / 2, W / 2};
+        KPB_LAUNCH(ctx, "conv3x3_b2c2", (conv3x3_h16<16, true>), grid, dim3(256), 0, st, h2);
+    } else {
+        launch_conv<8, 16, 1, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
+        c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), p1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
+        launch_conv<16, 16, 1, true, 8, 1>(ctx, "conv3x3_b2c2", st, c, batch);
+    }
     // block3 @ H/8 (141-142): pool4
     c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
     launch_conv<16, 32, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b3c1", st, c, batch);        // 80 columns at 480x640: 16-wide tiles divide them
@@ -1156,6 +1480,7 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         ws.put("b1c1.w", tmp);
         ws.put_raw("b1c1.b", bl.get("b1c1.b", {c1}), 8);
         repack3x3(bl.get("b1c2.w", {c1, c1, 3, 3}), 8, 8, tmp); ws.put("b1c2.w", tmp);
+        ws.put("b1c2.pairs", pack_b1c2_pairs(bl.get("b1c2.w", {c1, c1, 3, 3})));
         ws.put_raw("b1c2.b", bl.get("b1c2.b", {c1}), 8);
     }
     const uint32_t ch[5] = {0, c1, c2, c3, c4};
@@ -1168,6 +1493,15 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         snprintf(nm, 16, "b%dc2.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
         snprintf(nm, 16, "b%dds.w", i); transpose(bl.get(nm, {co, ci}), co, ci, tmp); ws.put(nm, tmp);
         snprintf(nm, 16, "b%dds.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
+    }
+    {   // block 2 on the split-f16 MFMA kernel: fragments + combined biases
+        ws.put("b2c1.h16", pack_h16(bl.get("b2c1.w", {c2, c1, 3, 3}), 8, nullptr));
+        ws.put("b2c2.h16", pack_h16(bl.get("b2c2.w", {c2, c2, 3, 3}), 16, bl.get("b2ds.w", {c2, c1})));
+        const float* b2 = bl.get("b2c2.b", {c2});
+        const float* bd = bl.get("b2ds.b", {c2});
+        tmp.assign(16, 0.f);
+        for (int i = 0; i < 16; ++i) tmp[i] = b2[i] + bd[i];
+        ws.put("b2c2.bsum", tmp);
     }
     ws.put("b3c2.wp", pack_mfma(bl.get("b3c2.w", {c3, c3, 3, 3}), 32, 32, 3, 32, 1));
     ws.put("b3c2.bp", pad_bias(bl.get("b3c2.b", {c3}), 32, 32));
