@@ -191,111 +191,123 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------ block1, conv2 on the matrix cores
-// Same fusion as alike_block1 (3 -> 8 -> 8 through LDS), with the second convolution -- 73 % of the block's multiply-adds --
-// moved from the fp32 vector ALUs to v_mfma_f32_16x16x32_f16 on split operands (x = hi + lo halves, three MFMAs per
-// product: conv3x3_h16 has the numerics).  N = 8 output channels would waste half of a 16-wide MFMA, so one accumulator
-// row stands for a PAIR of horizontally adjacent pixels: N = (pixel of the pair s, output channel), and K runs over the
-// 3 x 4 input window the pair shares, 12 pieces of 8 channels = exactly three 32-deep k-blocks (kb = window row, lane
-// group g = window column); the weight of piece (ky, kx) for pixel s is w[ky][kx - s], zero outside the 3 x 3 kernel.
-// The intermediate map is written to LDS by conv1 already split, in planes [hi | lo][column parity][row][column / 2]
-// of 16-byte slots, so the 16 lanes of a read group hit 16 consecutive slots.  Rows go to global memory straight from
-// the accumulators: with pi(4 g + r) = g + 4 r one store instruction covers 8 adjacent pixels x 8 channels = 256 B; the
-// 2 x 2 max-pool block 2 starts with (ALike.py:139) is one lane swap (the pair) and one register kept per row pair.
+// ------------------------------------------------------------------------------------------------ block1 on the matrix cores
+// Same fusion as alike_block1 (3 -> 8 -> 8 through LDS), with BOTH convolutions moved from the fp32 vector ALUs to
+// v_mfma_f32_16x16x32_f16 on split operands (x = hi + lo halves, three MFMAs per product: conv3x3_h16 has the numerics).
+// N = 8 output channels would waste half of a 16-wide MFMA, so one accumulator row stands for a PAIR of horizontally
+// adjacent pixels: N = (pixel of the pair s, output channel), and K runs over the 3 x 4 input window the pair shares; the
+// weight of window cell (ky, kx) for pixel s is w[ky][kx - s], zero outside the 3 x 3 kernel.
+//   conv2 (8 -> 8): 12 pieces of 8 channels = exactly three 32-deep k-blocks (kb = window row, lane group g = window column).
+//   conv1 (3 -> 8): the image tile is staged as [position][c0 c1 c2 0] halves (8 bytes), so a piece = two adjacent window
+//     cells; 6 pieces = two k-blocks (the second half empty); its accumulators go back to LDS split, two channels per
+//     32-bit write after one lane swap, in planes [hi | lo][column parity][row][column / 2] of 16-byte slots -- the layout
+//     in which the 16 lanes of conv2's read groups hit 16 consecutive slots.
+// Rows go to global memory straight from the accumulators: with pi(4 g + r) = g + 4 r one store instruction covers 8 adjacent
+// pixels x 8 channels = 256 B; the 2 x 2 max-pool block 2 starts with (ALike.py:139) is one lane swap (the pair) and one
+// register kept per row pair.  16 x 32 tiles: 31 KB of LDS, five workgroups per CU.
 struct Block1HArgs {
     Block1Args b;
+    const uint4* w1pk;   // [2 kb][hi / lo][64 lanes] fragments of conv1 (pack_b1c1_pairs)
     const uint4* w2pk;   // [3 kb][hi / lo][64 lanes] fragments of conv2 (pack_b1c2_pairs)
 };
+
+constexpr int B1H_TH = 16;
 
 __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
 {
     const Block1Args& a = ha.b;
-    constexpr int IH = B1_TH + 4, IW = B1_TW + 4, MH = B1_TH + 2, MW = B1_TW + 2, HW = MW / 2;        // HW: slots per row and parity
-    constexpr int PLANE = MH * HW, REGION = 2 * PLANE;
-    __shared__ float in[3][IH][IW];
+    constexpr int TH = B1H_TH, IH = TH + 4, IW = B1_TW + 4, MH = TH + 2, MW = B1_TW + 2, HW = MW / 2;     // HW: slots per row and parity
+    constexpr int PLANE = MH * HW, REGION = 2 * PLANE, NIN = IH * IW, NPAIR = MH * HW, NGRP = (NPAIR + 15) / 16;
+    __shared__ __attribute__((aligned(16))) uint2 inh[2 * NIN + 2];        // [hi | lo][position] = (c0 c1 c2 0) halves; + a zero piece
     __shared__ __attribute__((aligned(16))) uint4 mid[2 * REGION];          // [hi | lo][parity][row][column / 2]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
-    const int ty0 = blockIdx.y * B1_TH, tx0 = blockIdx.x * B1_TW;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * B1_TW;
     const size_t P = (size_t)a.H * a.W;
     const float* img = a.img + (size_t)b * 3 * P;
-    h8v bhi[3], blo[3];
+    h8v c1hi[2], c1lo[2], bhi[3], blo[3];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        c1hi[kb] = __builtin_bit_cast(h8v, ha.w1pk[(kb * 2 + 0) * 64 + lane]);
+        c1lo[kb] = __builtin_bit_cast(h8v, ha.w1pk[(kb * 2 + 1) * 64 + lane]);
+    }
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) {
         bhi[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 0) * 64 + lane]);
         blo[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 1) * 64 + lane]);
     }
-    {   // all of a thread's loads are issued before the first LDS store (one memory latency, not sixteen)
-        constexpr int N = 3 * IH * IW, PER = (N + 255) / 256;
-        float buf[PER];
+    {   // stage the (TH+4) x 36 image tile split, three channels per position; all loads of a thread in flight first
+        constexpr int PER = (NIN + 255) / 256;
+        float buf[PER][3];
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * 256;
-            const int c = i / (IH * IW), rem = i - c * IH * IW;
-            const int y = rem / IW, x = rem - y * IW;
+            const int y = i / IW, x = i - y * IW;
             const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
-            buf[k] = 0.0f;
-            if (i < N && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) buf[k] = img[c * P + (size_t)gy * a.W + gx];
+            const bool ok = i < NIN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) buf[k][c] = ok ? img[c * P + (size_t)gy * a.W + gx] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * 256;
-            if (i < N) (&in[0][0][0])[i] = buf[k];
+            uint2 hi, lo;
+            split4(make_float4(buf[k][0], buf[k][1], buf[k][2], 0.0f), hi, lo);
+            if (i < NIN) { inh[i] = hi; inh[NIN + i] = lo; }
         }
+        if (tid < 2) inh[2 * NIN + tid] = make_uint2(0u, 0u);
     }
     __syncthreads();
-    // conv1 + ReLU on MH x MW positions, two per item (fp32 VALU: K = 27), written split into the parity planes
-    for (int it = tid; it < MH * (MW / 2); it += 256) {
-        const int my = it / (MW / 2), mx = (it - my * (MW / 2)) * 2;
-        float acc[2][8];
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[q][j] = a.b1[j];
-#pragma unroll 1
-        for (int cky = 0; cky < 9; ++cky) {   // rolled: 24 scalar-loaded weights live per trip, no SGPR spills
-                const int c = cky / 3, ky = cky - 3 * c;
-                float v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = in[c][my + ky][mx + k];
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float w = a.w1[((c * 3 + ky) * 3 + kx) * 8 + j];
-                        acc[0][j] = fmaf(v[kx], w, acc[0][j]);
-                        acc[1][j] = fmaf(v[kx + 1], w, acc[1][j]);
-                    }
-            }
-        const int gy = ty0 - 1 + my;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int gx = tx0 - 1 + mx + q;
-            // conv2 pads its INPUT (the ReLU'd map) with zeros outside the image
-            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = inside ? relu(acc[q][j]) : 0.0f;
-            uint2 h0, l0, h1, l1;
-            split4(make_float4(f[0], f[1], f[2], f[3]), h0, l0);
-            split4(make_float4(f[4], f[5], f[6], f[7]), h1, l1);
-            const int slot = q * PLANE + my * HW + (mx >> 1);          // mx is even: pixel mx + q has parity q
-            mid[slot] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            mid[REGION + slot] = make_uint4(l0.x, l0.y, l1.x, l1.y);
-        }
-    }
-    __syncthreads();
-    // conv2 + ReLU on the matrix cores: a wave owns rows 8 wv .. 8 wv + 7 of the tile, one 32-pixel row = 16 pairs per MFMA group
     const int i16 = lane & 15, g = lane >> 4;
-    const int pr = (i16 >> 2) + 4 * (i16 & 3);                        // pi(i): the pixel pair this lane's A row stands for
+    const int pr = (i16 >> 2) + 4 * (i16 & 3);                        // pi(i): the pair of the group this lane's A row stands for
+    const int sN = i16 >> 3, co = i16 & 7;                            // this lane's output: pixel s of the pair, channel co
+    {   // conv1 + ReLU on the MH x MW halo'd positions, 16 pairs per MFMA group
+        const float bias1 = a.b1[co];
+        const uint4* inq = reinterpret_cast<const uint4*>(inh);       // a piece = two adjacent positions = 16 bytes (even column)
+#pragma unroll 1
+        for (int gi = wv; gi < NGRP; gi += 4) {
+            const int q = min(16 * gi + pr, NPAIR - 1);
+            const int my = q / HW, pc = q - my * HW;
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int piece = 4 * kb + g;                          // (ky, half) = (piece >> 1, piece & 1); pieces 6, 7 are empty
+                const int at = piece < 6 ? ((my + (piece >> 1)) * IW + 2 * pc + 2 * (piece & 1)) >> 1 : NIN;
+                const h8v ahi = __builtin_bit_cast(h8v, inq[at]);
+                const h8v alo = __builtin_bit_cast(h8v, inq[piece < 6 ? at + NIN / 2 : NIN]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, c1hi[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, c1lo[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, c1hi[kb], acc, 0, 0, 0);
+            }
+            // D: lane (s, co) holds pairs pi(4 g + r) = 16 gi + g + 4 r; back to LDS split, channels (co, co ^ 1) per 32-bit word
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 16 * gi + g + 4 * r;
+                const int y = qq / HW, pcc = qq - y * HW;
+                const int gy = ty0 - 1 + y, gx = tx0 - 1 + 2 * pcc + sN;
+                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;       // conv2 pads its INPUT (the ReLU'd map) with zeros
+                const float v = inside ? relu(acc[r] + bias1) : 0.0f;
+                const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.0f))[0];
+                const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.0f))[0];
+                const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+                const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
+                if ((co & 1) == 0 && qq < NPAIR) {
+                    unsigned* slot = reinterpret_cast<unsigned*>(&mid[sN * PLANE + y * HW + pcc]) + (co >> 1);
+                    slot[0] = (mine & 0xFFFFu) | (other << 16);
+                    slot[4 * REGION] = (mine >> 16) | (other & 0xFFFF0000u);          // unsigned units: the lo half starts REGION uint4 slots later
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // conv2 + ReLU: a wave owns rows TH/4 wv .. of the tile, one 32-pixel row = 16 pairs per MFMA group
     // piece (ky = kb, kx = g) of pair pr: tile column 2 pr + g of row + kb -> parity g & 1, slot pr + (g >> 1)
     const int abase = (g & 1) * PLANE + pr + (g >> 1);
-    const int sN = i16 >> 3, co = i16 & 7;                            // this lane's output: pixel s of the pair, channel co
     const float bias = a.b2[co];
     const int H2 = a.H / 2, W2 = a.W / 2;
     float keep[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int rr = 0; rr < 8; ++rr) {
-        const int row = 8 * wv + rr;
+    for (int rr = 0; rr < TH / 4; ++rr) {
+        const int row = (TH / 4) * wv + rr;
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb) {
@@ -328,6 +340,28 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             }
         }
     }
+}
+
+// conv1 of block 1, OIHW [8][3][3][3] -> alike_block1_h fragments [2 kb][hi / lo][64 lanes][8 halves]: lane (n = (s, cout), g),
+// piece 4 kb + g = (ky, half) for pieces 0..5; element j = (kx = 2 half + (j >> 2), cin = j & 3): w[cout][cin][ky][kx - s]
+std::vector<float> pack_b1c1_pairs(const float* w)
+{
+    std::vector<uint16_t> hl((size_t)2 * 2 * 64 * 8, 0);
+    for (int kb = 0; kb < 2; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int n = l & 15, g = l >> 4, s2 = n >> 3, co = n & 7, piece = 4 * kb + g;
+                const int ky = piece >> 1, kx = 2 * (piece & 1) + (j >> 2) - s2, c = j & 3;
+                const float v = (piece < 6 && c < 3 && kx >= 0 && kx <= 2) ? w[((size_t)co * 3 + c) * 9 + ky * 3 + kx] : 0.0f;
+                _Float16 hi = (_Float16)v;
+                if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                memcpy(&hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j], &hi, 2);
+                memcpy(&hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j], &lo, 2);
+            }
+    std::vector<float> out(hl.size() / 2);
+    memcpy(out.data(), hl.data(), hl.size() * 2);
+    return out;
 }
 
 // conv2 of block 1, OIHW [8][8][3][3] -> alike_block1_h fragments [3 kb = ky][hi / lo][64 lanes][8 halves = cin]:
@@ -1373,8 +1407,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     Block1Args b1{img_dev, x1, p1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
     static const int b1h = kpb_env_int("KPB_BLOCK1_H16", 1);
     if (b1h) {
-        Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c2.pairs"))};
-        KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, hb);
+        Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c1.pairs")), reinterpret_cast<const uint4*>(wp("b1c2.pairs"))};
+        KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1H_TH), batch), dim3(256), 0, st, hb);
     } else
     KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
 
@@ -1481,6 +1515,7 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         ws.put_raw("b1c1.b", bl.get("b1c1.b", {c1}), 8);
         repack3x3(bl.get("b1c2.w", {c1, c1, 3, 3}), 8, 8, tmp); ws.put("b1c2.w", tmp);
         ws.put("b1c2.pairs", pack_b1c2_pairs(bl.get("b1c2.w", {c1, c1, 3, 3})));
+        ws.put("b1c1.pairs", pack_b1c1_pairs(bl.get("b1c1.w", {c1, 3, 3, 3})));
         ws.put_raw("b1c2.b", bl.get("b1c2.b", {c1}), 8);
     }
     const uint32_t ch[5] = {0, c1, c2, c3, c4};
