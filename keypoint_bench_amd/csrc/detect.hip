@@ -27,6 +27,13 @@ struct NmsArgs {
     int* ucount;        // [B] sweep 0 of nms_sweep_r: number of pixels it left undecided (alive, not confirmed) ...
     int2* ulist;        // [B][2][ucap] ... as (raster index, -1) (null: not collected)
     int ucap;
+    // top-K pruning (kpb_detect with top_k < H*W): sweep 0 also lists the scores of the maxima it CONFIRMED inside the border
+    // frame and above the output thresholds; if an image has more than top_k of them, nothing that scores below the
+    // (top_k+1)-th can reach the output, and nms_tail drops those undecided pixels unresolved
+    float* clist;       // [B][ccap] (null: no pruning)
+    int* ccount;        // [B]
+    int ccap, border;
+    float cmin;         // a confirmed maximum counts when its score is > cmin (threshold / min_score of the detection)
     int H, W, r, tiles_y, tiles_x, sweep, max_local;
 };
 
@@ -200,6 +207,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     __shared__ __attribute__((aligned(16))) float e[ROWS * EP];      // row maxima over [x-R, x+R]
     __shared__ int maxlist[MAXLIST];
     __shared__ int s_n[2], s_changed, s_over;
+    constexpr int CLOCAL = 256;
+    __shared__ float clocal[CLOCAL];
+    __shared__ int s_nc, s_cbase;
 
     const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     int changed = 0;
     if (first && a.ulist) {     // the local rounds are over: maxlist and its counter are reused for the undecided pixels
         __syncthreads();
-        if (tid == 0) { s_n[0] = 0; s_over = 0; }
+        if (tid == 0) { s_n[0] = 0; s_over = 0; s_nc = 0; }
         __syncthreads();
     }
 #pragma unroll
@@ -392,6 +402,32 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
             undecided = v > 0.0f;
         }
         if (first && a.ulist) append(undecided, gy * a.W + gx, 0);     // what this tile could not settle goes to nms_tail
+        if (first && a.clist) {     // scores of the maxima confirmed here that the detection could output (wave-aggregated LDS append)
+            bool hit = false;
+            float sc = 0.0f;
+            if (gy < a.H && gx < a.W) {
+                const float v = t[(oy + 2 * R) * PITCH + ox + 2 * R];
+                sc = -v;
+                hit = v < 0.0f && sc > a.cmin && gx >= a.border && gx < a.W - a.border && gy >= a.border && gy < a.H - a.border;
+            }
+            const unsigned long long bal = __ballot(hit);
+            if (bal) {
+                int base = 0;
+                if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&s_nc, __popcll(bal));
+                base = __shfl(base, __ffsll((long long)bal) - 1, 64);
+                const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && slot < CLOCAL) clocal[slot] = sc;
+            }
+        }
+    }
+    if (first && a.clist) {
+        __syncthreads();
+        const int cnt = s_nc;
+        if (tid == 0) s_cbase = cnt ? atomicAdd(&a.ccount[img], cnt > CLOCAL ? a.ccap + cnt : cnt) : 0;     // overflow of the tile's list: poison the count
+        __syncthreads();
+        const int cb = s_cbase;
+        for (int i = tid; i < min(cnt, CLOCAL); i += NMS_THREADS)
+            if (cb + i < a.ccap) a.clist[(size_t)img * a.ccap + cb + i] = clocal[i];
     }
     if (first && a.ulist) {
         __syncthreads();
@@ -424,6 +460,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 struct TailArgs {
     float* cur; int2* wlist; int* slist; int* ucount; int* status;
     int ucap, H, W, r, max_rounds;
+    const float* clist; const int* ccount; int ccap, top_k;      // top-K pruning (see NmsArgs); clist null: none
 };
 
 constexpr int TAIL_THREADS = 1024;
@@ -438,9 +475,47 @@ __global__ __launch_bounds__(TAIL_THREADS) void nms_tail(TailArgs a)
     int2* wl[2] = {a.wlist + (size_t)img * 2 * a.ucap, a.wlist + (size_t)img * 2 * a.ucap + a.ucap};
     int* sl = a.slist + (size_t)img * a.ucap;
     __shared__ int s_nw, s_ns;
+    __shared__ unsigned s_hist[256], s_prefix, s_krem;
     const int total = a.ucount[img];
     int nw = total <= a.ucap ? total : 0;       // an overflowed list is incomplete (and partly unwritten): leave the image to the tiled sweeps
     const unsigned long long gmask = 0xFFFFull << (lane & 48);
+    // Top-K pruning.  The detection outputs the top_k best survivors.  If sweep 0 has already CONFIRMED more than top_k maxima
+    // that qualify for the output, let T be the (top_k+1)-th best of their scores: at least top_k+1 survivors score >= T, so
+    // (i) N > top_k holds whatever the undecided pixels turn out to be, and (ii) no pixel that scores below T can be among
+    // the top_k.  A pixel's fate depends only on pixels that outrank it, so the undecided pixels >= T can be resolved
+    // exactly while those below T are dropped unresolved (they stay positive in the map; select_topk takes confirmed maxima
+    // only).  Radix select of T over the listed scores (positive floats order like their bit patterns), 8 bits a pass.
+    float Tprune = 0.0f;
+    {
+        const int nc = a.clist ? a.ccount[img] : 0;
+        if (a.top_k > 0 && nc > a.top_k && nc <= a.ccap) {
+            const float* cl = a.clist + (size_t)img * a.ccap;
+            if (tid == 0) { s_prefix = 0; s_krem = (unsigned)(a.top_k + 1); }
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                if (tid < 256) s_hist[tid] = 0;
+                __syncthreads();
+                const unsigned prefix = s_prefix;
+                const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+                for (int i = tid; i < nc; i += TAIL_THREADS) {
+                    const unsigned k = __float_as_uint(cl[i]);
+                    if ((k & himask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    unsigned krem = s_krem, cum = 0;
+                    int d = 255;
+                    for (; d > 0; --d) {
+                        if (cum + s_hist[d] >= krem) break;
+                        cum += s_hist[d];
+                    }
+                    s_krem = krem - cum;
+                    s_prefix = prefix | ((unsigned)d << shift);
+                }
+                __syncthreads();
+            }
+            Tprune = __uint_as_float(s_prefix);
+        }
+    }
     int round = 0;
     for (; round < a.max_rounds && nw > 0; ++round) {
         if (tid == 0) { s_nw = 0; s_ns = 0; }
@@ -450,6 +525,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void nms_tail(TailArgs a)
         // phase A: watchers whose blocker is still alive stay parked, the rest are due for a scan
         for (int e = tid; e < nw; e += TAIL_THREADS) {
             const int2 w = src[e];
+            if (round == 0 && Tprune > 0.0f && cur[w.x] < Tprune) continue;       // cannot reach the top_k: left unresolved
             if (w.y >= 0 && cur[w.y] > 0.0f) dst[atomicAdd(&s_nw, 1)] = w;
             else sl[atomicAdd(&s_ns, 1)] = w.x;
         }
@@ -622,9 +698,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (i0 + j < P) v[j] = map[i0 + j];
         }
-        if (a.signed_map) {
+        if (a.signed_map) {     // confirmed maxima are stored negated; at the fixed point nothing else is alive, and pixels the
+                                // top-K pruning of nms_tail left unresolved (positive) are by construction not among the top_k
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fabsf(v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = v[j] < 0.0f ? -v[j] : 0.0f;
         }
         bool pred[4];
         int cnt = 0;
@@ -738,9 +815,13 @@ struct NmsPlan {
     int2* ulist;        // [B][2][ucap] watch lists (ping-pong)
     int* slist;         // [B][ucap] pixels due for a window scan
     int ucap;
+    float* clist;       // [B][ccap] scores of confirmed maxima (top-K pruning); null when off
+    int* ccount;
+    int ccap, prune_k, border;
+    float cmin;
 };
 
-int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p)
+int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p, int prune_k = 0, int border = 0, float cmin = 0.0f)
 {
     p.tiles_x = cdiv(W, TW);
     p.tiles_y = cdiv(H, TH);
@@ -748,25 +829,30 @@ int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p)
     const int LH = TH + 4 * r, LW = TW + 4 * r;
     p.lds = (size_t)2 * LH * LW * sizeof(float) + (MAXLIST + 4) * sizeof(int);
     const size_t nflag = (size_t)batch * p.ntiles;
-    const size_t bytes = (2 * nflag + 3 * (size_t)batch) * sizeof(int);
+    const size_t bytes = (2 * nflag + 4 * (size_t)batch) * sizeof(int);
     if (int rc = kpb_reserve(ctx, ctx->ws_nms_state, bytes)) return rc;
     int* base = static_cast<int*>(ctx->ws_nms_state.p);
     p.lastchg = base;
     p.negflag = base + batch;
     p.ucount = base + 2 * batch;
-    p.tchg[0] = base + 3 * batch;
+    p.ccount = base + 3 * batch;
+    p.tchg[0] = base + 4 * batch;
     p.tchg[1] = p.tchg[0] + nflag;
     p.ulist = nullptr;
     p.ucap = 0;
+    p.clist = nullptr; p.ccap = 0; p.prune_k = 0; p.border = border; p.cmin = cmin;
     // The tail is one workgroup per image and latency-bound (about 1.4 ms whatever the batch); four more tiled sweeps
     // cost about 8 us per 480x640 image.  It pays once the batch fills the chip.  KPB_NMS_TILED=1 / =0 force a choice.
     const int tiled = env_int("KPB_NMS_TILED", -1);
     const bool big = (size_t)batch * H * W >= (size_t)192 * 480 * 640;
     if (r >= 1 && r <= 8 && (tiled == 0 || (tiled < 0 && big))) {
         p.ucap = std::max(4096, H * W / 8);
-        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * 5 * p.ucap * sizeof(int))) return rc;
+        const bool prune = prune_k > 0 && prune_k < H * W && env_int("KPB_NMS_PRUNE", 1);
+        p.ccap = prune ? std::min(H * W, 16384) : 0;
+        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * (5 * (size_t)p.ucap + p.ccap) * sizeof(int))) return rc;
         p.ulist = static_cast<int2*>(ctx->ws_nms_list.p);
         p.slist = reinterpret_cast<int*>(p.ulist + (size_t)batch * 2 * p.ucap);
+        if (prune) { p.clist = reinterpret_cast<float*>(p.slist + (size_t)batch * p.ucap); p.prune_k = prune_k; }
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -789,11 +875,14 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.tchg_cur = p.tchg[s & 1];
         a.lastchg = p.lastchg; a.negflag = p.negflag;
         a.ucount = p.ucount; a.ulist = p.ulist; a.ucap = p.ucap;
+        a.clist = p.clist; a.ccount = p.ccount; a.ccap = p.ccap; a.border = p.border; a.cmin = p.cmin;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s;
         // with the sparse tail behind it, sweep 0 stops after three in-tile rounds (99.6 % of an ALIKE map is settled by
         // then; measured: 3 rounds 2.26 + 1.49 ms, 5 rounds 2.75 + 1.39 ms, 2 rounds 1.87 + 2.52 ms per 512 images)
-        a.max_local = env_int("KPB_NMS_MAXLOCAL", (p.ulist && s == 0) ? 3 : 64);
+        // with top-K pruning the tail is cheap and two rounds are the optimum (r02: 2 rounds 2.19 + <0.2 ms, 3 rounds 2.57 + <0.2 ms;
+        // one round confirms too few maxima for the bound and the tail overflows)
+        a.max_local = env_int("KPB_NMS_MAXLOCAL", (p.ulist && s == 0) ? (p.clist ? 2 : 3) : 64);
         const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
         switch (r) {
         case 1: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<1>, grid, block, 0, ctx->stream, a); break;
@@ -816,13 +905,13 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
 // over, with every tile marked as changed).  Returns the number of sweeps the status check has to account for.
 int nms_open(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int batch, int H, int W, int r, int chunk, int& sweeps_run)
 {
-    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 3 * (size_t)batch * sizeof(int), ctx->stream));
+    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 4 * (size_t)batch * sizeof(int), ctx->stream));
     if (!p.ulist) {
         sweeps_run = chunk;
         return nms_launch(ctx, p, src, cur, batch, H, W, r, 0, chunk);
     }
     if (int rc = nms_launch(ctx, p, src, cur, batch, H, W, r, 0, 1)) return rc;
-    TailArgs t{cur, p.ulist, p.slist, p.ucount, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256)};
+    TailArgs t{cur, p.ulist, p.slist, p.ucount, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256), p.clist, p.ccount, p.ccap, p.prune_k};
     switch (r) {
     case 1: KPB_LAUNCH(ctx, "nms_tail", nms_tail<1>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
     case 2: KPB_LAUNCH(ctx, "nms_tail", nms_tail<2>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
@@ -957,7 +1046,11 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     d.out_kps = out_kps_dev; d.out_idx = out_idx_dev; d.out_n = out_n_dev;
     if (int rc = kpb_reserve(ctx, ctx->ws_cand, (size_t)batch * P * sizeof(unsigned long long))) return rc;
     d.cand = static_cast<unsigned long long*>(ctx->ws_cand.p);
-    if (int rc = nms_plan(ctx, batch, H, W, prm->nms_dist, d.plan)) return rc;
+    {   // a confirmed maximum counts toward the pruning bound only if the detection could output it
+        const float cmin = std::max(prm->threshold, prm->min_score > 0.0f ? prm->min_score : prm->threshold);
+        const int border = std::max(prm->border_dist, 0);
+        if (int rc = nms_plan(ctx, batch, H, W, prm->nms_dist, d.plan, d.prm.top_k, border, cmin)) return rc;
+    }
     d.sweeps_run = 0;
     d.cur = nullptr;
     if (prm->nms_dist > 0) {
