@@ -635,6 +635,188 @@ __global__ __launch_bounds__(256) void conv3x3_h16(H16Args a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------ block 2 + agg2, fused
+// ResBlock 8 -> 16 at H/2 (ALike.py:65-81, 139-140) and the aggregation 1x1 + ReLU of its output (147-148) in ONE kernel:
+//   conv1 (8 -> 16) + ReLU on the (TH+2) x (TW+2) halo'd positions, from the pooled block-1 tile in LDS, back into LDS split;
+//   conv2 (16 -> 16) + the block's 1x1 identity branch (one more K piece, read from the input tile already in LDS) + ReLU -> x2;
+//   agg2 (16 -> 16, no bias) + ReLU on x2 -> a2, and a2 . w_score -> S2 (the group's share of the score logit).
+// All three on v_mfma_f32_16x16x32_f16 with split operands (conv3x3_h16 has the numerics and the operand layout).  As
+// three kernels (r02: 0.77 + 1.80 + 1.00 ms per 512 images) the 16-channel intermediate t2 made a round trip through HBM and
+// x2 was read back for the aggregation: 14.3 MB of avoidable traffic per image; fused, the block reads p1 once and writes
+// x2, a2, S2 once.  agg2 needs x2 with the pixel on the lane (A operand) where the accumulator has the channel on the lane:
+// each wave passes its 16 x 16 tile through 1 KB of LDS of its own (a wave's LDS operations execute in order: no barrier).
+struct Block2Args {
+    const float* p1;     // [B][H][W][8]
+    float* x2; float* a2; float* S2;
+    const uint4* w1pk;   // pack_h16(b2c1.w, 8, null): 3 k-blocks
+    const uint4* w2pk;   // pack_h16(b2c2.w, 16, b2ds.w): 5 k-blocks
+    const uint4* wapk;   // pack_1x1_h16(agg2.w): 1 k-block
+    const float* b1; const float* bsum; const float* wsg;
+    int H, W;
+};
+
+__device__ __forceinline__ unsigned split1(float v)     // (hi, lo) halves of one value in one 32-bit word: hi in the low half
+{
+    const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.0f))[0];
+    const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.0f))[0];
+    return (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+}
+
+__global__ __launch_bounds__(256) void alike_block2(Block2Args a)
+{
+    constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4, NP = PH * PW, MH = TH + 2, MW = TW + 2, NM = MH * MW;
+    constexpr int NG1 = (NM + 15) / 16;
+    __shared__ __attribute__((aligned(16))) uint4 pin[2 * NP];          // [hi | lo][position]: the pooled block-1 tile, 8 channels per slot
+    __shared__ __attribute__((aligned(16))) uint4 mid[4 * NM];          // [hi | lo][octet][position]: conv1's output
+    __shared__ __attribute__((aligned(16))) uint4 xs[4][2][2][16];      // per wave: [hi | lo][octet][pixel] of the x2 group in flight
+    __shared__ __attribute__((aligned(16))) uint4 zslot;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const size_t P = (size_t)a.H * a.W;
+    h8v w1h[3], w1l[3], w2h[5], w2l[5];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) { w1h[kb] = __builtin_bit_cast(h8v, a.w1pk[(kb * 2) * 64 + lane]); w1l[kb] = __builtin_bit_cast(h8v, a.w1pk[(kb * 2 + 1) * 64 + lane]); }
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) { w2h[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2) * 64 + lane]); w2l[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2 + 1) * 64 + lane]); }
+    const h8v wah = __builtin_bit_cast(h8v, a.wapk[lane]), wal = __builtin_bit_cast(h8v, a.wapk[64 + lane]);
+    {   // stage the (TH+4) x (TW+4) tile of p1, split, zero outside the image
+        const float* in = a.p1 + (size_t)b * P * 8;
+        for (int i = tid; i < NP * 2; i += 256) {
+            const int pos = i >> 1, q = i & 1;
+            const int y = pos / PW, x = pos - y * PW;
+            const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.W + gx) * 8 + 4 * q);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            uint2* d = reinterpret_cast<uint2*>(&pin[pos]) + q;
+            d[0] = hi;
+            d[2 * NP] = lo;
+        }
+        if (tid == 0) zslot = make_uint4(0u, 0u, 0u, 0u);
+    }
+    __syncthreads();
+    const int i16 = lane & 15, g = lane >> 4;
+    const int px = (i16 >> 2) + 4 * (i16 & 3);                // pi(i)
+    const uint4* zp = &zslot;
+    {   // conv1 + ReLU -> mid (split), 16 consecutive positions per MFMA group
+        const float bias1 = a.b1[i16];
+        unsigned* midw = reinterpret_cast<unsigned*>(mid);
+#pragma unroll 1
+        for (int gi = wv; gi < NG1; gi += 4) {
+            const int q = min(16 * gi + px, NM - 1);
+            const int my = q / MW, mx = q - my * MW;
+            f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                const int tap = 4 * kb + g;
+                const bool has = tap < 9;
+                const uint4* ph = has ? &pin[(my + tap / 3) * PW + mx + tap % 3] : zp;
+                const h8v ahi = __builtin_bit_cast(h8v, ph[0]);
+                const h8v alo = __builtin_bit_cast(h8v, has ? ph[NP] : zp[0]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, w1h[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w1l[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w1h[kb], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 16 * gi + g + 4 * r;
+                const int y = qq / MW, x = qq - y * MW;
+                const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
+                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;       // conv2 pads its INPUT with zeros
+                const unsigned mine = split1(inside ? relu(acc[r] + bias1) : 0.0f);
+                const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
+                if ((i16 & 1) == 0 && qq < NM) {
+                    const int w = (((i16 >> 3) * NM + qq) << 2) + ((i16 & 7) >> 1);       // word of (octet, position, channel pair) in the hi half
+                    midw[w] = (mine & 0xFFFFu) | (other << 16);
+                    midw[w + 8 * NM] = (mine >> 16) | (other & 0xFFFF0000u);               // lo half: 2 NM slots = 8 NM words further
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // conv2 + identity branch + ReLU -> x2; agg2 + ReLU -> a2, S2.  16 groups of 16 pixels per tile, four per wave
+    const float bsum = a.bsum[i16], wsg = a.wsg[i16];
+    float* x2 = a.x2 + (size_t)b * P * 16;
+    float* a2 = a.a2 + (size_t)b * P * 16;
+    float* S2 = a.S2 + (size_t)b * P;
+    unsigned* xw = reinterpret_cast<unsigned*>(&xs[wv][0][0][0]);
+#pragma unroll 1
+    for (int gi = 4 * wv; gi < 4 * wv + 4; ++gi) {
+        const int row = gi >> 1, col0 = (gi & 1) * 16;
+        const int mbase = row * MW + col0 + px;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 5; ++kb) {
+            const int kidx = 4 * kb + g;
+            const uint4* ph;
+            int lo_off;
+            if (kidx < 18) { const int tap = kidx >> 1; ph = &mid[(kidx & 1) * NM + mbase + (tap / 3) * MW + tap % 3]; lo_off = 2 * NM; }
+            else if (kidx == 18) { ph = &pin[(row + 2) * PW + col0 + px + 2]; lo_off = NP; }
+            else { ph = zp; lo_off = 0; }
+            const h8v ahi = __builtin_bit_cast(h8v, ph[0]);
+            const h8v alo = __builtin_bit_cast(h8v, ph[lo_off]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, w2h[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w2l[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w2h[kb], acc, 0, 0, 0);
+        }
+        const int gy = ty0 + row;
+        const bool rowok = gy < a.H;
+        // x2: lane holds channel i16 of pixels pi(4 g + r) = g + 4 r (256 contiguous bytes per store instruction)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = relu(acc[r] + bsum);
+            const int gx = tx0 + col0 + g + 4 * r;
+            if (rowok && gx < a.W) x2[((size_t)gy * a.W + gx) * 16 + i16] = v;
+            const unsigned mine = split1(v);
+            const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
+            if ((i16 & 1) == 0) {
+                const int w = (((i16 >> 3) * 16 + g + 4 * r) << 2) + ((i16 & 7) >> 1);     // [octet][pixel] slot, channel-pair word
+                xw[w] = (mine & 0xFFFFu) | (other << 16);
+                xw[w + 128] = (mine >> 16) | (other & 0xFFFF0000u);                          // lo half: 2 x 16 slots = 128 words further
+            }
+        }
+        // agg2: A = the group's x2 with the pixel on the lane: piece g = channel octet g (g < 2)
+        f32x4v ag = {0.f, 0.f, 0.f, 0.f};
+        {
+            const uint4* ph = g < 2 ? &xs[wv][0][g][px] : zp;
+            const h8v ahi = __builtin_bit_cast(h8v, ph[0]);
+            const h8v alo = __builtin_bit_cast(h8v, g < 2 ? ph[32] : zp[0]);
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, wah, ag, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wal, ag, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wah, ag, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = relu(ag[r]);
+            const int gx = tx0 + col0 + g + 4 * r;
+            if (rowok && gx < a.W) a2[((size_t)gy * a.W + gx) * 16 + i16] = v;
+            float sg = v * wsg;                    // this group's share of the score logit (the head commutes with the upsampling)
+            sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64); sg += __shfl_xor(sg, 8, 64);
+            if (i16 == 0 && rowok && gx < a.W) S2[(size_t)gy * a.W + gx] = sg;
+        }
+    }
+}
+
+// agg [16][16] (cout, cin) -> one k-block of fragments: piece g < 2 = channel octet g
+std::vector<float> pack_1x1_h16(const float* w)
+{
+    std::vector<uint16_t> hl((size_t)2 * 64 * 8, 0);
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int n = l & 15, g = l >> 4;
+            const float v = g < 2 ? w[n * 16 + 8 * g + j] : 0.0f;
+            _Float16 hi = (_Float16)v;
+            if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            memcpy(&hl[((size_t)0 * 64 + l) * 8 + j], &hi, 2);
+            memcpy(&hl[((size_t)1 * 64 + l) * 8 + j], &lo, 2);
+        }
+    std::vector<float> out(hl.size() / 2);
+    memcpy(out.data(), hl.data(), hl.size() * 2);
+    return out;
+}
+
 // OIHW [16][CIN][3][3] (+ identity-branch [16][8]) -> conv3x3_h16 fragments [KB][hi / lo][64 lanes][8 halves], as floats (bit patterns)
 std::vector<float> pack_h16(const float* w, int CIN, const float* ds_w)
 {
@@ -1006,8 +1188,8 @@ __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
     }
 }
 
-template <int MAP, bool PIPE>
-__global__ __launch_bounds__(256) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
+template <int MAP, bool PIPE, int WPS = 3>
+__global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
 {
     __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];         // [hi/lo][(kb, nh, h, n)]: one 16-byte fragment per lane and MFMA
     __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j
@@ -1415,8 +1597,12 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     ConvArgs c;
     // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
     c = ConvArgs{p1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};      // pooled by block1
-    static const int h16 = kpb_env_int("KPB_CONV_H16", 1);
-    if (h16) {
+    static const int h16 = kpb_env_int("KPB_CONV_H16", 1), fuse2 = kpb_env_int("KPB_BLOCK2_FUSED", 1);
+    if (h16 && fuse2) {
+        Block2Args b2{p1, x2, a2, S2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
+                      reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2};
+        KPB_LAUNCH(ctx, "alike_block2", alike_block2, dim3(cdiv(W / 2, 32), cdiv(H / 2, 8), batch), dim3(256), 0, st, b2);
+    } else if (h16) {
         const dim3 grid(cdiv(W / 2, 32), cdiv(H / 2, 8), batch);
         H16Args h1{p1, nullptr, t2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), wp("b2c1.b"), H / 2, W / 2};
         KPB_LAUNCH(ctx, "conv3x3_b2c1", (conv3x3_h16<8, false>), grid, dim3(256), 0, st, h1);
@@ -1448,7 +1634,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
     }
     // aggregation 1x1 + ReLU (147-150), each with its share of the score logit; agg1 is fused into the head
-    KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4, nullptr, nullptr);
+    if (!(h16 && fuse2))
+        KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4, nullptr, nullptr);
     KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64, wp("head.wT") + 32 * 64, E3);
     KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
     // upsample + concat + head (151-162)
@@ -1462,7 +1649,10 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         if (map == 2 && work4 % 8 != 0) map = 1;
         if (f16 && map != 0) {
             const uint4* wh16 = reinterpret_cast<const uint4*>(wp("head.wh16"));
-            if (map == 1 && !pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+            static const int wps = kpb_env_int("KPB_HEAD_WPS", 3);
+            if (wps == 4 && map == 1 && !pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, false, 4>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+            else if (wps == 4 && map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, true, 4>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
+            else if (map == 1 && !pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
             else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, true>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
             else if (!pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<2, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
             else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<2, true>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
@@ -1537,6 +1727,7 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         tmp.assign(16, 0.f);
         for (int i = 0; i < 16; ++i) tmp[i] = b2[i] + bd[i];
         ws.put("b2c2.bsum", tmp);
+        ws.put("agg2.h16", pack_1x1_h16(bl.get("agg2.w", {dim / 4, c2})));
     }
     ws.put("b3c2.wp", pack_mfma(bl.get("b3c2.w", {c3, c3, 3, 3}), 32, 32, 3, 32, 1));
     ws.put("b3c2.bp", pad_bias(bl.get("b3c2.b", {c3}), 32, 32));
