@@ -36,6 +36,13 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
 
+__device__ __forceinline__ unsigned split1(float v)     // (hi, lo) halves of one value in one 32-bit word: hi in the low half
+{
+    const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.0f))[0];
+    const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.0f))[0];
+    return (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+}
+
 // ------------------------------------------------------------------------------------------------ block1
 constexpr int B1_TH = 32, B1_TW = 32;
 
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
 {
     const Block1Args& a = ha.b;
     constexpr int TH = B1H_TH, IH = TH + 4, IW = B1_TW + 4, MH = TH + 2, MW = B1_TW + 2, HW = MW / 2;     // HW: slots per row and parity
-    constexpr int PLANE = MH * HW, REGION = 2 * PLANE, NIN = IH * IW, NPAIR = MH * HW, NGRP = (NPAIR + 15) / 16;
+    constexpr int PLANE = MH * HW, REGION = 2 * PLANE, NIN = IH * IW;
     __shared__ __attribute__((aligned(16))) uint2 inh[2 * NIN + 2];        // [hi | lo][position] = (c0 c1 c2 0) halves; + a zero piece
     __shared__ __attribute__((aligned(16))) uint4 mid[2 * REGION];          // [hi | lo][parity][row][column / 2]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
@@ -263,10 +270,13 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
     {   // conv1 + ReLU on the MH x MW halo'd positions, 16 pairs per MFMA group
         const float bias1 = a.b1[co];
         const uint4* inq = reinterpret_cast<const uint4*>(inh);       // a piece = two adjacent positions = 16 bytes (even column)
+        // MFMA groups without index arithmetic: group gi < MH = pairs 0..15 of row gi; the 17th pair of every row goes to two
+        // extra groups (rows 0..15 and 16..17): pair slot k of a group is (row, pair) = (yb + ys k, pb + ps k)
 #pragma unroll 1
-        for (int gi = wv; gi < NGRP; gi += 4) {
-            const int q = min(16 * gi + pr, NPAIR - 1);
-            const int my = q / HW, pc = q - my * HW;
+        for (int gi = wv; gi < MH + 2; gi += 4) {
+            const bool extra = gi >= MH;
+            const int yb = extra ? 16 * (gi - MH) : gi, ys = extra ? 1 : 0, pb = extra ? 16 : 0, ps = extra ? 0 : 1;
+            const int my = min(yb + ys * pr, MH - 1), pc = pb + ps * pr;
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -278,22 +288,20 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, c1lo[kb], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, c1hi[kb], acc, 0, 0, 0);
             }
-            // D: lane (s, co) holds pairs pi(4 g + r) = 16 gi + g + 4 r; back to LDS split, channels (co, co ^ 1) per 32-bit word
+            // D: lane (s, co) holds pair slots 4 g + r -> pi = g + 4 r; back to LDS split, channels (co, co ^ 1) per 32-bit word
+            unsigned* midw = reinterpret_cast<unsigned*>(mid);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qq = 16 * gi + g + 4 * r;
-                const int y = qq / HW, pcc = qq - y * HW;
+                const int k = g + 4 * r;
+                const int y = yb + ys * k, pcc = pb + ps * k;
                 const int gy = ty0 - 1 + y, gx = tx0 - 1 + 2 * pcc + sN;
                 const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;       // conv2 pads its INPUT (the ReLU'd map) with zeros
-                const float v = inside ? relu(acc[r] + bias1) : 0.0f;
-                const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.0f))[0];
-                const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.0f))[0];
-                const unsigned mine = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+                const unsigned mine = split1(inside ? relu(acc[r] + bias1) : 0.0f);
                 const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
-                if ((co & 1) == 0 && qq < NPAIR) {
-                    unsigned* slot = reinterpret_cast<unsigned*>(&mid[sN * PLANE + y * HW + pcc]) + (co >> 1);
-                    slot[0] = (mine & 0xFFFFu) | (other << 16);
-                    slot[4 * REGION] = (mine >> 16) | (other & 0xFFFF0000u);          // unsigned units: the lo half starts REGION uint4 slots later
+                if ((co & 1) == 0 && y < MH) {
+                    const int w = ((sN * PLANE + y * HW + pcc) << 2) + (co >> 1);
+                    midw[w] = (mine & 0xFFFFu) | (other << 16);
+                    midw[w + 4 * REGION] = (mine >> 16) | (other & 0xFFFF0000u);      // lo half: REGION slots = 4 REGION words further
                 }
             }
         }
@@ -655,17 +663,10 @@ struct Block2Args {
     int H, W;
 };
 
-__device__ __forceinline__ unsigned split1(float v)     // (hi, lo) halves of one value in one 32-bit word: hi in the low half
-{
-    const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.0f))[0];
-    const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.0f))[0];
-    return (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
-}
 
 __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
 {
     constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4, NP = PH * PW, MH = TH + 2, MW = TW + 2, NM = MH * MW;
-    constexpr int NG1 = (NM + 15) / 16;
     __shared__ __attribute__((aligned(16))) uint4 pin[2 * NP];          // [hi | lo][position]: the pooled block-1 tile, 8 channels per slot
     __shared__ __attribute__((aligned(16))) uint4 mid[4 * NM];          // [hi | lo][octet][position]: conv1's output
     __shared__ __attribute__((aligned(16))) uint4 xs[4][2][2][16];      // per wave: [hi | lo][octet][pixel] of the x2 group in flight
@@ -702,10 +703,13 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     {   // conv1 + ReLU -> mid (split), 16 consecutive positions per MFMA group
         const float bias1 = a.b1[i16];
         unsigned* midw = reinterpret_cast<unsigned*>(mid);
+        // groups without index arithmetic: gi < 2 MH = (row gi / 2, columns 16 (gi & 1) .. + 15); the two rightmost columns of all
+        // rows go to two extra groups: slot k of an extra group e is position (row, column) = ((16 e + k) / 2, 32 + (k & 1))
 #pragma unroll 1
-        for (int gi = wv; gi < NG1; gi += 4) {
-            const int q = min(16 * gi + px, NM - 1);
-            const int my = q / MW, mx = q - my * MW;
+        for (int gi = wv; gi < 2 * MH + 2; gi += 4) {
+            const bool extra = gi >= 2 * MH;
+            const int e16 = extra ? 16 * (gi - 2 * MH) : 0;
+            const int my = extra ? min((e16 + px) >> 1, MH - 1) : gi >> 1, mx = extra ? 32 + (px & 1) : 16 * (gi & 1) + px;
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
@@ -720,14 +724,14 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qq = 16 * gi + g + 4 * r;
-                const int y = qq / MW, x = qq - y * MW;
+                const int k = g + 4 * r;
+                const int y = extra ? (e16 + k) >> 1 : gi >> 1, x = extra ? 32 + (k & 1) : 16 * (gi & 1) + k;
                 const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
                 const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;       // conv2 pads its INPUT with zeros
                 const unsigned mine = split1(inside ? relu(acc[r] + bias1) : 0.0f);
                 const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
-                if ((i16 & 1) == 0 && qq < NM) {
-                    const int w = (((i16 >> 3) * NM + qq) << 2) + ((i16 & 7) >> 1);       // word of (octet, position, channel pair) in the hi half
+                if ((i16 & 1) == 0 && y < MH) {
+                    const int w = (((i16 >> 3) * NM + y * MW + x) << 2) + ((i16 & 7) >> 1);       // word of (octet, position, channel pair) in the hi half
                     midw[w] = (mine & 0xFFFFu) | (other << 16);
                     midw[w + 8 * NM] = (mine >> 16) | (other & 0xFFFF0000u);               // lo half: 2 NM slots = 8 NM words further
                 }
