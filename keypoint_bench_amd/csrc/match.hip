@@ -69,6 +69,7 @@ constexpr int TM = 4, TN = 8;                                 // distances per t
 constexpr int MTI = 16 * TM, MTJ = 16 * TN, KC = 16, MATCH_THREADS = 256;
 
 struct MatchArgs {
+    const int* only;                 // optional [B]: run only for pairs whose flag is set (the prefilter's exact fallback)
     const float* d0; const float* d1; const int* n; const int* m;
     double* rpart_s; int* rpart_j;   // [B][tiles_j][max_n]
     double* cpart_s; int* cpart_i;   // [B][tiles_i][max_m]
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void match_tile(MatchArgs a)
     double (*A)[PA] = reinterpret_cast<double (*)[PA]>(smem);
     double (*Bt)[PB] = reinterpret_cast<double (*)[PB]>(smem + KC * PA * 2);
     const int b = blockIdx.z, tj = blockIdx.x, ti = blockIdx.y, tid = threadIdx.x;
+    if (a.only && !a.only[b]) return;
     const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
     const int i0 = ti * MTI, j0 = tj * MTJ;
     if (i0 >= n || j0 >= m) return;   // partials of empty tiles are never read (finalize clips to n, m)
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
         for (int t = 0; t < tiles_i; ++t) {
             const size_t o = ((size_t)b * a.tiles_i + t) * a.max_m + j;
             const double s = a.cpart_s[o]; const int i = a.cpart_i[o];
-            if (precedes(s, i, bs, bi)) { bs = s; bi = i; }
+            if (i != 0x7FFFFFFF && precedes(s, i, bs, bi)) { bs = s; bi = i; }        // INT_MAX: an empty slot of the prefilter path
         }
         colarg[j] = bi;
     }
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
             for (int t = 0; t < tiles_j; ++t) {
                 const size_t o = ((size_t)b * a.tiles_j + t) * a.max_n + i;
                 const double s = a.rpart_s[o]; const int j = a.rpart_j[o];
-                if (precedes(s, j, bs, bj)) { bs = s; bj = j; }
+                if (j != 0x7FFFFFFF && precedes(s, j, bs, bj)) { bs = s; bj = j; }
             }
             dist = sqrt(bs);
             // skimage filters on distance only `if max_distance < np.inf`: inf / nan distances survive max_distance = inf
@@ -259,6 +261,263 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
         base += tot;
     }
     if (tid == 0) a.out_k[b] = base;
+}
+
+// ------------------------------------------------------------------------------------------------ M2, prefilter
+// The exact float64 distances above cost 3 N M C non-fusable fp64 operations per pair (2.2 ms per 256 pairs, 65 % of what the
+// fp64 vector ALUs deliver without FMA).  Only the arg-minima and the distances of the matched pairs have to be exact, so the
+// bulk is replaced by a FILTER on the matrix cores and the exact arithmetic runs on what survives it:
+//   1. match_prep: squared norms in fp32 and every descriptor split into two half-precision terms (x = hi + lo);
+//   2. match_approx<.., 0>: D~_ij = |a_i|^2 + |b_j|^2 - 2 a_i.b_j with the dot products on v_mfma_f32_16x16x32_f16 (three MFMAs
+//      per product, fp32 accumulation); row and column minima of D~;
+//   3. match_approx<.., 1>: the same pass again; (i, j) is listed as a row candidate when D~_ij <= rowmin_i + mr_i and as a
+//      column candidate when D~_ij <= colmin_j + mc_j.  Error bound of the filter, worst case: each operand is carried to
+//      2^-20 relative (two toward-zero half-precision terms) or 2^-25 absolute (f16 subnormal grid), the dropped lo.lo terms
+//      are <= 2^-20 of their product, the 3 C products are accumulated in fp32 (<= 3 C 2^-24 |a||b|), the norms are fp32 sums of
+//      C squares:  |D~ - D| <= (2.9e-6 + 2.4e-7 C)(|a|^2 + |b|^2) + 2e-6 (|a| + |b|)  =: delta.  The exact arg-minimum j* of row i
+//      satisfies D~_ij* <= D_ij* + delta_ij* <= D_ij' + delta_ij* <= rowmin_i + delta_ij' + delta_ij* (j' the approximate
+//      arg-minimum), so mr_i = 2.5 x delta evaluated with the LARGEST column norm of the pair covers it with a quarter to
+//      spare, for every exact tie as well; mc_j likewise with the largest row norm;
+//   4. match_exact: scipy's float64 sum for the listed pairs only (same order, no FMA), filed under their row and column
+//      in the slots match_finalize reads (the per-tile partial arrays of match_tile, one slot per column / row tile).
+// A pair whose descriptors are not finite, or that needs more slots than there are tiles (massive exact ties), raises a
+// flag: match_tile then runs for that pair alone (it returns at once for the others) and overwrites the slots.  Results
+// are bit-identical to match_tile's by construction; tests/test_gpu_match.py checks them on the goldens and the tie / NaN cases.
+typedef _Float16 mh8 __attribute__((ext_vector_type(8)));
+typedef float mf4 __attribute__((ext_vector_type(4)));
+constexpr unsigned INF_BITS = 0x7F800000u;
+__device__ __forceinline__ float match_margin(float na, float nb, int C)
+{
+    return (7.5e-6f + 6.0e-7f * (float)C) * (na + nb) + 5.0e-6f * (sqrtf(na) + sqrtf(nb));
+}
+
+struct PreArgs {
+    const float* d0; const float* d1; const int* n; const int* m;
+    int C, max_n, max_m;
+    uint4* h0; uint4* h1;            // [B][max][C/8] hi pieces then lo pieces (second half of each array)
+    float* nrm0; float* nrm1;        // [B][max]
+    unsigned* rowmin; unsigned* colmin;      // [B][max_n], [B][max_m] float bits, start at +inf
+    int* rcnt; int* ccnt;            // slot counters
+    int* flag;                       // [B] 1: exact fallback for the pair
+    int* ncand;                      // [B]
+    unsigned* nmax;                  // [B][2] largest squared norm of either side (float bits; zeroed by the host)
+};
+
+__global__ __launch_bounds__(256) void match_prep(PreArgs a)
+{
+    // eight lanes per descriptor row: lane q takes the 8-float pieces q, q + 8, ... (coalesced 32-byte loads, 16-byte stores)
+    __shared__ unsigned s_max[2];
+    const int b = blockIdx.y, tid = threadIdx.x, q = tid & 7;
+    const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
+    const int P8 = a.C / 8;
+    if (tid < 2) s_max[tid] = 0u;
+    __syncthreads();
+    const int r = min(blockIdx.x * 32 + (tid >> 3), a.max_n + a.max_m - 1);      // (a duplicate of the last row does no harm)
+    const bool second = r >= a.max_n;
+    const int row = second ? r - a.max_n : r;
+    const int cnt = second ? m : n, cap = second ? a.max_m : a.max_n;
+    const float* src = (second ? a.d1 : a.d0) + ((size_t)b * cap + row) * a.C;
+    uint4* dst = (second ? a.h1 : a.h0) + ((size_t)b * cap + row) * P8;
+    const size_t lo_off = (size_t)gridDim.y * cap * P8;
+    float nn = 0.0f;
+    if (row < cnt) {
+        for (int p8 = q; p8 < P8; p8 += 8) {
+            const float4 u = *reinterpret_cast<const float4*>(src + 8 * p8), v = *reinterpret_cast<const float4*>(src + 8 * p8 + 4);
+            const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 hh = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(f[2 * k], f[2 * k + 1]));
+                const h2 ll = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(f[2 * k] - (float)hh[0], f[2 * k + 1] - (float)hh[1]));
+                hw[k] = __builtin_bit_cast(unsigned, hh); lw[k] = __builtin_bit_cast(unsigned, ll);
+                nn = fmaf(f[2 * k], f[2 * k], nn); nn = fmaf(f[2 * k + 1], f[2 * k + 1], nn);
+            }
+            dst[p8] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+            dst[lo_off + p8] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+        }
+    }
+    nn += __shfl_xor(nn, 1, 64); nn += __shfl_xor(nn, 2, 64); nn += __shfl_xor(nn, 4, 64);       // the same tree for every row: deterministic
+    if (row < cnt && q == 0) {
+        if (!(nn < 3.0e38f)) a.flag[b] = 1;             // NaN / inf / overflow: the exact kernel takes this pair
+        else atomicMax(&s_max[second ? 1 : 0], __float_as_uint(nn));
+    }
+    if (q == 0) {
+        (second ? a.nrm1 : a.nrm0)[(size_t)b * cap + row] = nn;
+        (second ? a.colmin : a.rowmin)[(size_t)b * cap + row] = INF_BITS;
+        (second ? a.ccnt : a.rcnt)[(size_t)b * cap + row] = 0;
+    }
+    __syncthreads();
+    if (tid < 2 && s_max[tid]) atomicMax(&a.nmax[2 * b + tid], s_max[tid]);      // one global atomic per workgroup and side
+}
+
+struct ApxArgs {
+    const uint4* h0; const uint4* h1; const float* nrm0; const float* nrm1; const int* n; const int* m;
+    int max_n, max_m, P8; size_t lo0, lo1;      // lo*: offset of the lo pieces inside h0 / h1
+    unsigned* rowmin; unsigned* colmin;
+    int2* cand; int* ncand; int cap; int* flag;
+    const unsigned* nmax; int C;
+};
+
+// A wave owns RT 16-row tiles (all columns); KB = C / 32 k-blocks.  PASS 0: minima.  PASS 1: candidate list.
+constexpr int CBUF = 192;       // candidates a wave collects in LDS before it reserves room in the pair's list with ONE global atomic
+
+template <int KB, int RT, int PASS>
+__global__ __launch_bounds__(256) void match_approx(ApxArgs a)
+{
+    __shared__ int2 cbuf[PASS == 1 ? 4 : 1][PASS == 1 ? CBUF : 1];
+    int wcnt = 0;                   // wave-uniform: every append goes through a ballot
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto flush = [&]() {
+        if (PASS == 1 && wcnt > 0) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&a.ncand[b], wcnt);
+            base = __shfl(base, 0, 64);
+            for (int i = lane; i < wcnt; i += 64) {
+                if (base + i < a.cap) a.cand[(size_t)b * a.cap + base + i] = cbuf[PASS == 1 ? wv : 0][i];
+                else a.flag[b] = 1;
+            }
+            wcnt = 0;
+        }
+    };
+    const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
+    if (a.flag[b]) return;                                   // the exact kernel takes this pair
+    const int i0 = (blockIdx.x * 4 + wv) * (16 * RT);
+    if (i0 >= n) return;
+    const int c16 = lane & 15, g = lane >> 4;
+    const uint4* A = a.h0 + (size_t)b * a.max_n * a.P8;
+    const uint4* Bm = a.h1 + (size_t)b * a.max_m * a.P8;
+    mh8 ah[RT][KB], al[RT][KB];
+    float na[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = min(i0 + 16 * rt + c16, n - 1);      // A operand: lane (row c16, k-group g)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            ah[rt][kb] = __builtin_bit_cast(mh8, A[(size_t)row * a.P8 + 4 * kb + g]);
+            al[rt][kb] = __builtin_bit_cast(mh8, A[a.lo0 + (size_t)row * a.P8 + 4 * kb + g]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                         // D rows of this lane: 4 g + r
+            const int i = i0 + 16 * rt + 4 * g + r;
+            na[rt][r] = i < n ? a.nrm0[(size_t)b * a.max_n + i] : __uint_as_float(INF_BITS);
+        }
+    }
+    const float namax = __uint_as_float(a.nmax[2 * b]), nbmax = __uint_as_float(a.nmax[2 * b + 1]);
+    float rmin[RT][4];        // PASS 1: rowmin_i + mr_i
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rmin[rt][r] = PASS == 0 ? __uint_as_float(INF_BITS)
+                                                             : (i0 + 16 * rt + 4 * g + r < n ? __uint_as_float(a.rowmin[(size_t)b * a.max_n + i0 + 16 * rt + 4 * g + r]) + match_margin(na[rt][r], nbmax, a.C) : -1.0f);
+    for (int j0 = 0; j0 < m; j0 += 16) {
+        const int j = j0 + c16;
+        const int jr = min(j, m - 1);
+        mh8 bh[KB], bl[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            bh[kb] = __builtin_bit_cast(mh8, Bm[(size_t)jr * a.P8 + 4 * kb + g]);
+            bl[kb] = __builtin_bit_cast(mh8, Bm[a.lo1 + (size_t)jr * a.P8 + 4 * kb + g]);
+        }
+        const float nb = j < m ? a.nrm1[(size_t)b * a.max_m + j] : __uint_as_float(INF_BITS);
+        const float cmin_j = PASS == 1 && j < m ? __uint_as_float(a.colmin[(size_t)b * a.max_m + j]) + match_margin(namax, nb, a.C) : -1.0f;     // colmin_j + mc_j
+        float cm = __uint_as_float(INF_BITS);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            mf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[rt][kb], bh[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][kb], bl[kb], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[rt][kb], bh[kb], acc, 0, 0, 0);
+            }
+            float dd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                       // entry (row 4 g + r of tile rt, column c16); +0 (never -0: the minima are kept as unsigned bit patterns); inf past the end
+                dd[r] = fmaxf(__fadd_rn(__fadd_rn(na[rt][r], nb), -2.0f * acc[r]), 0.0f) + 0.0f;
+            if (PASS == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { rmin[rt][r] = fminf(rmin[rt][r], dd[r]); cm = fminf(cm, dd[r]); }
+            } else {
+                unsigned rowc = 0, colc = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool fin = dd[r] < __uint_as_float(INF_BITS);
+                    rowc |= (fin && dd[r] <= rmin[rt][r]) ? 1u << r : 0u;
+                    colc |= (fin && dd[r] <= cmin_j) ? 1u << r : 0u;
+                }
+                const unsigned any = rowc | colc;
+                if (__ballot(any != 0)) {                     // wave-uniform: most 16 x 16 tiles hold no candidate at all
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool hit = (any >> r) & 1u;
+                        const unsigned long long bal = __ballot(hit);
+                        if (bal) {
+                            if (hit) cbuf[PASS == 1 ? wv : 0][wcnt + __popcll(bal & ((1ull << lane) - 1ull))] =
+                                make_int2((i0 + 16 * rt + 4 * g + r) | (((rowc >> r) & 1u) ? 1 << 30 : 0) | (((colc >> r) & 1u) ? 1 << 29 : 0), j);
+                            wcnt += __popcll(bal);
+                            if (wcnt > CBUF - 64) flush();      // a wave's LDS operations execute in order: the copy sees the writes
+                        }
+                    }
+                }
+            }
+        }
+        if (PASS == 0) {            // column minimum over this wave's rows: over the four lane groups, then one atomic per column
+            cm = fminf(cm, __shfl_xor(cm, 16, 64));
+            cm = fminf(cm, __shfl_xor(cm, 32, 64));
+            if (g == 0 && j < m) atomicMin(&a.colmin[(size_t)b * a.max_m + j], __float_as_uint(cm));
+        }
+    }
+    flush();
+    if (PASS == 0) {                // row minima: over the 16 columns of a lane group; each row belongs to exactly one wave
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = rmin[rt][r];
+                v = fminf(v, __shfl_xor(v, 1, 64)); v = fminf(v, __shfl_xor(v, 2, 64));
+                v = fminf(v, __shfl_xor(v, 4, 64)); v = fminf(v, __shfl_xor(v, 8, 64));
+                const int i = i0 + 16 * rt + 4 * g + r;
+                if (c16 == 0 && i < n) a.rowmin[(size_t)b * a.max_n + i] = __float_as_uint(v);
+            }
+    }
+}
+
+struct ExactArgs {
+    const float* d0; const float* d1; const int2* cand; const int* ncand; int cap, C, max_n, max_m;
+    int* rcnt; int* ccnt; double* rs; int* rj; double* cs; int* ci; int tiles_i, tiles_j; const int* m; const int* n; int* flag;
+};
+
+// scipy's float64 sum (ascending k, no FMA: the same three instructions as match_tile) for the listed pairs only
+__global__ __launch_bounds__(256) void match_exact(ExactArgs a)
+{
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (a.flag[b] || e >= min(a.ncand[b], a.cap)) return;
+    const int2 c = a.cand[(size_t)b * a.cap + e];
+    const int i = c.x & 0x1FFFFFFF, j = c.y;
+    const float* pa = a.d0 + ((size_t)b * a.max_n + i) * a.C;
+    const float* pb = a.d1 + ((size_t)b * a.max_m + j) * a.C;
+    double s = 0.0;
+    for (int k = 0; k < a.C; k += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(pa + k), v = *reinterpret_cast<const float4*>(pb + k);
+        double d = __dsub_rn((double)u.x, (double)v.x); s = __dadd_rn(s, __dmul_rn(d, d));
+        d = __dsub_rn((double)u.y, (double)v.y); s = __dadd_rn(s, __dmul_rn(d, d));
+        d = __dsub_rn((double)u.z, (double)v.z); s = __dadd_rn(s, __dmul_rn(d, d));
+        d = __dsub_rn((double)u.w, (double)v.w); s = __dadd_rn(s, __dmul_rn(d, d));
+    }
+    const int n = a.n ? min(a.n[b], a.max_n) : a.max_n, m = a.m ? min(a.m[b], a.max_m) : a.max_m;
+    const int slots_r = (m + MTJ - 1) / MTJ, slots_c = (n + MTI - 1) / MTI;      // what match_finalize reads for this pair
+    if (c.x & (1 << 30)) {
+        const int t = atomicAdd(&a.rcnt[(size_t)b * a.max_n + i], 1);
+        if (t < slots_r) { const size_t o = ((size_t)b * a.tiles_j + t) * a.max_n + i; a.rs[o] = s; a.rj[o] = j; }
+        else a.flag[b] = 1;
+    }
+    if (c.x & (1 << 29)) {
+        const int t = atomicAdd(&a.ccnt[(size_t)b * a.max_m + j], 1);
+        if (t < slots_c) { const size_t o = ((size_t)b * a.tiles_i + t) * a.max_m + j; a.cs[o] = s; a.ci[o] = i; }
+        else a.flag[b] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ M3
@@ -313,7 +572,49 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
     double* cs = rs + nr;
     int* rj = reinterpret_cast<int*>(cs + nc);
     int* ci = rj + nr;
-    MatchArgs a{d0_dev, d1_dev, n_dev, m_dev, rs, rj, cs, ci, C, max_n, max_m, tiles_i, tiles_j};
+    // prefilter on the matrix cores + exact refinement (see match_prep): C a multiple of 32 up to 256, at least two slots per row and column
+    static const int prefilter = kpb_env_int("KPB_MATCH_PREFILTER", 1);
+    const bool pre = prefilter && (C % 32 == 0) && C <= 256 && tiles_i >= 2 && tiles_j >= 2 && (reinterpret_cast<uintptr_t>(d0_dev) % 16 == 0) &&
+                     (reinterpret_cast<uintptr_t>(d1_dev) % 16 == 0);
+    const int* only = nullptr;
+    if (pre) {
+        const int P8 = C / 8, cap = 8 * (max_n + max_m);
+        const size_t nh0 = (size_t)batch * max_n * P8, nh1 = (size_t)batch * max_m * P8;
+        const size_t words = 4 * 2 * (nh0 + nh1) + 3 * ((size_t)batch * (max_n + max_m)) + 4 * (size_t)batch + 2 * (size_t)batch * cap + 64;
+        if (int rc = kpb_reserve(ctx, ctx->ws_misc, words * 4)) return rc;
+        uint4* h0 = static_cast<uint4*>(ctx->ws_misc.p);
+        uint4* h1 = h0 + 2 * nh0;
+        float* nrm0 = reinterpret_cast<float*>(h1 + 2 * nh1);
+        float* nrm1 = nrm0 + (size_t)batch * max_n;
+        unsigned* rowmin = reinterpret_cast<unsigned*>(nrm1 + (size_t)batch * max_m);
+        unsigned* colmin = rowmin + (size_t)batch * max_n;
+        int* rcnt = reinterpret_cast<int*>(colmin + (size_t)batch * max_m);
+        int* ccnt = rcnt + (size_t)batch * max_n;
+        int* flag = ccnt + (size_t)batch * max_m;
+        int* ncand = flag + batch;
+        unsigned* nmax = reinterpret_cast<unsigned*>(ncand + batch);
+        int2* cand = reinterpret_cast<int2*>(nmax + 2 * batch + ((reinterpret_cast<uintptr_t>(nmax + 2 * batch) & 4) ? 1 : 0));
+        KPB_HIP(ctx, hipMemsetAsync(flag, 0, (size_t)batch * 4 * sizeof(int), ctx->stream));      // flag, ncand, nmax
+        PreArgs pa{d0_dev, d1_dev, n_dev, m_dev, C, max_n, max_m, h0, h1, nrm0, nrm1, rowmin, colmin, rcnt, ccnt, flag, ncand, nmax};
+        // empty slots are marked by the index INT_MAX (match_finalize skips them): one coalesced 32-bit fill of both index arrays
+        KPB_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(rj), 0x7FFFFFFF, nr + nc, ctx->stream));
+        KPB_LAUNCH(ctx, "match_prep", match_prep, dim3(cdiv(max_n + max_m, 32), batch), dim3(256), 0, ctx->stream, pa);
+        ApxArgs xa{h0, h1, nrm0, nrm1, n_dev, m_dev, max_n, max_m, P8, nh0, nh1, rowmin, colmin, cand, ncand, cap, flag, nmax, C};
+        const int KB = C / 32;
+#define KPB_APX(KB_, RT_)                                                                                                                   \
+        {                                                                                                                                       \
+            const dim3 grid(cdiv(max_n, 64 * RT_), batch);                                                                                      \
+            KPB_LAUNCH(ctx, "match_approx_min", (match_approx<KB_, RT_, 0>), grid, dim3(256), 0, ctx->stream, xa);                              \
+            KPB_LAUNCH(ctx, "match_approx_cand", (match_approx<KB_, RT_, 1>), grid, dim3(256), 0, ctx->stream, xa);                             \
+        }
+        if (KB == 1) KPB_APX(1, 4) else if (KB == 2) KPB_APX(2, 4) else if (KB == 3) KPB_APX(3, 2) else if (KB == 4) KPB_APX(4, 2)
+        else if (KB == 5) KPB_APX(5, 1) else if (KB == 6) KPB_APX(6, 1) else if (KB == 7) KPB_APX(7, 1) else KPB_APX(8, 1)
+#undef KPB_APX
+        ExactArgs ea{d0_dev, d1_dev, cand, ncand, cap, C, max_n, max_m, rcnt, ccnt, rs, rj, cs, ci, tiles_i, tiles_j, m_dev, n_dev, flag};
+        KPB_LAUNCH(ctx, "match_exact", match_exact, dim3(cdiv(cap, 256), batch), dim3(256), 0, ctx->stream, ea);
+        only = flag;
+    }
+    MatchArgs a{only, d0_dev, d1_dev, n_dev, m_dev, rs, rj, cs, ci, C, max_n, max_m, tiles_i, tiles_j};
     KPB_LAUNCH(ctx, "match_tile", match_tile, dim3(tiles_j, tiles_i, batch), dim3(MATCH_THREADS), 0, ctx->stream, a);
     FinArgs f{rs, rj, cs, ci, n_dev, m_dev, out_pairs_dev, out_dist_dev, out_k_dev,
               max_n, max_m, tiles_i, tiles_j, prm->cross_check, prm->max_distance};
