@@ -88,6 +88,8 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     c["conv3x3_b4c1"] = (2 * (P // 1024) * 9 * 32 * 64 * B2, ((P // 64) * 128 + (P // 1024) * 256) * B2)
     c["conv3x3_b4c2"] = (2 * (P // 1024) * (9 * 64 * 64 + 32 * 64) * B2, ((P // 1024) * 256 * 2 + (P // 64) * 128) * B2)
     c["conv1x1_agg2"] = (2 * (P // 4) * 16 * 16 * B2, (P // 4) * 128 * B2)
+    # block 2 fused (b2c1 + b2c2 + identity branch + agg2): reads the pooled block-1 map, writes x2, a2 and the score share
+    c["alike_block2"] = (c["conv3x3_b2c1"][0] + c["conv3x3_b2c2"][0] + c["conv1x1_agg2"][0], (P // 4) * (32 + 64 + 64 + 4) * B2)
     c["conv1x1_agg3"] = (2 * (P // 64) * 32 * 16 * B2, (P // 64) * 192 * B2)
     c["conv1x1_agg4"] = (2 * (P // 1024) * 64 * 16 * B2, (P // 1024) * 320 * B2)
     feat = 2 * 8 * 16 + 3 * 16 * 8 + 2 * 64            # agg1 + three 4-tap lerps + score dot (score-only kernel)
@@ -99,6 +101,8 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     c["sample_bilinear"] = (7 * K * C * B2, (4 * K * C * 4 + K * C * 4) * B2)
     c["alike_desc_at"] = ((2 * 64 * 64 + 4 * 64 * 8) * K * B2, (4 * 4 * 64 * 4 + K * 0 + 256) * K * B2)
     c["match_tile"] = (3 * K * K * C * B, 2 * K * C * 4 * B)     # float64 sub/mul/add per element
+    c["match_approx_min"] = (2 * K * K * C * B, 2 * K * C * 4 * B)     # the prefilter's approximate distance matrix (2 MAC flops per element), twice
+    c["match_approx_cand"] = c["match_approx_min"]
     c["match_finalize"] = (0, (2 * K * 16 * 12 + K * 20) * B)
     c["gather_rows"] = (0, K * 32 * B)
     return c

@@ -36,12 +36,6 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
 
-__device__ __forceinline__ unsigned split1(float v)     // (hi, lo) halves of one value in one 32-bit word: hi in the low half
-{
-    const _Float16 vh = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v, 0.0f))[0];
-    const _Float16 vl = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v - (float)vh, 0.0f))[0];
-    return (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
-}
 
 // ------------------------------------------------------------------------------------------------ block1
 constexpr int B1_TH = 32, B1_TW = 32;
@@ -222,6 +216,12 @@ constexpr int B1H_TH = 16;
 
 __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
 {
+    // Both products are taken TRANSPOSED, D^T = W^T A^T (the weight fragment as the MFMA's A operand, the input pieces as B:
+    // the register layouts of the two operands are the same, so this is only the argument order): the accumulator then has
+    // the pixel pair on the LANE (column) and (pixel of the pair, channel) in the four registers of the four lane groups --
+    // lane (pair, g) holds channels 4 (g & 1) .. + 3 of pixel g >> 1.  A lane therefore owns one position: one bounds test,
+    // one packed split, 8-byte LDS writes for conv1, and for conv2 one 16-byte global store per lane (16 pairs x 64 B = 1 KB
+    // contiguous per instruction), with no cross-lane traffic except the pixel-pair maximum of the pooling.
     const Block1Args& a = ha.b;
     constexpr int TH = B1H_TH, IH = TH + 4, IW = B1_TW + 4, MH = TH + 2, MW = B1_TW + 2, HW = MW / 2;     // HW: slots per row and parity
     constexpr int PLANE = MH * HW, REGION = 2 * PLANE, NIN = IH * IW;
@@ -264,55 +264,50 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         if (tid < 2) inh[2 * NIN + tid] = make_uint2(0u, 0u);
     }
     __syncthreads();
-    const int i16 = lane & 15, g = lane >> 4;
-    const int pr = (i16 >> 2) + 4 * (i16 & 3);                        // pi(i): the pair of the group this lane's A row stands for
-    const int sN = i16 >> 3, co = i16 & 7;                            // this lane's output: pixel s of the pair, channel co
-    {   // conv1 + ReLU on the MH x MW halo'd positions, 16 pairs per MFMA group
-        const float bias1 = a.b1[co];
+    const int pr = lane & 15, g = lane >> 4;                         // this lane's pair slot (operand column and accumulator column)
+    const int sN = g >> 1, c0 = 4 * (g & 1);                          // ... and what its accumulator holds: pixel sN of the pair, channels c0 .. c0 + 3
+    {   // conv1 + ReLU on the MH x MW halo'd positions, 16 pairs per MFMA group: group gi < MH = pairs 0..15 of row gi; the 17th
+        // pair of every row goes to two extra groups (rows 0..15 and 16..17)
+        const float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + c0);
         const uint4* inq = reinterpret_cast<const uint4*>(inh);       // a piece = two adjacent positions = 16 bytes (even column)
-        // MFMA groups without index arithmetic: group gi < MH = pairs 0..15 of row gi; the 17th pair of every row goes to two
-        // extra groups (rows 0..15 and 16..17): pair slot k of a group is (row, pair) = (yb + ys k, pb + ps k)
+        uint2* midh = reinterpret_cast<uint2*>(mid);
 #pragma unroll 1
         for (int gi = wv; gi < MH + 2; gi += 4) {
             const bool extra = gi >= MH;
-            const int yb = extra ? 16 * (gi - MH) : gi, ys = extra ? 1 : 0, pb = extra ? 16 : 0, ps = extra ? 0 : 1;
-            const int my = min(yb + ys * pr, MH - 1), pc = pb + ps * pr;
+            const int y = extra ? 16 * (gi - MH) + pr : gi, pc = extra ? 16 : pr;
+            const int my = min(y, MH - 1);
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const int piece = 4 * kb + g;                          // (ky, half) = (piece >> 1, piece & 1); pieces 6, 7 are empty
                 const int at = piece < 6 ? ((my + (piece >> 1)) * IW + 2 * pc + 2 * (piece & 1)) >> 1 : NIN;
-                const h8v ahi = __builtin_bit_cast(h8v, inq[at]);
-                const h8v alo = __builtin_bit_cast(h8v, inq[piece < 6 ? at + NIN / 2 : NIN]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, c1hi[kb], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, c1lo[kb], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, c1hi[kb], acc, 0, 0, 0);
+                const h8v ihi = __builtin_bit_cast(h8v, inq[at]);
+                const h8v ilo = __builtin_bit_cast(h8v, inq[piece < 6 ? at + NIN / 2 : NIN]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1hi[kb], ilo, acc, 0, 0, 0);      // small terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1lo[kb], ihi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1hi[kb], ihi, acc, 0, 0, 0);
             }
-            // D: lane (s, co) holds pair slots 4 g + r -> pi = g + 4 r; back to LDS split, channels (co, co ^ 1) per 32-bit word
-            unsigned* midw = reinterpret_cast<unsigned*>(mid);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = g + 4 * r;
-                const int y = yb + ys * k, pcc = pb + ps * k;
-                const int gy = ty0 - 1 + y, gx = tx0 - 1 + 2 * pcc + sN;
-                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;       // conv2 pads its INPUT (the ReLU'd map) with zeros
-                const unsigned mine = split1(inside ? relu(acc[r] + bias1) : 0.0f);
-                const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
-                if ((co & 1) == 0 && y < MH) {
-                    const int w = ((sN * PLANE + y * HW + pcc) << 2) + (co >> 1);
-                    midw[w] = (mine & 0xFFFFu) | (other << 16);
-                    midw[w + 4 * REGION] = (mine >> 16) | (other & 0xFFFF0000u);      // lo half: REGION slots = 4 REGION words further
-                }
+            const int gy = ty0 - 1 + y, gx = tx0 - 1 + 2 * pc + sN;
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;           // conv2 pads its INPUT (the ReLU'd map) with zeros
+            float4 v = make_float4(relu(acc[0] + bias1.x), relu(acc[1] + bias1.y), relu(acc[2] + bias1.z), relu(acc[3] + bias1.w));
+            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            if (y < MH) {
+                const int h8 = ((sN * PLANE + y * HW + pc) << 1) + (g & 1);            // 8-byte half of the position's slot
+                midh[h8] = hi;
+                midh[h8 + 2 * REGION] = lo;
             }
         }
     }
     __syncthreads();
-    // conv2 + ReLU: a wave owns rows TH/4 wv .. of the tile, one 32-pixel row = 16 pairs per MFMA group
+    // conv2 + ReLU: a wave owns TH/4 rows of the tile, one 32-pixel row = 16 pairs per MFMA group
     // piece (ky = kb, kx = g) of pair pr: tile column 2 pr + g of row + kb -> parity g & 1, slot pr + (g >> 1)
     const int abase = (g & 1) * PLANE + pr + (g >> 1);
-    const float bias = a.b2[co];
+    const float4 bias2 = *reinterpret_cast<const float4*>(a.b2 + c0);
     const int H2 = a.H / 2, W2 = a.W / 2;
-    float keep[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int gx = tx0 + 2 * pr + sN;
 #pragma unroll 1
     for (int rr = 0; rr < TH / 4; ++rr) {
         const int row = (TH / 4) * wv + rr;
@@ -320,32 +315,23 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
 #pragma unroll
         for (int kb = 0; kb < 3; ++kb) {
             const int at = abase + (row + kb) * HW;
-            const h8v ahi = __builtin_bit_cast(h8v, mid[at]);
-            const h8v alo = __builtin_bit_cast(h8v, mid[REGION + at]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[kb], acc, 0, 0, 0);      // small terms first
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[kb], acc, 0, 0, 0);
+            const h8v ihi = __builtin_bit_cast(h8v, mid[at]);
+            const h8v ilo = __builtin_bit_cast(h8v, mid[REGION + at]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[kb], ilo, acc, 0, 0, 0);      // small terms first
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(blo[kb], ihi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[kb], ihi, acc, 0, 0, 0);
         }
         const int gy = ty0 + row;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            v[r] = relu(acc[r] + bias);
-            const int gx = tx0 + 2 * (g + 4 * r) + sN;                 // pair pi(4 g + r) = g + 4 r
-            if (gy < a.H && gx < a.W) a.x1[((size_t)b * P + (size_t)gy * a.W + gx) * 8 + co] = v[r];
-        }
+        const float4 v = make_float4(relu(acc[0] + bias2.x), relu(acc[1] + bias2.y), relu(acc[2] + bias2.z), relu(acc[3] + bias2.w));
+        if (gy < a.H && gx < a.W) *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8 + c0) = v;
         if ((rr & 1) == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) keep[r] = v[r];
-        } else {        // max_pool2d(x1, 2, 2): the row pair in registers, the pixel pair one lane swap away
-            const int py = gy >> 1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float m = fmaxf(keep[r], v[r]);
-                m = fmaxf(m, __shfl_xor(m, 8, 64));
-                const int pxl = (tx0 >> 1) + g + 4 * r;
-                if (sN == 0 && py < H2 && pxl < W2) a.p1[(((size_t)b * H2 + py) * W2 + pxl) * 8 + co] = m;
-            }
+            keep = v;
+        } else {        // max_pool2d(x1, 2, 2): the row pair in registers, the other pixel of the pair two lane groups away
+            float4 m = make_float4(fmaxf(keep.x, v.x), fmaxf(keep.y, v.y), fmaxf(keep.z, v.z), fmaxf(keep.w, v.w));
+            m.x = fmaxf(m.x, __shfl_xor(m.x, 32, 64)); m.y = fmaxf(m.y, __shfl_xor(m.y, 32, 64));
+            m.z = fmaxf(m.z, __shfl_xor(m.z, 32, 64)); m.w = fmaxf(m.w, __shfl_xor(m.w, 32, 64));
+            const int py = gy >> 1, pxl = (tx0 >> 1) + pr;
+            if (sN == 0 && py < H2 && pxl < W2) *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + py) * W2 + pxl) * 8 + c0) = m;
         }
     }
 }
@@ -666,6 +652,10 @@ struct Block2Args {
 
 __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
 {
+    // All three products are taken transposed (weights as the MFMA's A operand, the input pieces as B: see alike_block1_h): the
+    // accumulator has the pixel on the LANE and channels 4 g .. 4 g + 3 in the registers of lane group g, so a lane owns one
+    // position -- one bounds test, one packed split, 8-byte LDS writes -- and x2 / a2 leave as one 16-byte store per lane
+    // (16 pixels x 64 B = 1 KB contiguous per instruction).
     constexpr int TH = 8, TW = 32, PH = TH + 4, PW = TW + 4, NP = PH * PW, MH = TH + 2, MW = TW + 2, NM = MH * MW;
     __shared__ __attribute__((aligned(16))) uint4 pin[2 * NP];          // [hi | lo][position]: the pooled block-1 tile, 8 channels per slot
     __shared__ __attribute__((aligned(16))) uint4 mid[4 * NM];          // [hi | lo][octet][position]: conv1's output
@@ -697,54 +687,50 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         if (tid == 0) zslot = make_uint4(0u, 0u, 0u, 0u);
     }
     __syncthreads();
-    const int i16 = lane & 15, g = lane >> 4;
-    const int px = (i16 >> 2) + 4 * (i16 & 3);                // pi(i)
+    const int px = lane & 15, g = lane >> 4;                  // this lane's position slot (operand column and accumulator column); it holds channels 4 g .. 4 g + 3
     const uint4* zp = &zslot;
-    {   // conv1 + ReLU -> mid (split), 16 consecutive positions per MFMA group
-        const float bias1 = a.b1[i16];
-        unsigned* midw = reinterpret_cast<unsigned*>(mid);
-        // groups without index arithmetic: gi < 2 MH = (row gi / 2, columns 16 (gi & 1) .. + 15); the two rightmost columns of all
-        // rows go to two extra groups: slot k of an extra group e is position (row, column) = ((16 e + k) / 2, 32 + (k & 1))
+    {   // conv1 + ReLU -> mid (split).  Groups gi < 2 MH = (row gi / 2, columns 16 (gi & 1) .. + 15); the two rightmost columns of
+        // all rows go to two extra groups: slot k of extra group e is position ((16 e + k) / 2, 32 + (k & 1))
+        const float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + 4 * g);
+        uint2* midh = reinterpret_cast<uint2*>(mid);
 #pragma unroll 1
         for (int gi = wv; gi < 2 * MH + 2; gi += 4) {
             const bool extra = gi >= 2 * MH;
-            const int e16 = extra ? 16 * (gi - 2 * MH) : 0;
-            const int my = extra ? min((e16 + px) >> 1, MH - 1) : gi >> 1, mx = extra ? 32 + (px & 1) : 16 * (gi & 1) + px;
+            const int k = extra ? 16 * (gi - 2 * MH) + px : 0;
+            const int y = extra ? k >> 1 : gi >> 1, x = extra ? 32 + (k & 1) : 16 * (gi & 1) + px;
+            const int my = min(y, MH - 1);
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 3; ++kb) {
                 const int tap = 4 * kb + g;
                 const bool has = tap < 9;
-                const uint4* ph = has ? &pin[(my + tap / 3) * PW + mx + tap % 3] : zp;
-                const h8v ahi = __builtin_bit_cast(h8v, ph[0]);
-                const h8v alo = __builtin_bit_cast(h8v, has ? ph[NP] : zp[0]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, w1h[kb], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w1l[kb], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w1h[kb], acc, 0, 0, 0);
+                const uint4* ph = has ? &pin[(my + tap / 3) * PW + x + tap % 3] : zp;
+                const h8v ihi = __builtin_bit_cast(h8v, ph[0]);
+                const h8v ilo = __builtin_bit_cast(h8v, has ? ph[NP] : zp[0]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[kb], ilo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[kb], ihi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[kb], ihi, acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int k = g + 4 * r;
-                const int y = extra ? (e16 + k) >> 1 : gi >> 1, x = extra ? 32 + (k & 1) : 16 * (gi & 1) + k;
-                const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
-                const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;       // conv2 pads its INPUT with zeros
-                const unsigned mine = split1(inside ? relu(acc[r] + bias1) : 0.0f);
-                const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
-                if ((i16 & 1) == 0 && y < MH) {
-                    const int w = (((i16 >> 3) * NM + y * MW + x) << 2) + ((i16 & 7) >> 1);       // word of (octet, position, channel pair) in the hi half
-                    midw[w] = (mine & 0xFFFFu) | (other << 16);
-                    midw[w + 8 * NM] = (mine >> 16) | (other & 0xFFFF0000u);               // lo half: 2 NM slots = 8 NM words further
-                }
+            const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
+            const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;           // conv2 pads its INPUT with zeros
+            float4 v = make_float4(relu(acc[0] + bias1.x), relu(acc[1] + bias1.y), relu(acc[2] + bias1.z), relu(acc[3] + bias1.w));
+            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            if (y < MH) {
+                const int h8 = (((g >> 1) * NM + y * MW + x) << 1) + (g & 1);         // 8-byte half (channels 4 g ..) of (octet g / 2, position)
+                midh[h8] = hi;
+                midh[h8 + 4 * NM] = lo;                                                // lo half: 2 NM slots = 4 NM 8-byte units further
             }
         }
     }
     __syncthreads();
     // conv2 + identity branch + ReLU -> x2; agg2 + ReLU -> a2, S2.  16 groups of 16 pixels per tile, four per wave
-    const float bsum = a.bsum[i16], wsg = a.wsg[i16];
+    const float4 bsum = *reinterpret_cast<const float4*>(a.bsum + 4 * g), wsg = *reinterpret_cast<const float4*>(a.wsg + 4 * g);
     float* x2 = a.x2 + (size_t)b * P * 16;
     float* a2 = a.a2 + (size_t)b * P * 16;
     float* S2 = a.S2 + (size_t)b * P;
-    unsigned* xw = reinterpret_cast<unsigned*>(&xs[wv][0][0][0]);
+    uint2* xh = reinterpret_cast<uint2*>(&xs[wv][0][0][0]);
 #pragma unroll 1
     for (int gi = 4 * wv; gi < 4 * wv + 4; ++gi) {
         const int row = gi >> 1, col0 = (gi & 1) * 16;
@@ -758,47 +744,38 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             if (kidx < 18) { const int tap = kidx >> 1; ph = &mid[(kidx & 1) * NM + mbase + (tap / 3) * MW + tap % 3]; lo_off = 2 * NM; }
             else if (kidx == 18) { ph = &pin[(row + 2) * PW + col0 + px + 2]; lo_off = NP; }
             else { ph = zp; lo_off = 0; }
-            const h8v ahi = __builtin_bit_cast(h8v, ph[0]);
-            const h8v alo = __builtin_bit_cast(h8v, ph[lo_off]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, w2h[kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w2l[kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, w2h[kb], acc, 0, 0, 0);
+            const h8v ihi = __builtin_bit_cast(h8v, ph[0]);
+            const h8v ilo = __builtin_bit_cast(h8v, ph[lo_off]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[kb], ilo, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[kb], ihi, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[kb], ihi, acc, 0, 0, 0);
         }
-        const int gy = ty0 + row;
-        const bool rowok = gy < a.H;
-        // x2: lane holds channel i16 of pixels pi(4 g + r) = g + 4 r (256 contiguous bytes per store instruction)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = relu(acc[r] + bsum);
-            const int gx = tx0 + col0 + g + 4 * r;
-            if (rowok && gx < a.W) x2[((size_t)gy * a.W + gx) * 16 + i16] = v;
-            const unsigned mine = split1(v);
-            const unsigned other = (unsigned)__shfl_xor((int)mine, 1, 64);
-            if ((i16 & 1) == 0) {
-                const int w = (((i16 >> 3) * 16 + g + 4 * r) << 2) + ((i16 & 7) >> 1);     // [octet][pixel] slot, channel-pair word
-                xw[w] = (mine & 0xFFFFu) | (other << 16);
-                xw[w + 128] = (mine >> 16) | (other & 0xFFFF0000u);                          // lo half: 2 x 16 slots = 128 words further
-            }
+        const int gy = ty0 + row, gx = tx0 + col0 + px;
+        const bool ok = gy < a.H && gx < a.W;
+        const float4 v = make_float4(relu(acc[0] + bsum.x), relu(acc[1] + bsum.y), relu(acc[2] + bsum.z), relu(acc[3] + bsum.w));
+        if (ok) *reinterpret_cast<float4*>(x2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = v;
+        {   // the x2 group, split, to this wave's LDS strip with the channel octets as slots: the B operand of agg2
+            uint2 hi, lo;
+            split4(v, hi, lo);
+            const int h8 = (((g >> 1) * 16 + px) << 1) + (g & 1);
+            xh[h8] = hi;
+            xh[h8 + 64] = lo;                      // lo half: 2 x 16 slots = 64 8-byte units further
         }
-        // agg2: A = the group's x2 with the pixel on the lane: piece g = channel octet g (g < 2)
         f32x4v ag = {0.f, 0.f, 0.f, 0.f};
         {
             const uint4* ph = g < 2 ? &xs[wv][0][g][px] : zp;
-            const h8v ahi = __builtin_bit_cast(h8v, ph[0]);
-            const h8v alo = __builtin_bit_cast(h8v, g < 2 ? ph[32] : zp[0]);
-            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, wah, ag, 0, 0, 0);
-            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wal, ag, 0, 0, 0);
-            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, wah, ag, 0, 0, 0);
+            const h8v ihi = __builtin_bit_cast(h8v, ph[0]);
+            const h8v ilo = __builtin_bit_cast(h8v, g < 2 ? ph[32] : zp[0]);
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah, ilo, ag, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal, ihi, ag, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah, ihi, ag, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = relu(ag[r]);
-            const int gx = tx0 + col0 + g + 4 * r;
-            if (rowok && gx < a.W) a2[((size_t)gy * a.W + gx) * 16 + i16] = v;
-            float sg = v * wsg;                    // this group's share of the score logit (the head commutes with the upsampling)
-            sg += __shfl_xor(sg, 1, 64); sg += __shfl_xor(sg, 2, 64); sg += __shfl_xor(sg, 4, 64); sg += __shfl_xor(sg, 8, 64);
-            if (i16 == 0 && rowok && gx < a.W) S2[(size_t)gy * a.W + gx] = sg;
-        }
+        const float4 av = make_float4(relu(ag[0]), relu(ag[1]), relu(ag[2]), relu(ag[3]));
+        if (ok) *reinterpret_cast<float4*>(a2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = av;
+        float sg = fmaf(av.w, wsg.w, fmaf(av.z, wsg.z, fmaf(av.y, wsg.y, av.x * wsg.x)));      // this group's share of the score logit
+        sg += __shfl_xor(sg, 16, 64);
+        sg += __shfl_xor(sg, 32, 64);
+        if (g == 0 && ok) S2[(size_t)gy * a.W + gx] = sg;
     }
 }
 
