@@ -980,6 +980,7 @@ struct HybArgs {
     const float* wsc;  // [64]
     float* score; float* desc;
     int H, W;
+    int pf;            // line prefetch of the f16 head: 0 none, 1 streaming loads, 2 plain loads
 };
 
 constexpr int SEG_TILES = 4;            // a wave owns one 128-pixel row segment
@@ -1217,11 +1218,12 @@ __global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint
         const int ncol = min(W2 - c0, npx / 2 + 2);
         const int lines_a2 = (ncol * 16 + 31) / 32;
         float dummy = 0.f;
-        if (lane < npx / 4) dummy += __builtin_nontemporal_load(x1row + lane * 32);
+        if (a.pf == 1 && lane < npx / 4) dummy += __builtin_nontemporal_load(x1row + lane * 32);
+        if (a.pf == 2 && lane < npx / 4) dummy += x1row[lane * 32];
         const int r = lane >= 34 ? 1 : 0, li = lane - 34 * r;
         const int yy = min(fy0 + r, H2 - 1);
-        if (lane < 68 && li < lines_a2) dummy += a2[((size_t)yy * W2 + c0) * 16 + li * 32];
-        if (lane + 64 < 68 && lane + 64 - 34 < lines_a2) dummy += a2[((size_t)min(fy0 + 1, H2 - 1) * W2 + c0) * 16 + (lane + 64 - 34) * 32];
+        if (a.pf && lane < 68 && li < lines_a2) dummy += a2[((size_t)yy * W2 + c0) * 16 + li * 32];
+        if (a.pf && lane + 64 < 68 && lane + 64 - 34 < lines_a2) dummy += a2[((size_t)min(fy0 + 1, H2 - 1) * W2 + c0) * 16 + (lane + 64 - 34) * 32];
         asm volatile("" :: "v"(dummy));
     }
     if (live) {
@@ -1602,7 +1604,11 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         m.in = t3; m.out = x3; m.wp = wp("b3c2.wp"); m.bias = wp("b3c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r3;
         m.Hi = H / 8; m.Wi = W / 8; m.H = H / 8; m.W = W / 8; m.CIN = 32; m.COUT = 32; m.NCH = 1; m.relu = 0; m.nblk = 1;
         m.istride = 32; m.ostride = 32; m.ooff = 0;
-        KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+        if (conv_mfma_use_h16()) {
+            m.unscale = 1.0f / (ACT_SCALE * wscale.at("b3c2.wp"));
+            KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
+        } else
+            KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
     }
     // block4 @ H/32 (143-144): pool4
     c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, wp("b4ds.w"), wp("b4ds.b"), r4, H / 32, W / 32};
@@ -1612,7 +1618,11 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         m.in = t4; m.out = x4; m.wp = wp("b4c2.wp"); m.bias = wp("b4c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r4;
         m.Hi = H / 32; m.Wi = W / 32; m.H = H / 32; m.W = W / 32; m.CIN = 64; m.COUT = 64; m.NCH = 2; m.relu = 0; m.nblk = 1;
         m.istride = 64; m.ostride = 64; m.ooff = 0;
-        KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+        if (conv_mfma_use_h16()) {
+            m.unscale = 1.0f / (ACT_SCALE * wscale.at("b4c2.wp"));
+            KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
+        } else
+            KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
     }
     // aggregation 1x1 + ReLU (147-150), each with its share of the score logit; agg1 is fused into the head
     if (!(h16 && fuse2))
@@ -1621,7 +1631,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
     // upsample + concat + head (151-162)
     if (desc_out_dev) {
-        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W};
+        static const int pf_env = kpb_env_int("KPB_HEAD_PF", 1);
+        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W, pf_env};
         const int segs_per_row = cdiv(W / 32, SEG_TILES);
         const int segs = H * segs_per_row, work4 = cdiv(H, 4) * segs_per_row;
         // measured choices (r02, 512 images of 480x640): row-group mapping 1, split-f16 fine groups, interleaved stores
@@ -1710,9 +1721,18 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         ws.put("b2c2.bsum", tmp);
         ws.put("agg2.h16", pack_1x1_h16(bl.get("agg2.w", {dim / 4, c2})));
     }
-    ws.put("b3c2.wp", pack_mfma(bl.get("b3c2.w", {c3, c3, 3, 3}), 32, 32, 3, 32, 1));
+    auto put_mfma = [&](const char* name, const float* w, int cout, int cin, int ntb) {
+        if (conv_mfma_use_h16()) {
+            const float sc = weight_scale_h(w, (size_t)cout * cin * 9);
+            ws.put(name, pack_mfma_h(w, cout, cin, 3, 32, ntb, sc));
+            ws.wscale[name] = sc;
+        } else {
+            ws.put(name, pack_mfma(w, cout, cin, 3, 32, ntb));
+        }
+    };
+    put_mfma("b3c2.wp", bl.get("b3c2.w", {c3, c3, 3, 3}), 32, 32, 1);
     ws.put("b3c2.bp", pad_bias(bl.get("b3c2.b", {c3}), 32, 32));
-    ws.put("b4c2.wp", pack_mfma(bl.get("b4c2.w", {c4, c4, 3, 3}), 64, 64, 3, 32, 2));
+    put_mfma("b4c2.wp", bl.get("b4c2.w", {c4, c4, 3, 3}), 64, 64, 2);
     ws.put("b4c2.bp", pad_bias(bl.get("b4c2.b", {c4}), 64, 64));
     for (int i = 1; i <= 4; ++i) {
         char nm[16];

@@ -3,6 +3,10 @@
 #pragma once
 #include "net.h"
 
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -19,6 +23,7 @@ struct ConvM {
     const float* res;   // optional [B][H][W][COUT] added before the ReLU (ALIKE ResBlock identity branch, ALike.py:76-79)
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
     int istride, ostride, ooff;   // floats between consecutive input / output pixels, channel offset of the output
+    float unscale = 1.0f;         // conv_mfma_h: 1 / (ACT_SCALE x the layer's weight scale)
 };
 
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2>
@@ -149,6 +154,254 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- split-f16 form
+// The same convolution with every fp32 operand written as hi + lo, hi = f16(x) rounded toward zero and lo = f16(x - hi)
+// (x - hi is exact in fp32), and each product taken as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_f16
+// with fp32 accumulation: three f16 MFMAs cover K = 16 in 96 cycles where the fp32 instruction needs 512, and the
+// dropped a_lo*b_lo term is <= 2^-22 of the product.  Both operands are scaled by powers of two first so that the lo
+// halves stay out of the f16 subnormals: the weights per layer to max|w| in [2^12, 2^13) at pack time, the activations
+// by ACT_SCALE when they are staged (exact), and the accumulator is scaled back in the epilogue (ConvM::unscale).
+// Activations beyond 65504 / ACT_SCALE = 4094 would saturate; image-normalised feature maps are orders below that.
+//
+// LDS: two planes (hi, lo) of [IH*IW] pixels x CC halves, pixel pitch 2*CC + 16 bytes = an odd number of 16-byte
+// slots, so the 16 pixels one ds_read_b128 group touches fall on distinct 4-bank sets.  A wave owns MT 32-pixel M tiles
+// (two output rows each) and reuses every weight fragment it loads (L1/L2-resident, 1 KB per wave-load) MT times;
+// MT = 2 keeps the fragment stream under the L1 rate once the MFMA time has shrunk five-fold.
+typedef _Float16 cm_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
+constexpr float ACT_SCALE = 16.0f;
+
+__device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
+{
+    const cm_h2 a = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)), b = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
+    const cm_h2 c = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.x - (float)a[0], v.y - (float)a[1]));
+    const cm_h2 d = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.z - (float)b[0], v.w - (float)b[1]));
+    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
+
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1>
+__global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
+{
+    constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
+    constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
+    constexpr int PITCH = 2 * CC + 16, PLANE = IH * IW * PITCH;     // bytes
+    constexpr int NLD = (IH * IW * Q + 255) / 256;
+    static_assert(2 * PLANE <= 65536, "conv_mfma_h: input tile exceeds the static LDS window");
+    __shared__ __attribute__((aligned(16))) unsigned char tile[2 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
+    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * 16;
+    const int Hc = POOL_IN ? a.Hi / 2 : a.Hi, Wc = POOL_IN ? a.Wi / 2 : a.Wi;
+    const int iy0 = ty0 * S - PAD, ix0 = tx0 * S - PAD;
+    if (a.active && !a.active[b]) return;
+    const float* in = a.in + (size_t)b * a.Hi * a.Wi * a.istride;
+    const int ocol = p & 15;
+    const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][tap][chunk][kb][hi/lo][h][32] x 8 halves
+    const size_t ntile_stride = (size_t)T * a.NCH * NKB * 4 * 32;
+
+    f32x16 acc[MT][NTB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+    for (int ch = 0; ch < a.NCH; ++ch) {
+        __syncthreads();
+        {
+            float4 buf[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                const int pix = idx / Q, q = idx - pix * Q;
+                const int y = pix / IW, x = pix - y * IW;
+                const int gy = iy0 + y, gx = ix0 + x;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (idx < IH * IW * Q && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
+                    if (POOL_IN) {
+                        const float* s = in + ((size_t)(2 * gy) * a.Wi + 2 * gx) * a.istride + ch * CC + 4 * q;
+                        const float4 v00 = *reinterpret_cast<const float4*>(s), v01 = *reinterpret_cast<const float4*>(s + a.istride);
+                        const float4 v10 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.istride);
+                        const float4 v11 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.istride + a.istride);
+                        v.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)); v.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
+                        v.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); v.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+                    } else {
+                        v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.istride + ch * CC + 4 * q);
+                    }
+                    if (XF) {
+                        const float4* t4 = reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + ch * CC + 4 * q) * 4);
+                        const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+                        v.x = fmaf(v.x, t0.x, t0.y); v.x = v.x >= 0.0f ? v.x : v.x * t0.z;
+                        v.y = fmaf(v.y, t1.x, t1.y); v.y = v.y >= 0.0f ? v.y : v.y * t1.z;
+                        v.z = fmaf(v.z, t2.x, t2.y); v.z = v.z >= 0.0f ? v.z : v.z * t2.z;
+                        v.w = fmaf(v.w, t3.x, t3.y); v.w = v.w >= 0.0f ? v.w : v.w * t3.z;
+                    }
+                }
+                buf[k] = v;
+            }
+#pragma unroll
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                const int pix = idx / Q, q = idx - pix * Q;
+                if (idx < IH * IW * Q) {
+                    uint2 hi, lo;
+                    cm_split4(make_float4(buf[k].x * ACT_SCALE, buf[k].y * ACT_SCALE, buf[k].z * ACT_SCALE, buf[k].w * ACT_SCALE), hi, lo);
+                    *reinterpret_cast<uint2*>(&tile[pix * PITCH + 8 * q]) = hi;
+                    *reinterpret_cast<uint2*>(&tile[PLANE + pix * PITCH + 8 * q]) = lo;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
+            const uint4* bp = wq + ((((size_t)nt0 * T + tap) * a.NCH + ch) * NKB * 4 + h) * 32 + p;
+            cm_h8 Bh[NTB][NKB], Bl[NTB][NKB], Ah[MT][NKB], Al[MT][NKB];
+#pragma unroll
+            for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    Bh[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 0) * 32]);
+                    Bl[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 2) * 32]);
+                }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int orow = 2 * (wv * MT + m) + (p >> 4);
+                const unsigned char* ap = &tile[((orow * S + ky) * IW + ocol * S + kx) * PITCH + h * KC * 2];
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
+                    Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + PLANE + 16 * kb));
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bl[n][kb], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
+                    }
+        }
+    }
+
+    // epilogue: as conv_mfma, per M tile; the accumulator carries ACT_SCALE x the layer's weight scale
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int trow = 2 * (wv * MT + m);          // first of the tile's two output rows inside the workgroup tile
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+            const int co = (nt0 + n) * 32 + p;
+            const float bias = a.bias[co];
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = fmaf(acc[m][n][r], a.unscale, bias);
+                if (a.relu) v[r] = relu(v[r]);
+            }
+            if (co >= a.COUT) continue;
+            if (!POOL_OUT) {
+                float* out = a.out + (size_t)b * a.H * a.W * a.ostride + a.ooff;
+                const float* res = a.res ? a.res + (size_t)b * a.H * a.W * a.COUT : nullptr;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int gy = ty0 + trow + (i >> 4), gx = tx0 + (i & 15);
+                    if (gy < a.H && gx < a.W) {
+                        float o = v[r];
+                        if (res) {
+                            o += res[((size_t)gy * a.W + gx) * a.COUT + co];
+                            o = relu(o);
+                        }
+                        out[((size_t)gy * a.W + gx) * a.ostride + co] = o;
+                    }
+                }
+            } else {
+                const int Ho = a.H / 2, Wo = a.W / 2;
+                float* out = a.out + (size_t)b * Ho * Wo * a.ostride + a.ooff;
+                const int gy = (ty0 + trow) / 2;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = 2 * h + (cc & 1) + 4 * (cc >> 1);
+                    const int rA = 2 * (cc & 1) + 4 * (cc >> 1);
+                    const int gx = tx0 / 2 + c;
+                    if (gy < Ho && gx < Wo)
+                        out[((size_t)gy * Wo + gx) * a.ostride + co] = fmaxf(fmaxf(v[rA], v[rA + 1]), fmaxf(v[rA + 8], v[rA + 9]));
+                }
+            }
+        }
+    }
+}
+
+// power of two that brings max|w| into [2^12, 2^13); 1 for an all-zero layer
+inline float weight_scale_h(const float* w, size_t n)
+{
+    float m = 0.0f;
+    for (size_t i = 0; i < n; ++i) m = std::max(m, std::fabs(w[i]));
+    if (!(m > 0.0f) || !std::isfinite(m)) return 1.0f;
+    int e;
+    std::frexp(m, &e);          // m = f * 2^e, f in [0.5, 1)
+    return std::ldexp(1.0f, 13 - e);
+}
+
+inline uint16_t f16_bits_rtz(float x)   // fp32 -> f16 toward zero (normal and subnormal results; |x| < 65520)
+{
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const int e = (int)((u >> 23) & 0xFF) - 127;
+    const uint32_t man = (u & 0x7FFFFFu) | 0x800000u;
+    if (((u >> 23) & 0xFF) == 0 || e < -24) return sign;
+    if (e > 15) return (uint16_t)(sign | 0x7BFFu);
+    if (e >= -14) return (uint16_t)(sign | ((uint32_t)(e + 15) << 10) | ((man >> 13) & 0x3FFu));
+    return (uint16_t)(sign | (man >> (13 + (-14 - e))));
+}
+
+inline float f16_bits_to_float(uint16_t hb)
+{
+    const int e = (hb >> 10) & 0x1F;
+    const int man = hb & 0x3FF;
+    float v = e == 0 ? std::ldexp((float)man, -24) : std::ldexp((float)(man | 0x400), e - 25);
+    return (hb & 0x8000) ? -v : v;
+}
+
+// OIHW -> conv_mfma_h fragment order [ntile][tap][chunk][kb][hi/lo][h][32] x 8 halves, scaled by `scale`; the result
+// has exactly the byte count of pack_mfma's, and is returned in a float vector so that it travels the same way
+std::vector<float> pack_mfma_h(const float* w, int COUT, int CIN, int KS, int CC, int NTB, float scale)
+{
+    const int KC = CC / 2, NKB = CC / 16, T = KS * KS, NCH = CIN / CC, NT = ((COUT + 32 * NTB - 1) / (32 * NTB)) * NTB;
+    std::vector<uint16_t> out((size_t)NT * T * NCH * NKB * 4 * 32 * 8, 0);
+    for (int nt = 0; nt < NT; ++nt)
+        for (int tap = 0; tap < T; ++tap)
+            for (int ch = 0; ch < NCH; ++ch)
+                for (int kb = 0; kb < NKB; ++kb)
+                    for (int h = 0; h < 2; ++h)
+                        for (int j = 0; j < 32; ++j)
+                            for (int e = 0; e < 8; ++e) {
+                                const int o = nt * 32 + j, c = ch * CC + h * KC + 8 * kb + e;
+                                if (o >= COUT) continue;
+                                const float x = w[((size_t)o * CIN + c) * T + tap] * scale;
+                                const uint16_t hi = f16_bits_rtz(x);
+                                const uint16_t lo = f16_bits_rtz(x - f16_bits_to_float(hi));
+                                const size_t base = (((((size_t)nt * T + tap) * NCH + ch) * NKB + kb) * 4) * 32;
+                                out[((base + (0 + h) * 32 + j) * 8) + e] = hi;
+                                out[((base + (2 + h) * 32 + j) * 8) + e] = lo;
+                            }
+    std::vector<float> f(out.size() / 2);
+    std::memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
+}
+
+// measured default (r02): the split-f16 form; KPB_CONVM_H16=0 brings back the fp32 MFMA kernels for comparison
+inline bool conv_mfma_use_h16()
+{
+    static const int v = kpb_env_int("KPB_CONVM_H16", 1);
+    return v != 0;
 }
 
 // OIHW [COUT][CIN][KS][KS] -> conv_mfma fragment order [ntile][tap][chunk][h][32][KC]

@@ -328,9 +328,25 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     a.Hi = Hi; a.Wi = Wi;
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
     a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 32 * L.ntb - 1) / (32 * L.ntb);
-    const dim3 grid(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk), block(256);
     hipStream_t st = ctx->stream;
     const bool x = xf != nullptr;
+    const dim3 block(256);
+    if (conv_mfma_use_h16()) {     // split-f16 form: stride-1 layers take two M tiles per wave (16-row workgroup tiles)
+        a.unscale = 1.0f / (ACT_SCALE * net->wscale.at(L.name + ".w"));
+        const dim3 g2(cdiv(a.W, 16), cdiv(a.H, 16), B * a.nblk), g1(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk);
+        if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<1, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 5, 1>), g1, block, 0, st, a);
+        else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no instance for ks=%d stride=%d cc=%d pool_in=%d pool_out=%d xf=%d", L.ks, S, CC, pool_in, pool_out, x);
+        return KPB_OK;
+    }
+    const dim3 grid(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk);
     if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, false, false, 1>), grid, block, 0, st, a);
     else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, false, false>), grid, block, 0, st, a);
     else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma<3, 1, 32, false, true, false>), grid, block, 0, st, a);
@@ -368,7 +384,13 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
 void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b)
 {
     if (L.mfma) {
-        ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.cc, L.ntb));
+        if (conv_mfma_use_h16()) {
+            const float sc = weight_scale_h(w, (size_t)L.cout * L.cin * L.ks * L.ks);
+            ws.put(L.name + ".w", pack_mfma_h(w, L.cout, L.cin, L.ks, L.cc, L.ntb, sc));
+            ws.wscale[L.name + ".w"] = sc;
+        } else {
+            ws.put(L.name + ".w", pack_mfma(w, L.cout, L.cin, L.ks, L.cc, L.ntb));
+        }
         ws.put(L.name + ".b", pad_bias(b, L.cout, 32 * L.ntb));
     } else {
         ws.put(L.name + ".w", pack_valu(w, L.cout, L.cin, L.ks));

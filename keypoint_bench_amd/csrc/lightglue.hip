@@ -525,6 +525,7 @@ struct kpb_lg {
     float desc_scale = 8.0f;
     float* wdev = nullptr;
     std::map<std::string, size_t> off;
+    std::map<std::string, float> wscale;   // split-f16 packs: the power-of-two weight scale of each Linear
     kpb_buf ws;
     float* wp(const std::string& n) { return wdev + off.at(n); }
 };
@@ -543,7 +544,11 @@ int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name
     a.Hi = MP / 16; a.Wi = 16; a.H = MP / 16; a.W = 16;
     a.CIN = cin; a.COUT = cout; a.NCH = cin / 32; a.relu = 0; a.nblk = (cout + 63) / 64;
     a.istride = istride; a.ostride = ostride; a.ooff = ooff;
-    KPB_LAUNCH(ctx, tag, (conv_mfma<1, 1, 32, false, false, false, 2>), dim3(1, MP / 128, S * a.nblk), dim3(256), 0, ctx->stream, a);
+    if (conv_mfma_use_h16()) {
+        a.unscale = 1.0f / (ACT_SCALE * lg->wscale.at(name + ".w"));
+        KPB_LAUNCH(ctx, tag, (conv_mfma_h<1, 1, 32, false, false, false, 2, 2>), dim3(1, cdiv(MP, 256), S * a.nblk), dim3(256), 0, ctx->stream, a);
+    } else
+        KPB_LAUNCH(ctx, tag, (conv_mfma<1, 1, 32, false, false, false, 2>), dim3(1, MP / 128, S * a.nblk), dim3(256), 0, ctx->stream, a);
     return KPB_OK;
 }
 
@@ -565,7 +570,13 @@ KPB_API int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc
         const float* w = bl.get((key + ".weight").c_str(), {cout, cin});
         const float* b = bl.get((key + ".bias").c_str(), {cout});
         if (!w || !b) return false;
-        ws.put(name + ".w", pack_mfma(w, (int)cout, (int)cin, 1, 32, 2));
+        if (conv_mfma_use_h16()) {
+            const float sc = weight_scale_h(w, (size_t)cout * cin);
+            ws.put(name + ".w", pack_mfma_h(w, (int)cout, (int)cin, 1, 32, 2, sc));
+            ws.wscale[name + ".w"] = sc;
+        } else {
+            ws.put(name + ".w", pack_mfma(w, (int)cout, (int)cin, 1, 32, 2));
+        }
         ws.put(name + ".b", pad_bias(b, (int)cout, 64));
         return true;
     };
@@ -605,7 +616,7 @@ KPB_API int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc
     LgNetShim shim;
     shim.ctx = ctx;
     if (int rc = ws.upload(&shim)) { delete lg; return rc; }
-    lg->wdev = shim.wdev; lg->off = shim.off;
+    lg->wdev = shim.wdev; lg->off = shim.off; lg->wscale = shim.wscale;
     shim.wdev = nullptr;
     *out = lg;
     return KPB_OK;

@@ -11,6 +11,7 @@ struct kpb_net {
     int desc_div = 1;   // descriptor map is (H/desc_div) x (W/desc_div)
     float* wdev = nullptr;                 // all repacked weights
     std::map<std::string, size_t> off;     // name -> float offset in wdev
+    std::map<std::string, float> wscale;   // name -> power-of-two scale a split-f16 pack was made with (conv_mfma_h)
     kpb_buf act;                           // activations of the last forward
     int B = 0, H = 0, W = 0;
     virtual ~kpb_net() {}
@@ -64,6 +65,7 @@ struct KpbwBlob {
 struct WeightStage {
     std::vector<float> host;
     std::map<std::string, size_t> off;
+    std::map<std::string, float> wscale;
     void put(const std::string& name, const std::vector<float>& v)
     {
         while (host.size() % 64) host.push_back(0.0f);   // 256-byte alignment for scalar/vector loads
@@ -79,6 +81,7 @@ struct WeightStage {
         if (hipMemcpy(net->wdev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
             return kpb_fail(ctx, KPB_E_HIP, "kpb_net_create: weight upload failed");
         net->off = off;
+        net->wscale = wscale;
         return KPB_OK;
     }
 };
