@@ -31,6 +31,26 @@ BRUTE_FORCE = dict(metric="euclidean", max_distance=5, cross_check=True)        
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 matrix (= vector) peak; the path computes in fp32
 PEAK_F64_TFLOPS = 78.6
+PEAK_F16_TFLOPS = 16 * 157.3   # MI355X_MICROARCH.md, matrix cores: the F16/BF16 forms run at 16x the fp32 MFMA rate (~2.5 PF dense)
+# Kernels that take their fp32 products as three f16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): their matrix roof,
+# counted in the fp32 FLOPs of the algorithm, is a third of the f16 peak.
+PEAK_SPLIT_TFLOPS = PEAK_F16_TFLOPS / 3.0
+
+
+def mfma_peak(kernel):
+    """Matrix roof (TFLOP/s of algorithmic fp32 FLOPs) of `kernel` in this build."""
+    env = os.environ.get
+    if kernel == "alike_head_dense":
+        return PEAK_SPLIT_TFLOPS if env("KPB_HEAD_F16", "1") != "0" else PEAK_F32_TFLOPS
+    if kernel == "alike_block1":
+        return PEAK_SPLIT_TFLOPS if env("KPB_BLOCK1_H16", "1") != "0" else PEAK_F32_TFLOPS
+    if kernel == "alike_block2":
+        return PEAK_SPLIT_TFLOPS
+    if kernel.startswith("match_approx"):
+        return PEAK_SPLIT_TFLOPS
+    if kernel in ("conv3x3_b3c2", "conv3x3_b4c2") or kernel.startswith(("sp_conv", "xf_", "disk_", "lg_")):
+        return PEAK_SPLIT_TFLOPS if env("KPB_CONVM_H16", "1") != "0" else PEAK_F32_TFLOPS
+    return PEAK_F32_TFLOPS
 
 
 # ---------------------------------------------------------------------------------------- CPU baseline
@@ -337,16 +357,16 @@ def main():
         tf, gbs = flops / avg_ms / 1e9, nbytes / avg_ms / 1e6
         if name == "match_tile":
             bound, achieved, peak, unit = "mfma", tf, PEAK_F64_TFLOPS, "TFLOP/s"     # fp64 vector peak (no MFMA used)
-        elif flops and (flops / max(nbytes, 1)) > (PEAK_F32_TFLOPS * 1e3 / PEAK_HBM_GBS):
-            bound, achieved, peak, unit = "mfma", tf, PEAK_F32_TFLOPS, "TFLOP/s"
+        elif flops and (flops / max(nbytes, 1)) > (mfma_peak(name) * 1e3 / PEAK_HBM_GBS):
+            bound, achieved, peak, unit = "mfma", tf, round(mfma_peak(name), 1), "TFLOP/s"
         else:
             bound, achieved, peak, unit = "hbm", gbs, PEAK_HBM_GBS, "GB/s"
         tot = sum(v[1] for v in prof.values())
         traffic = pmc_traffic(name, B, not args.sparse) if args.model == "alike" else None
         roof = dict(bound=bound, achieved=round(achieved, 3), peak=peak, unit=unit, frac=round(achieved / peak, 4),
                     traffic=traffic, other_roof=dict(bound="hbm" if bound == "mfma" else "mfma", achieved=round(gbs if bound == "mfma" else tf, 3),
-                                                     peak=PEAK_HBM_GBS if bound == "mfma" else PEAK_F32_TFLOPS, unit="GB/s" if bound == "mfma" else "TFLOP/s",
-                                                     frac=round((gbs / PEAK_HBM_GBS) if bound == "mfma" else (tf / PEAK_F32_TFLOPS), 4)),
+                                                     peak=PEAK_HBM_GBS if bound == "mfma" else round(mfma_peak(name), 1), unit="GB/s" if bound == "mfma" else "TFLOP/s",
+                                                     frac=round((gbs / PEAK_HBM_GBS) if bound == "mfma" else (tf / mfma_peak(name)), 4)),
                     kernel=name, avg_ms=round(avg_ms, 4), launches_per_step=calls / prof_steps,
                     share_of_step=round(total_ms / tot, 3),
                     kernels_ms_per_step={k: round(v[1] / prof_steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])})
@@ -360,7 +380,8 @@ def main():
             "config": {"workload": workload_label(args.model, args.matcher),
                        "matcher": args.matcher, "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
-                       "nms_reruns": pipe.reruns},
+                       "nms_reruns": pipe.reruns,
+                       "arithmetic": "fp32 results; matrix products as split-f16 MFMA triples with fp32 accumulation (2^-22 per product), fp64 match"},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
                         "pairs_gathered": int(allrows.shape[0])},
             "roofline": roof, "cpu_baseline": cpu, "variant": variant,

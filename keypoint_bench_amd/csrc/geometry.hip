@@ -945,7 +945,206 @@ __global__ __launch_bounds__(RS_THREADS) void recover_pose(PoseArgs a)
     if (tid == 0) a.good[b] = (int)cnt[bestc];
 }
 
+// ================================================================================================ RANSAC fundamental matrix
+// cv2.findFundamentalMat(pts0, pts1, cv2.FM_RANSAC) as utils/mvg.py:16 calls it (threshold 3, confidence 0.99, maxIters
+// 1000) -- PARITY UNPINNED like the two estimators above; numpy restatement: oracle/geometry_ref.py find_fundamental_ransac.
+// One hypothesis per thread and round: 7 distinct matches (void when the last one is collinear with two earlier ones in
+// either image), the two-dimensional null space of the 7 x 9 epipolar system by Gauss-Jordan, the cubic det(x B1 + B2),
+// its real roots in closed form, up to three models, each scored against all matches with OpenCV's error (the larger
+// squared point-to-epipolar-line distance, rounded to float32 as OpenCV stores it).  The winning minimal model is returned
+// as it is (OpenCV does not refit it).
+__device__ __forceinline__ bool last_collinear7(const double* x /* 7 x (u, v) */)
+{
+    bool bad = false;
+    for (int j = 0; j < 6; ++j) {
+        const double dx1 = x[2 * j] - x[12], dy1 = x[2 * j + 1] - x[13];
+        for (int k = 0; k < j; ++k) {
+            const double dx2 = x[2 * k] - x[12], dy2 = x[2 * k + 1] - x[13];
+            bad = bad || fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
+        }
+    }
+    return bad;
+}
+
+__device__ __forceinline__ double det3r(const double* r0, const double* r1, const double* r2)
+{
+    return r0[0] * (r1[1] * r2[2] - r1[2] * r2[1]) - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0]) + r0[2] * (r1[0] * r2[1] - r1[1] * r2[0]);
+}
+
+// real roots of c3 x^3 + c2 x^2 + c1 x + c0 (trigonometric form for three, Cardano for one); a vanishing c3 voids the sample
+__device__ int solve_cubic(double c3, double c2, double c1, double c0, double* r)
+{
+    if (!(c3 != 0.0) || !isfinite(c3) || !isfinite(c2) || !isfinite(c1) || !isfinite(c0)) return 0;
+    const double inv = 1.0 / c3;
+    const double a1 = c2 * inv, a2 = c1 * inv, a3 = c0 * inv;
+    const double Q = (a1 * a1 - 3.0 * a2) * (1.0 / 9.0);
+    const double R = (2.0 * a1 * a1 * a1 - 9.0 * a1 * a2 + 27.0 * a3) * (1.0 / 54.0);
+    const double Q3 = Q * Q * Q, d = Q3 - R * R, t2 = a1 * (1.0 / 3.0);
+    if (d > 0.0) {
+        const double theta = acos(fmin(fmax(R / sqrt(Q3), -1.0), 1.0)), t0 = -2.0 * sqrt(Q);
+        r[0] = t0 * cos(theta * (1.0 / 3.0)) - t2;
+        r[1] = t0 * cos(theta * (1.0 / 3.0) + 1.0 * (2.0 * 3.141592653589793 / 3.0)) - t2;
+        r[2] = t0 * cos(theta * (1.0 / 3.0) + 2.0 * (2.0 * 3.141592653589793 / 3.0)) - t2;
+        return 3;
+    }
+    double e = cbrt(sqrt(-d) + fabs(R));
+    if (R > 0.0) e = -e;
+    r[0] = (e != 0.0 ? e + Q / e : 0.0) - t2;
+    return 1;
+}
+
+// x1 / x2: the sample's seven pixel points (u, v interleaved).  F: up to three models, F[8] = 1.  Returns their number.
+__device__ int fundamental_7pt(const double* x1, const double* x2, double (*F)[9], bool* valid)
+{
+    for (int s = 0; s < 3; ++s) valid[s] = false;
+    double A[7 * 9];
+    for (int i = 0; i < 7; ++i) {
+        const double u1 = x1[2 * i], v1 = x1[2 * i + 1], u2 = x2[2 * i], v2 = x2[2 * i + 1];
+        double* q = A + 9 * i;
+        q[0] = u2 * u1; q[1] = u2 * v1; q[2] = u2; q[3] = v2 * u1; q[4] = v2 * v1; q[5] = v2; q[6] = u1; q[7] = v1; q[8] = 1.0;
+    }
+    if (!gauss_jordan(A, 7, 9, 7)) return 0;
+    double B1[9], B2[9];
+    for (int e = 0; e < 7; ++e) { B1[e] = -A[e * 9 + 7]; B2[e] = -A[e * 9 + 8]; }
+    B1[7] = 1.0; B1[8] = 0.0; B2[7] = 0.0; B2[8] = 1.0;
+    const double c3 = det3r(B1, B1 + 3, B1 + 6), c0 = det3r(B2, B2 + 3, B2 + 6);
+    const double c2 = det3r(B2, B1 + 3, B1 + 6) + det3r(B1, B2 + 3, B1 + 6) + det3r(B1, B1 + 3, B2 + 6);
+    const double c1 = det3r(B1, B2 + 3, B2 + 6) + det3r(B2, B1 + 3, B2 + 6) + det3r(B2, B2 + 3, B1 + 6);
+    double roots[3] = {0.0, 0.0, 0.0};
+    const int nr = solve_cubic(c3, c2, c1, c0, roots);
+    int nvalid = 0;
+    for (int s = 0; s < nr; ++s) {
+        bool fin = isfinite(roots[s]);
+        double f[9];
+        for (int e = 0; e < 9; ++e) f[e] = roots[s] * B1[e] + B2[e];
+        const double sc = f[8];
+        const bool big = fabs(sc) > RS_EPS;
+        for (int e = 0; e < 9; ++e) { F[s][e] = big ? f[e] / sc : f[e]; fin = fin && isfinite(F[s][e]); }
+        valid[s] = fin;
+        nvalid += fin;
+    }
+    return nvalid;
+}
+
+// OpenCV's FMEstimatorCallback::computeError of one correspondence, rounded to float32 as OpenCV stores it
+__device__ __forceinline__ float fm_err(const double* F, double u1, double v1, double u2, double v2)
+{
+    double a = F[0] * u1 + F[1] * v1 + F[2], b = F[3] * u1 + F[4] * v1 + F[5], c = F[6] * u1 + F[7] * v1 + F[8];
+    const double s2 = 1.0 / (a * a + b * b), d2 = u2 * a + v2 * b + c;
+    a = F[0] * u2 + F[3] * v2 + F[6]; b = F[1] * u2 + F[4] * v2 + F[7]; c = F[2] * u2 + F[5] * v2 + F[8];
+    const double s1 = 1.0 / (a * a + b * b), d1 = u1 * a + v1 * b + c;
+    return (float)fmax(d1 * d1 * s1, d2 * d2 * s2);
+}
+
+struct FundArgs {
+    const float* m0; int cols0; const float* m1; int cols1;
+    int max_k; const int32_t* k_dev; const float* scale;      // [B][4]: normalised -> pixels, fp32 (FundamentalMatrix.py:76-77)
+    const uint32_t* seed_dev; uint32_t seed;
+    double threshold, confidence; int max_iters;
+    double* F; uint8_t* mask; int32_t* info;                  // [B][9], [B][max_k], [B][4] = (found, inliers, hypotheses, 0)
+};
+
+__global__ __launch_bounds__(RS_THREADS) void ransac_fundamental(FundArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* pts = reinterpret_cast<float4*>(smem);                       // [n] (u1, v1, u2, v2) pixels
+    __shared__ double bestF[9];
+    __shared__ unsigned long long wkey[RS_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = a.k_dev ? min(a.k_dev[b], a.max_k) : a.max_k;
+    const uint32_t seed = a.seed_dev ? a.seed_dev[b] : a.seed;
+    const float* sc = a.scale + 4 * b;
+    for (int i = tid; i < n; i += RS_THREADS) {
+        const float* p0 = a.m0 + ((size_t)b * a.max_k + i) * a.cols0;
+        const float* p1 = a.m1 + ((size_t)b * a.max_k + i) * a.cols1;
+        pts[i] = make_float4(p0[0] * sc[0], p0[1] * sc[1], p1[0] * sc[2], p1[1] * sc[3]);
+    }
+    uint8_t* mask = a.mask + (size_t)b * a.max_k;
+    for (int i = tid; i < a.max_k; i += RS_THREADS) mask[i] = 0;
+    __syncthreads();
+    int32_t* info = a.info + 4 * b;
+    double* Fout = a.F + 9 * b;
+    if (n < 8) {        // utils/mvg.py:13-15 never calls cv2 below eight matches
+        if (tid < 9) Fout[tid] = 0.0;
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = 0; info[3] = 0; }
+        return;
+    }
+    const float t2 = (float)(a.threshold * a.threshold);
+    int done = 0, niters = a.max_iters, best = 0;
+    while (done < niters) {
+        const uint32_t it = (uint32_t)(done + tid);
+        int idx[7] = {0, 0, 0, 0, 0, 0, 0};
+        bool ok = draw_samples<7>(seed, it, n, idx) && (int)it < a.max_iters;
+        double x1[14], x2[14];
+        for (int j = 0; j < 7; ++j) { const float4 q = pts[idx[j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
+        ok = ok && !last_collinear7(x1) && !last_collinear7(x2);
+        double F[3][9];
+        bool valid[3] = {false, false, false};
+        int nv = 0;
+        if (ok) nv = fundamental_7pt(x1, x2, F, valid);
+        int bcnt = 0, bslot = 0;
+        if (nv) {
+            for (int s = 0; s < 3; ++s) {
+                if (!valid[s]) continue;
+                int cnt = 0;
+                for (int i = 0; i < n; ++i) { const float4 q = pts[i]; cnt += fm_err(F[s], q.x, q.y, q.z, q.w) <= t2; }
+                if (cnt > bcnt) { bcnt = cnt; bslot = s; }
+            }
+        }
+        const unsigned low = (0x0FFFFFFFu - it) * 16u + (15u - (unsigned)bslot);
+        const unsigned long long key = ((unsigned long long)(unsigned)bcnt << 32) | low;
+        unsigned long long kmax = key;
+        for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_down(kmax, o); kmax = t > kmax ? t : kmax; }
+        if ((tid & 63) == 0) wkey[tid >> 6] = kmax;
+        __syncthreads();
+        kmax = wkey[0];
+        for (int w = 1; w < RS_THREADS / 64; ++w) kmax = wkey[w] > kmax ? wkey[w] : kmax;
+        const int top = (int)(kmax >> 32);
+        if (top > max(best, 6)) {
+            best = top;
+            if (key == kmax) for (int e = 0; e < 9; ++e) bestF[e] = F[bslot][e];
+        }
+        __syncthreads();
+        done += RS_THREADS;
+        niters = best ? update_iters(a.confidence, (double)(n - best) / n, 7, a.max_iters) : a.max_iters;
+    }
+    if (best == 0) {
+        if (tid < 9) Fout[tid] = 0.0;
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = done; info[3] = 0; }
+        return;
+    }
+    double Fb[9];
+    for (int e = 0; e < 9; ++e) Fb[e] = bestF[e];
+    for (int i = tid; i < n; i += RS_THREADS) { const float4 q = pts[i]; mask[i] = fm_err(Fb, q.x, q.y, q.z, q.w) <= t2; }
+    if (tid < 9) Fout[tid] = Fb[tid];
+    if (tid == 0) { info[0] = 1; info[1] = best; info[2] = done; info[3] = 0; }
+}
+
 }  // namespace
+
+extern "C" __attribute__((visibility("default"))) int kpb_find_fundamental(
+    kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k, const int32_t* k_dev,
+    const float* scale_dev, const uint32_t* seed_dev, uint32_t seed, const kpb_ransac_params* prm, double* out_f_dev, uint8_t* out_mask_dev,
+    int32_t* out_info_dev)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_find_fundamental: null context");
+    if (batch <= 0 || max_k < 0 || cols0 < 2 || cols1 < 2 || !scale_dev || !prm || !out_f_dev || !out_info_dev || (max_k && (!m0_dev || !m1_dev || !out_mask_dev)))
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_fundamental: bad argument");
+    if ((size_t)max_k * sizeof(float4) > 128 * 1024)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_fundamental: at most %d matches per pair", (int)(128 * 1024 / sizeof(float4)));
+    if (!(prm->threshold > 0.0) || prm->max_iters < 1) return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_fundamental: bad parameters");
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    FundArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, seed_dev, seed, prm->threshold, prm->confidence, prm->max_iters,
+               out_f_dev, out_mask_dev, out_info_dev};
+    static bool attr_set = false;
+    if (!attr_set) {
+        KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_fundamental), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_set = true;
+    }
+    KPB_LAUNCH(ctx, "ransac_fundamental", ransac_fundamental, dim3(batch), dim3(RS_THREADS), (size_t)max_k * sizeof(float4), ctx->stream, a);
+    KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
 
 extern "C" __attribute__((visibility("default"))) int kpb_find_essential(
     kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k, const int32_t* k_dev,

@@ -561,3 +561,146 @@ def estimate_pose(kpts0, kpts1, K0, K1, thresh, conf=0.99999, seed=0):
     if n > 0:
         return R, t, mask_new > 0
     return None
+
+
+# --------------------------------------------------------------------------------------------- fundamental matrix (7 points)
+# cv2.findFundamentalMat(pts0, pts1, cv2.FM_RANSAC) as utils/mvg.py:16 calls it: ransacReprojThreshold 3, confidence
+# 0.99, maxIters 1000; 7-point samples (degenerate when the last drawn point is collinear with two earlier ones in
+# either image); up to three models per sample (the real roots of det(x F1 + F2) = 0 over the two-dimensional null space
+# of the 7x9 epipolar system, built from the raw pixel coordinates in double); error of a correspondence = the larger of
+# its two squared point-to-epipolar-line distances; inlier when error <= threshold^2; the best model's inliers are the
+# mask.  No refit follows (OpenCV returns the best minimal model).  PARITY UNPINNED, as everything in this file.
+F_MAX_ITERS = 1000
+F_CONFIDENCE = 0.99
+F_THRESHOLD = 3.0
+FLT_EPSILON = 1.1920928955078125e-07
+
+
+def have_collinear(p):
+    """OpenCV's haveCollinearPoints on samples p [T, m, 2]: is the LAST point on (or too close to) a line through two
+    earlier ones."""
+    T, m, _ = p.shape
+    bad = np.zeros(T, bool)
+    i = m - 1
+    for j in range(i):
+        dx1, dy1 = p[:, j, 0] - p[:, i, 0], p[:, j, 1] - p[:, i, 1]
+        for k in range(j):
+            dx2, dy2 = p[:, k, 0] - p[:, i, 0], p[:, k, 1] - p[:, i, 1]
+            bad |= np.abs(dx2 * dy1 - dy2 * dx1) <= FLT_EPSILON * (np.abs(dx1) + np.abs(dy1) + np.abs(dx2) + np.abs(dy2))
+    return bad
+
+
+def _det3(m):
+    return (m[..., 0, 0] * (m[..., 1, 1] * m[..., 2, 2] - m[..., 1, 2] * m[..., 2, 1])
+            - m[..., 0, 1] * (m[..., 1, 0] * m[..., 2, 2] - m[..., 1, 2] * m[..., 2, 0])
+            + m[..., 0, 2] * (m[..., 1, 0] * m[..., 2, 1] - m[..., 1, 1] * m[..., 2, 0]))
+
+
+def solve_cubic(c3, c2, c1, c0):
+    """Real roots of c3 x^3 + c2 x^2 + c1 x + c0 for T polynomials (the trigonometric / Cardano form OpenCV's solveCubic
+    uses).  Returns (roots [T, 3], valid [T, 3]); a vanishing leading coefficient voids the sample."""
+    T = len(c3)
+    roots = np.zeros((T, 3))
+    valid = np.zeros((T, 3), bool)
+    lead = (c3 != 0) & np.isfinite(c3) & np.isfinite(c2) & np.isfinite(c1) & np.isfinite(c0)
+    inv = 1.0 / np.where(lead, c3, 1.0)
+    a1, a2, a3 = c2 * inv, c1 * inv, c0 * inv
+    Q = (a1 * a1 - 3.0 * a2) * (1.0 / 9.0)
+    R = (2.0 * a1 * a1 * a1 - 9.0 * a1 * a2 + 27.0 * a3) * (1.0 / 54.0)
+    Q3 = Q * Q * Q
+    d = Q3 - R * R
+    three = lead & (d > 0)
+    with np.errstate(all="ignore"):
+        theta = np.arccos(np.clip(R / np.sqrt(np.where(three, Q3, 1.0)), -1.0, 1.0))
+        t0 = -2.0 * np.sqrt(np.where(three, Q, 0.0))
+        t2 = a1 * (1.0 / 3.0)
+        for k in range(3):
+            roots[:, k] = np.where(three, t0 * np.cos(theta * (1.0 / 3.0) + k * (2.0 * np.pi / 3.0)) - t2, roots[:, k])
+            valid[:, k] = three
+        one = lead & ~three
+        e = np.cbrt(np.sqrt(np.where(one, -d, 0.0)) + np.abs(R))
+        e = np.where(R > 0, -e, e)
+        x = np.where(e != 0, e + Q / np.where(e != 0, e, 1.0), 0.0) - t2
+    roots[:, 0] = np.where(one, x, roots[:, 0])
+    valid[:, 0] |= one
+    valid &= np.isfinite(roots)
+    return roots, valid
+
+
+def fundamental_7pt(x1, x2):
+    """x1, x2 [T, 7, 2] pixel coordinates -> (F [T, 3, 3, 3] up to three models each with F[2,2] = 1, valid [T, 3])."""
+    T = x1.shape[0]
+    u1, v1, u2, v2 = x1[..., 0], x1[..., 1], x2[..., 0], x2[..., 1]
+    A = np.stack([u2 * u1, u2 * v1, u2, v2 * u1, v2 * v1, v2, u1, v1, np.ones_like(u1)], -1)       # [T, 7, 9]
+    G, ok = _gauss_jordan(A, 7)
+    # null space: b_j = (-G[:, :, 7 + j], e_j), j = 0, 1
+    B1 = np.concatenate([-G[:, :, 7], np.ones((T, 1)), np.zeros((T, 1))], 1).reshape(T, 3, 3)
+    B2 = np.concatenate([-G[:, :, 8], np.zeros((T, 1)), np.ones((T, 1))], 1).reshape(T, 3, 3)
+    # det(x B1 + B2) = c3 x^3 + c2 x^2 + c1 x + c0, expanded by rows
+    c3, c0 = _det3(B1), _det3(B2)
+    c2 = np.zeros(T)
+    c1 = np.zeros(T)
+    for r in range(3):
+        m = B1.copy(); m[:, r] = B2[:, r]; c2 += _det3(m)
+        m = B2.copy(); m[:, r] = B1[:, r]; c1 += _det3(m)
+    roots, valid = solve_cubic(c3, c2, c1, c0)
+    valid &= ok[:, None]
+    F = roots[:, :, None, None] * B1[:, None] + B2[:, None]                 # [T, 3, 3, 3]
+    s = F[..., 2, 2]
+    big = np.abs(s) > 2.220446049250313e-16
+    F = F / np.where(big, s, 1.0)[..., None, None]
+    valid &= np.isfinite(F).all((-1, -2))
+    return F, valid
+
+
+def fm_error(F, x1, x2):
+    """OpenCV's FMEstimatorCallback::computeError: F [..., 3, 3], x1 / x2 [N, 2] -> [..., N], float32 like OpenCV's err."""
+    X1 = np.concatenate([x1, np.ones((len(x1), 1))], 1)
+    X2 = np.concatenate([x2, np.ones((len(x2), 1))], 1)
+    l2 = np.einsum("...ij,nj->...ni", F, X1)           # epipolar lines in image 2
+    l1 = np.einsum("...ji,nj->...ni", F, X2)           # in image 1
+    with np.errstate(all="ignore"):
+        d2 = (l2 * X2).sum(-1); s2 = 1.0 / (l2[..., 0] ** 2 + l2[..., 1] ** 2)
+        d1 = (l1 * X1).sum(-1); s1 = 1.0 / (l1[..., 0] ** 2 + l1[..., 1] ** 2)
+        return np.maximum(d1 * d1 * s1, d2 * d2 * s2).astype(np.float32)
+
+
+def find_fundamental_ransac(x1, x2, seed=0, threshold=F_THRESHOLD, confidence=F_CONFIDENCE, max_iters=F_MAX_ITERS):
+    """cv2.findFundamentalMat(x1, x2, cv2.FM_RANSAC) restated for n >= 8 (utils/mvg.py:13 never calls it with fewer).
+    x1, x2 [N, 2] pixel coordinates (float32 values).  Returns (F [3,3] or None, mask [N] uint8, info)."""
+    x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
+    n = len(x1)
+    mask = np.zeros(n, np.uint8)
+    if n < 8:
+        return None, mask, dict(iters=0, inliers=0)
+    t2 = np.float32(threshold * threshold)
+    best_cnt, best_F, niters, done = 0, None, max_iters, 0
+    while done < niters:
+        its = np.arange(done, done + ROUND)
+        idx, ok = draw_samples(seed, its, n, 7)
+        ok &= ~have_collinear(x1[idx]) & ~have_collinear(x2[idx]) & (its < max_iters)
+        F, valid = fundamental_7pt(x1[idx], x2[idx])
+        valid &= ok[:, None]
+        with np.errstate(invalid="ignore"):
+            cnt = (fm_error(F, x1, x2) <= t2).sum(-1)
+        cnt = np.where(valid, cnt, 0)                                   # [ROUND, 3]
+        flat = cnt.reshape(-1)
+        j = int(np.argmax(flat))                                        # lowest iteration, then lowest root slot
+        if flat[j] > max(best_cnt, 6):
+            best_cnt, best_F = int(flat[j]), F[j // 3, j % 3]
+        done += ROUND
+        niters = update_iters(confidence, (n - best_cnt) / n, 7, max_iters) if best_cnt else max_iters
+    if best_F is None:
+        return None, mask, dict(iters=done, inliers=0)
+    mask[fm_error(best_F, x1, x2) <= t2] = 1
+    return best_F, mask, dict(iters=done, inliers=int(best_cnt))
+
+
+def fundamental_estimate(pts0, pts1, seed=0):
+    """utils/mvg.py:4-19 with the cv2 call answered by the restatement above."""
+    if len(pts0) < 8:
+        return None, pts0, pts1
+    F, mask, _ = find_fundamental_ransac(pts0, pts1, seed=seed)
+    if F is None:                   # cv2 hands back (None, None); the reference then fails on mask.ravel()
+        raise AttributeError("'NoneType' object has no attribute 'ravel'")
+    return F, pts0[mask == 1], pts1[mask == 1]

@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 b = json.load(open(os.path.join(src, R, "bench_default.json")))
 B = b["config"]["pairs_per_step_per_gpu"]
-shutil.copy(glob.glob(os.path.join(src, R, "stats", "*", "*_kernel_stats.csv"))[0], os.path.join(dst, "%s_bench_default_kernel_stats.csv" % R))
+shutil.copy(max(glob.glob(os.path.join(src, R, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime), os.path.join(dst, "%s_bench_default_kernel_stats.csv" % R))
 shutil.copy(os.path.join(src, R, "bench_default.json"), os.path.join(dst, "%s_bench_default.json" % R))
 shutil.copy(os.path.join(src, R, "bench_sparse.json"), os.path.join(dst, "%s_bench_sparse.json" % R))
 for mode in ("dense", "sparse"):
