@@ -229,6 +229,18 @@ int kpb_recover_pose(kpb_ctx* ctx, const double* e_dev, const double* pts_dev, c
                      const int32_t* k_dev, const int32_t* info_dev, double dist, double* out_rt_dev, uint8_t* out_mask_dev,
                      int32_t* out_good_dev);
 
+/* ---- 8(f)3: fundamental matrix, cv2.findFundamentalMat(pts0, pts1, cv2.FM_RANSAC) as called at utils/mvg.py:16 (the
+ * FundamentalMatrixRansac task, tasks/FundamentalMatrix.py:12-86) -- PARITY UNPINNED, like kpb_find_homography (OpenCV absent;
+ * restated: 7-point samples, up to three models each, error = the larger squared point-to-epipolar-line distance, the
+ * winning minimal model returned unrefined).  Arguments as kpb_find_homography; params: threshold 3.0, confidence 0.99,
+ * max_iters 1000 are cv2's defaults, `refine` is ignored.  scale_dev: (w-1, h-1, w-1, h-1) at FundamentalMatrix.py:76-77.
+ * out_f_dev [batch][9] float64 row-major with F[2][2] = 1 (zeros when nothing was found), out_mask_dev [batch][max_k] its
+ * inliers, out_info_dev [batch][4] = (found, inliers, hypotheses evaluated, 0).  Fewer than 8 matches: found = 0
+ * (utils/mvg.py:13-15 does not call cv2 then and keeps every match). */
+int kpb_find_fundamental(kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k,
+                         const int32_t* k_dev, const float* scale_dev, const uint32_t* seed_dev, uint32_t seed,
+                         const kpb_ransac_params* params, double* out_f_dev, uint8_t* out_mask_dev, int32_t* out_info_dev);
+
 /* ---- 8(f)2: per-image input transform after decoding, datasets/hpatches.py:47-69 --------------------
  * src_dev [batch][Hs][Ws][3] uint8 as decoded (BGR from cv2.imread with swap_rb = 1, RGB with 0);
  * out_dev [batch][3][Hd][Wd] fp32 = cv2.resize(src / 255, (Wd, Hd)) (INTER_LINEAR), channels first.

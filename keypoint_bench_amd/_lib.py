@@ -64,6 +64,8 @@ SIGNATURES = {
                                    c_float, c_void_p, c_void_p]),
     "kpb_find_homography": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_uint32,
                                     ctypes.POINTER(RansacParams), c_void_p, c_void_p, c_void_p]),
+    "kpb_find_fundamental": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, ctypes.c_uint32,
+                                     ctypes.POINTER(RansacParams), c_void_p, c_void_p, c_void_p]),
     "kpb_find_essential": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    ctypes.c_uint32, c_double, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "kpb_recover_pose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_double, c_void_p, c_void_p,

@@ -149,7 +149,7 @@ def aggregate(task_type, rows, params=None):
     if task_type == "AUC":                # rows: [max(err_t, err_R), inliers]
         th = params["AUC_params"]["th"] if params else [5, 10, 20]
         return {"AUC": [float(a) for a in pose_auc(rows[:, 0], th)], "inliers": float(rows[:, 1].mean())}
-    if task_type == "FundamentalMatrix":  # rows: [error, ratio, num]
+    if task_type in ("FundamentalMatrix", "FundamentalMatrixRansac"):  # rows: [error, ratio, num]
         return {"fundamental_error": float(rows[:, 0].mean()), "fundamental_radio": float(rows[:, 1].mean()),
                 "fundamental_num": float(rows[:, 2].mean())}
     if task_type == "match_stats":        # rows: [n0, n1, matches]
@@ -212,7 +212,15 @@ def match_stats(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, p
     return [k0.shape[0], k1.shape[0], m0.shape[0]]
 
 
-TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "AUC": auc_row, "match_stats": match_stats}
+def fund_ransac_row(idx, img0, score0, desc0, img1, score1, desc1, warp01, warp10, params, matcher=None):
+    """model_interface.py:277-282: [0, kept / detected keypoints, kept keypoints] (tasks/FundamentalMatrix.py:86)."""
+    from .tasks.FundamentalMatrix import fundamental_matrix_ransac
+    r = fundamental_matrix_ransac(idx, img0, img1, score0, score1, desc0, desc1, matcher, params)
+    return [float(r["fundamental_error"]), float(r["fundamental_radio"]), float(r["fundamental_num"])]
+
+
+TASKS = {"repeatability": repeatability_row, "MHA": mha_row, "AUC": auc_row, "match_stats": match_stats,
+         "FundamentalMatrixRansac": fund_ransac_row}
 
 
 # ---- the same tasks over a whole PairPipeline batch (rows equal to the single-pair functions above)
@@ -241,6 +249,11 @@ def _batched_auc(pipe, items, params, indices=None):
     return auc_batch(pipe, items, params, indices)
 
 
+def _batched_fund_ransac(pipe, items, params, indices=None):
+    from .tasks.FundamentalMatrix import fundamental_ransac_batch
+    return fundamental_ransac_batch(pipe, items, params, indices)
+
+
 def _covis_tables(items, B, dev):
     """(hmat [2B,9], wh [2B,2]) of the MHA flow: rows 0..B-1 warp01 of each pair, B..2B-1 warp10 (padded by repetition)."""
     from .tasks.repeatability import homography_tables
@@ -252,7 +265,8 @@ def _covis_tables(items, B, dev):
 
 # task -> (rows function, pipeline needs the match stage, keypoints are covisibility-filtered before matching)
 BATCHED_TASKS = {"match_stats": (_batched_match_stats, True, False), "repeatability": (_batched_repeatability, False, False),
-                 "MHA": (_batched_mha, True, True), "AUC": (_batched_auc, True, False)}
+                 "MHA": (_batched_mha, True, True), "AUC": (_batched_auc, True, False),
+                 "FundamentalMatrixRansac": (_batched_fund_ransac, True, False)}
 
 
 def _homo_only(item):
@@ -293,8 +307,9 @@ class PairRunner:
         with torch.no_grad():
             s0, d0 = self.model(img0)     # model_interface.py:205-207
             s1, d1 = self.model(img1)
+        kw = {"matcher": self.matcher} if self.task_fn is fund_ransac_row else {}
         r = self.task_fn(idx, img0, s0, d0, img1, s1, d1, batch.get("warp01_params", {}), batch.get("warp10_params", {}),
-                         self.params)
+                         self.params, **kw)
         self.results.append(r)
         return r
 
@@ -355,6 +370,9 @@ class PairRunner:
 
     def _run_pairs(self, dataset, indices, task_type):
         batched = (not self.user_task) and task_type in BATCHED_TASKS and self.batch > 1 and hasattr(self.model, "_handle")
+        if task_type == "FundamentalMatrixRansac":          # the batched rows are the brute-force branch without cv2 drawing
+            mp = self.params["matcher_params"]
+            batched = batched and mp["type"] == "brute_force" and not mp.get("save_result") and not self.params["extractor_params"].get("save_result")
         out, group, shape = {}, [], None
 
         def flush():
@@ -366,7 +384,7 @@ class PairRunner:
 
         for i in indices:
             item = dataset[i]
-            if not batched or (task_type != "AUC" and not _homo_only(item)):
+            if not batched or (task_type not in ("AUC", "FundamentalMatrixRansac") and not _homo_only(item)):
                 flush()
                 out[i] = self.test_step(item, i)
                 continue

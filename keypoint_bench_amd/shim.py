@@ -212,7 +212,7 @@ def _table():
     from .models.lightglue import LightGlue
     from .tasks import repeatability as rp
     from .tasks import FundamentalMatrix as fm
-    from .utils import extracter as ex, matcher as ma, projection as pj
+    from .utils import extracter as ex, matcher as ma, mvg, projection as pj
     fn, net = "fn", "net"
     return [
         ("utils.extracter", "detection", fn, ex.detection, _c_detection),
@@ -224,6 +224,8 @@ def _table():
         ("utils.projection", "warp_se3", fn, pj.warp_se3, _c_first),
         ("tasks.repeatability", "val_key_points", fn, rp.val_key_points, _c_vkp),
         ("tasks.FundamentalMatrix", "fundamental_matrix", fn, fm.fundamental_matrix, fm.in_contract),
+        ("tasks.FundamentalMatrix", "fundamental_matrix_ransac", fn, fm.fundamental_matrix_ransac, fm.ransac_in_contract),
+        ("utils.mvg", "fundamental_estimate", fn, mvg.fundamental_estimate, _c_first),
         ("models.ALike", "ALNet", net, ALNet, None),
         ("models.SuperPoint", "SuperPointNet", net, SuperPointNet, None),
         ("models.XFeat", "XFeatModel", net, XFeatModel, None),

@@ -1,7 +1,9 @@
-"""Drop-in for the reference's tasks/FundamentalMatrix.py `fundamental_matrix` (89-161), the task of BASELINE configs[3]
+"""Drop-in for the reference's tasks/FundamentalMatrix.py: `fundamental_matrix` (89-161), the task of BASELINE configs[3]
 (XFeat + brute-force match on TartanAir): detection on both score maps, one of the three matcher branches, then the
 epipolar residual of the matches against the ground-truth fundamental matrix -- all on the device
-(csrc/geometry.hip `epipolar_error`); three numbers come back to the host per pair."""
+(csrc/geometry.hip `epipolar_error`); three numbers come back to the host per pair.  And `fundamental_matrix_ransac`
+(12-86, task_type FundamentalMatrixRansac of config/long_term.yaml): the same front end, then the share of keypoints that
+survive cv2.findFundamentalMat(FM_RANSAC) -- restated on the device (utils/mvg.py here; PARITY UNPINNED, OpenCV absent)."""
 import torch
 
 from .._lib import Context, ptr
@@ -65,3 +67,68 @@ def fundamental_matrix(step, last_img, batch, score_map_0, score_map_1, desc_map
                               params["FundamentalMatrix_params"]["th"])
     s = stats[0].cpu()
     return {"fundamental_error": s[0], "fundamental_radio": float(s[2]) / k, "fundamental_num": int(s[2])}
+
+
+def _ransac_branch(kps0, kps1, score_map_0, desc_map_0, desc_map_1, matcher, params):
+    """FundamentalMatrix.py:52-69: like match_branch, but every branch leaves three columns."""
+    from ..utils.matcher import brute_force_matcher, optical_flow_tensor
+    mp = params["matcher_params"]
+    h, w = score_map_0.shape[2], score_map_0.shape[3]
+    if mp["type"] == "optical_flow":
+        k1 = optical_flow_tensor(kps0[:, 0:2], kps0[:, 0:2], desc_map_0, desc_map_1, mp["optical_flow_params"])
+        return kps0, torch.cat([k1[0], torch.ones(k1.shape[1], 1, device=k1.device)], dim=1)
+    if mp["type"] == "brute_force" or (mp["type"] == "light_glue" and matcher is None):
+        return brute_force_matcher(kps0, kps1, desc_map_0, desc_map_1, mp["brute_force_params"])
+    if mp["type"] == "light_glue":
+        return matcher.match(kps0, kps1, desc_map_0, desc_map_1, {"w": w, "h": h})
+    return kps0, kps1           # any other type: the reference matches nothing and pairs the rows as they are
+
+
+def ransac_in_contract(step, image_0, image_1, score_map_0, score_map_1, desc_map_0, desc_map_1, matcher, params):
+    if not (torch.is_tensor(score_map_0) and score_map_0.is_cuda):
+        return "score maps are not on a HIP device"
+    if params["matcher_params"].get("save_result") or params["extractor_params"].get("save_result"):
+        return "save_result draws with cv2"
+    return None
+
+
+def fundamental_matrix_ransac(step, image_0, image_1, score_map_0, score_map_1, desc_map_0, desc_map_1, matcher, params, seed=None):
+    """tasks/FundamentalMatrix.py:12-86 without its cv2 drawing (save_result must be off).  Returns the reference's dict:
+    fundamental_error 0, fundamental_radio = kept keypoints / detected keypoints, fundamental_num = kept keypoints.
+    `seed` (default: step) drives the RANSAC sampler."""
+    from ..utils.extracter import detection
+    from ..utils.mvg import find_fundamental
+    h, w = score_map_0.shape[2], score_map_0.shape[3]
+    kps0 = detection(score_map_0, params["extractor_params"])                   # 32, 35
+    kps1 = detection(score_map_1, params["extractor_params"])
+    total_size = kps0.shape[0] + kps1.shape[0]
+    kps0, kps1 = _ransac_branch(kps0, kps1, score_map_0, desc_map_0, desc_map_1, matcher, params)
+    n = kps0.shape[0]
+    if n < 8:                       # utils/mvg.py:13-15: no estimate, every match kept
+        kept = n
+    else:                           # 76-78: (x, y) scaled by (w - 1, h - 1) in fp32, then cv2.findFundamentalMat(FM_RANSAC)
+        _, mask, info = find_fundamental(kps0[None, :, :-1], kps1[None, :, :-1], [w - 1, h - 1, w - 1, h - 1], seed=step if seed is None else seed)
+        found, kept = (int(v) for v in info[0, :2].cpu())
+        if not found:               # cv2 returns (None, None) and utils/mvg.py:17 fails on it
+            raise AttributeError("'NoneType' object has no attribute 'ravel'")
+    valid_size = 2 * kept
+    return {"fundamental_error": 0, "fundamental_radio": valid_size / total_size, "fundamental_num": valid_size}
+
+
+def fundamental_ransac_batch(pipe, items, params, indices=None):
+    """The FundamentalMatrixRansac rows [error 0, ratio, num] of a whole PairPipeline batch (brute-force branch): one
+    launch of the 7-point RANSAC over the batch's matches; sampler seed of a pair = its index in the run."""
+    from ..utils.mvg import find_fundamental
+    B, f = pipe.B, len(items)
+    H, W = pipe.H, pipe.W
+    seeds = list(indices) + [0] * (B - f) if indices is not None else None
+    _, _, info = find_fundamental(pipe.m0, pipe.m1, [W - 1, H - 1, W - 1, H - 1], k_dev=pipe.k, seeds=seeds)
+    info = info.cpu().numpy()
+    n, k = pipe.n.cpu().numpy(), pipe.k.cpu().numpy()
+    rows = []
+    for b in range(f):
+        if k[b] >= 8 and not info[b, 0]:
+            raise AttributeError("'NoneType' object has no attribute 'ravel'")
+        kept = int(info[b, 1]) if k[b] >= 8 else int(k[b])
+        rows.append([0.0, 2.0 * kept / float(n[b] + n[B + b]), 2.0 * kept])
+    return rows

@@ -1,5 +1,7 @@
 """Robust two-view geometry on the device: what the reference gets from OpenCV --
-`cv2.findHomography(pts0, pts1, cv2.RANSAC)` (tasks/MHA.py:45-47) -- computed by csrc/geometry.hip through libkpb.so.
+`cv2.findHomography(pts0, pts1, cv2.RANSAC)` (tasks/MHA.py:45-47), `cv2.findEssentialMat` + `cv2.recoverPose`
+(tasks/AUC.py:50-64), `cv2.findFundamentalMat(pts0, pts1, cv2.FM_RANSAC)` (utils/mvg.py:16, the reference module this one
+stands in for: `fundamental_estimate` keeps its name and return shape) -- computed by csrc/geometry.hip through libkpb.so.
 
 PARITY UNPINNED: cv2 is a third-party dependency, absent from the reference tree and from this image, and its RANSAC is
 driven by its own RNG; the kernels restate OpenCV's published algorithm with its default parameters and are validated
@@ -88,3 +90,43 @@ def estimate_pose(m0, m1, scale, K0, K1, thresh=1.0, conf=0.99999, k_dev=None, s
                                          ptr(mask), ptr(info), ptr(pts)))
     ctx.check(ctx.lib.kpb_recover_pose(ctx.handle, ptr(E), ptr(pts), ptr(mask), B, K, ptr(k_dev), ptr(info), 1e9, ptr(rt), ptr(mask2), ptr(good)))
     return rt, mask2[:, :K], good, info
+
+
+def find_fundamental(m0, m1, scale, k_dev=None, seeds=None, seed=0, threshold=3.0, confidence=0.99, max_iters=1000):
+    """cv2.findFundamentalMat(.., cv2.FM_RANSAC) for B pairs in one launch (PARITY UNPINNED, see the module docstring).
+    Arguments as find_homography.  Returns (F [B, 3, 3] float64 with F[2,2] = 1, mask [B, K] uint8, info [B, 4] int32 =
+    found, inliers, hypotheses, 0) on the device; found = 0 below 8 matches."""
+    a = m0.detach().to(torch.float32).contiguous()
+    b = m1.detach().to(torch.float32).contiguous()
+    if a.dim() == 2:
+        a, b = a[None], b[None]
+    if not a.is_cuda:
+        raise RuntimeError("keypoint_bench_amd needs CUDA/HIP tensors; there is no CPU path")
+    dev = a.device
+    B, K = a.shape[0], a.shape[1]
+    sc = torch.as_tensor(scale, dtype=torch.float32).to(dev).reshape(-1, 4)
+    sc = (sc.expand(B, 4) if sc.shape[0] == 1 else sc).contiguous()
+    F = torch.zeros((B, 3, 3), dtype=torch.float64, device=dev)
+    mask = torch.zeros((B, max(K, 1)), dtype=torch.uint8, device=dev)
+    info = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    ctx = Context.get(dev)
+    prm = RansacParams(float(threshold), float(confidence), int(max_iters), 0)
+    ctx.check(ctx.lib.kpb_find_fundamental(ctx.handle, ptr(a), a.shape[2], ptr(b), b.shape[2], B, K, ptr(k_dev), ptr(sc), ptr(_seeds(seeds, B, dev)),
+                                           ctypes.c_uint32(int(seed) & 0xFFFFFFFF), ctypes.byref(prm), ptr(F), ptr(mask), ptr(info)))
+    return F, mask[:, :K], info
+
+
+def fundamental_estimate(pts0, pts1, seed=0):
+    """Drop-in for utils/mvg.py:4-19: pts0, pts1 [n, 2] pixel coordinates (device tensors).  Returns (F 3x3 numpy or None,
+    inlier pts0, inlier pts1) as numpy arrays, like the reference; fewer than 8 points: (None, all points)."""
+    p0 = pts0.detach().to(torch.float32)
+    p1 = pts1.detach().to(torch.float32)
+    if p0.shape[0] < 8:
+        print("\n too few points to estimate fundamental matrix \n")
+        return None, p0.cpu().numpy(), p1.cpu().numpy()
+    F, mask, info = find_fundamental(p0[None], p1[None], [1.0, 1.0, 1.0, 1.0], seed=seed)
+    found = int(info[0, 0])
+    if not found:                   # cv2 returns (None, None) there and the reference fails on mask.ravel()
+        raise AttributeError("'NoneType' object has no attribute 'ravel'")
+    keep = mask[0].bool()
+    return F[0].cpu().numpy(), p0[keep].cpu().numpy(), p1[keep].cpu().numpy()

@@ -190,3 +190,98 @@ def test_runner_auc_batched_equals_single_pair_rows():
     assert np.array_equal(rows1, rowsb), (rows1, rowsb)
     assert (rows1[:, 1] > 20).all()                    # inliers: the pose is supported by many matches
     assert aggb["AUC"] == agg1["AUC"] and len(aggb["AUC"]) == 3
+
+
+# ------------------------------------------------------------------------------------------------ fundamental matrix (7 points)
+def test_batched_fundamental_equals_oracle_and_ground_truth():
+    from keypoint_bench_amd.utils.mvg import find_fundamental
+    from test_oracle_geometry import fscene
+    cases = [(800, 0.7, 0.4), (300, 0.5, 0.5), (1000, 0.9, 0.0), (60, 0.6, 0.3), (8, 1.0, 0.0), (7, 1.0, 0.0), (0, 1.0, 0.0), (997, 0.35, 0.5)]
+    B, K = len(cases), 1000
+    W, H = 640, 480
+    scale = np.array([W - 1, H - 1, W - 1, H - 1], np.float32)
+    m0, m1 = np.zeros((B, K, 3), np.float32), np.zeros((B, K, 3), np.float32)
+    kk = np.zeros(B, np.int32)
+    gt = []
+    for b, (n, share, noise) in enumerate(cases):
+        if n:
+            p1, p2, F, inl = fscene(n, share, noise, 500 + b)
+            m0[b, :n, :2] = (p1 / scale[:2]).astype(np.float32)
+            m1[b, :n, :2] = (p2 / scale[2:]).astype(np.float32)
+            gt.append((F, inl))
+        else:
+            gt.append(None)
+        kk[b] = n
+    seeds = np.arange(B) * 15485863 + 3
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    F, mask, info = find_fundamental(t(m0), t(m1), scale, k_dev=t(kk), seeds=seeds)
+    F, mask, info = F.cpu().numpy(), mask.cpu().numpy(), info.cpu().numpy()
+    for b, (n, share, noise) in enumerate(cases):
+        if n < 8:
+            assert info[b, 0] == 0 and mask[b].sum() == 0 and not F[b].any()
+            continue
+        p0 = (m0[b, :n, :2] * scale[:2]).astype(np.float64)          # the fp32 pixel products the kernel forms
+        p1 = (m1[b, :n, :2] * scale[2:]).astype(np.float64)
+        Fe, me, ie = g.find_fundamental_ransac(p0, p1, seed=int(seeds[b]))
+        assert info[b, 0] == 1 and info[b, 2] == ie["iters"], (b, info[b], ie)
+        # same sampler and solver: the same winning hypothesis unless two tie within rounding of an error at the threshold
+        assert abs(int(info[b, 1]) - ie["inliers"]) <= 1, (b, info[b], ie)
+        assert mask[b, n:].sum() == 0 and mask[b, :n].sum() == info[b, 1]
+        if info[b, 1] == ie["inliers"]:
+            assert (mask[b, :n] != me).sum() <= 2
+            np.testing.assert_allclose(F[b], Fe, rtol=0, atol=1e-6 * np.abs(Fe).max(), err_msg=str(b))
+        inl = gt[b][1]
+        if share >= 0.5:            # at 35 % inliers 1000 seven-point samples rarely contain a clean one (0.35^7): oracle parity only
+            err = g.fm_error(F[b], p0[inl], p1[inl])
+            assert np.median(np.sqrt(err)) < max(2.5 * noise, 1e-3) + 0.5, (b, np.median(np.sqrt(err)))
+            if (~inl).any():
+                assert mask[b, :n][inl].mean() > 0.85 and mask[b, :n][~inl].mean() < 0.2
+
+
+def _fund_params(matcher="brute_force", top_k=300):
+    EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=top_k, min_score=0.0, save_result=False)
+    return {"model_type": "Alike", "task_type": "FundamentalMatrixRansac", "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),
+            "extractor_params": EP,
+            "matcher_params": {"type": matcher, "save_result": False, "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
+            "FundamentalMatrixRansac": {"th": 3, "output": "/tmp/", "save_path": "/tmp/f.png"}}
+
+
+def test_fundamental_ransac_task_equals_oracle_chain():
+    """tasks/FundamentalMatrix.py:12-86 on the device against the same steps taken with the oracle's pieces."""
+    import oracle
+    from keypoint_bench_amd import synthetic
+    from keypoint_bench_amd import runner
+    from keypoint_bench_amd.tasks.FundamentalMatrix import fundamental_matrix_ransac
+    prm = _fund_params()
+    net = runner.build_model(prm)
+    v0, v1 = synthetic.image_pair(77, 96, 128)
+    i0, i1 = torch.from_numpy(v0)[None].to(DEV), torch.from_numpy(v1)[None].to(DEV)
+    s0, d0 = net(i0)
+    s1, d1 = net(i1)
+    res = fundamental_matrix_ransac(5, i0, i1, s0, s1, d0, d1, None, prm)
+    k0, _ = oracle.detection(s0[0, 0].cpu().numpy(), prm["extractor_params"])
+    k1, _ = oracle.detection(s1[0, 0].cpu().numpy(), prm["extractor_params"])
+    m0, m1 = oracle.brute_force_matcher(k0, k1, d0[0].cpu().numpy(), d1[0].cpu().numpy(), prm["matcher_params"]["brute_force_params"])
+    px = np.array([127, 95], np.float32)
+    _, a, b = g.fundamental_estimate((m0[:, :-1] * px).astype(np.float32), (m1[:, :-1] * px).astype(np.float32), seed=5)
+    want_num = len(a) + len(b)
+    assert abs(res["fundamental_num"] - want_num) <= 2 and res["fundamental_error"] == 0
+    assert res["fundamental_radio"] == res["fundamental_num"] / (len(k0) + len(k1))
+    assert res["fundamental_num"] > 0.5 * 2 * len(m0)               # a shifted view: most matches obey one epipolar geometry
+
+
+def test_runner_fundamental_ransac_batched_equals_single_pair_rows():
+    from keypoint_bench_amd import runner, synthetic
+    prm = _fund_params()
+    ds = []
+    for i in range(6):
+        v0, v1 = synthetic.image_pair(900 + i, 96, 128)
+        ds.append({"image0": v0, "image1": v1, "dataset": "image_pair"})
+    single = runner.PairRunner(prm, device=DEV, batch=1)
+    agg1, rows1 = single.run(ds)
+    batched = runner.PairRunner(prm, device=DEV, batch=4)
+    aggb, rowsb = batched.run(ds)
+    assert single.batched_pairs == 0 and batched.batched_pairs == 6
+    assert np.array_equal(rows1, rowsb), (rows1, rowsb)
+    assert (rows1[:, 0] == 0).all() and (rows1[:, 1] > 0.2).all() and (rows1[:, 1] <= 1).all()
+    assert aggb == agg1 and set(aggb) == {"fundamental_error", "fundamental_radio", "fundamental_num"}

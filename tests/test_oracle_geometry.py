@@ -194,3 +194,72 @@ def test_auc_chain_around_the_estimator_against_reference(case):
     np.testing.assert_allclose(t, f[p + "t"], atol=1e-12)
     et, eR = g.compute_pose_error(f[p + "T01"], R, t)            # float32 pose, as the dataset hands it over (norms of t_gt in float32)
     assert [max(et, eR), float(inl.sum())] == want.tolist()
+
+
+# ------------------------------------------------------------------------------------------------ fundamental matrix (7 points)
+def fscene(n, share, noise, seed, f=500.0):
+    """Pixel correspondences of a two-view scene, the true F (F[2,2] = 1) and the inlier flags."""
+    x1, x2, R, t, inl = scene(n, share, noise, seed, f)
+    c = np.array([319.5, 239.5])
+    p1 = (x1 * f + c).astype(np.float32).astype(np.float64)
+    p2 = (x2 * f + c).astype(np.float32).astype(np.float64)
+    Kc = np.array([[f, 0, c[0]], [0, f, c[1]], [0, 0, 1.0]])
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    F = np.linalg.inv(Kc).T @ tx @ R @ np.linalg.inv(Kc)
+    return p1, p2, F / F[2, 2], inl
+
+
+def test_seven_point_solver_contains_the_true_fundamental_matrix():
+    p1, p2, F, _ = fscene(300, 1.0, 0.0, 21)
+    rng = np.random.default_rng(0)
+    idx = np.stack([rng.choice(300, 7, replace=False) for _ in range(64)])
+    Fs, valid = g.fundamental_7pt(p1[idx], p2[idx])
+    assert valid.any(1).all() and (valid.sum(1) >= 1).all() and set(valid.sum(1).tolist()) <= {1, 3}
+    # every model satisfies the seven constraints and is singular; one of them is the scene's matrix
+    for s in range(64):
+        best = np.inf
+        for k in range(3):
+            if not valid[s, k]:
+                continue
+            Fk = Fs[s, k]
+            res = np.einsum("ni,ij,nj->n", np.c_[p2[idx[s]], np.ones(7)], Fk, np.c_[p1[idx[s]], np.ones(7)])
+            assert np.abs(res).max() < 1e-6 * np.abs(Fk).max() * 640 * 640
+            assert abs(np.linalg.det(Fk / np.linalg.norm(Fk))) < 1e-9
+            best = min(best, np.abs(Fk - F).max() / np.abs(F).max())
+        assert best < 1e-3, (s, best)                     # float32-rounded pixels: the exact matrix up to that rounding
+
+
+def test_cubic_roots_against_numpy():
+    rng = np.random.default_rng(1)
+    c = rng.normal(size=(500, 4))
+    r, v = g.solve_cubic(c[:, 0], c[:, 1], c[:, 2], c[:, 3])
+    for i in range(500):
+        want = np.roots(c[i])
+        want = np.sort(want[np.abs(want.imag) < 1e-7].real)
+        np.testing.assert_allclose(np.sort(r[i][v[i]]), want, rtol=1e-7, atol=1e-9)
+    r, v = g.solve_cubic(np.zeros(3), np.ones(3), np.ones(3), np.ones(3))
+    assert not v.any()                                    # a vanishing leading coefficient voids the sample
+
+
+@pytest.mark.parametrize("n,share,noise", [(800, 0.7, 0.4), (300, 0.5, 0.5), (1000, 0.9, 0.0), (60, 0.6, 0.3), (8, 1.0, 0.0)])
+def test_ransac_fundamental_recovers_ground_truth(n, share, noise):
+    p1, p2, F, inl = fscene(n, share, noise, 40 + n)
+    Fe, mask, info = g.find_fundamental_ransac(p1, p2, seed=9)
+    assert Fe is not None and abs(Fe[2, 2] - 1) < 1e-12 and info["inliers"] == mask.sum()
+    # true correspondences lie on their epipolar lines of the estimate (a minimal 7-point model: a few pixels at most)
+    err = g.fm_error(Fe, p1[inl], p2[inl])
+    assert np.median(np.sqrt(err)) < max(2.5 * noise, 1e-3) + 0.5
+    assert mask[inl].mean() > 0.85 and mask[~inl].mean() < 0.2 if (~inl).any() else True
+
+
+def test_ransac_fundamental_small_and_degenerate_inputs():
+    p1, p2, _, _ = fscene(7, 1.0, 0.0, 3)
+    F, mask, info = g.find_fundamental_ransac(p1, p2, seed=0)          # below 8: utils/mvg.py never calls cv2
+    assert F is None and mask.sum() == 0 and info["iters"] == 0
+    line = np.stack([np.arange(30.0) * 7, np.arange(30.0) * 3 + 5], 1)  # collinear in both images: every sample is void
+    F, mask, info = g.find_fundamental_ransac(line, line + 2, seed=0)
+    assert F is None and info["iters"] >= g.F_MAX_ITERS
+    a, b, c = g.fundamental_estimate(p1, p2)
+    assert a is None and len(b) == 7 and len(c) == 7
+    with pytest.raises(AttributeError):
+        g.fundamental_estimate(line, line + 2)

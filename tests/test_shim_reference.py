@@ -70,7 +70,8 @@ def test_install_swaps_rebinds_and_keeps_the_originals(reference_on_path):
     assert not [x for x in w if "not swapped" in str(x.message)], [str(x.message) for x in w]
     want = {"utils.extracter.detection", "utils.extracter.fast_nms", "utils.matcher.brute_force_matcher", "utils.matcher.optical_flow_tensor",
             "utils.matcher.OpticalFlow", "utils.projection.warp_homography", "utils.projection.warp_se3", "tasks.repeatability.val_key_points",
-            "tasks.FundamentalMatrix.fundamental_matrix", "models.ALike.ALNet", "models.SuperPoint.SuperPointNet", "models.XFeat.XFeatModel",
+            "tasks.FundamentalMatrix.fundamental_matrix", "tasks.FundamentalMatrix.fundamental_matrix_ransac", "utils.mvg.fundamental_estimate",
+            "models.ALike.ALNet", "models.SuperPoint.SuperPointNet", "models.XFeat.XFeatModel",
             "models.disk.DISK", "models.lightglue.LightGlue"}
     assert set(swapped) == want
     assert shim.installed()["skipped"] == {}
@@ -87,6 +88,12 @@ def test_install_swaps_rebinds_and_keeps_the_originals(reference_on_path):
     assert ref_rep.val_key_points.reference is orig["vkp"]
     bound = shim.installed()["rebound"]
     assert "tasks.repeatability.detection" in bound and "tasks.FundamentalMatrix.brute_force_matcher" in bound
+    import utils.mvg as ref_mvg
+    assert "tasks.FundamentalMatrix.fundamental_estimate" in bound and ref_fm.fundamental_estimate is ref_mvg.fundamental_estimate
+    # host tensors are outside the contract: the reference's own utils/mvg.py:13-15 answers (fewer than 8 points: no cv2 call)
+    few = torch.arange(10, dtype=torch.float32).reshape(5, 2)
+    F, a, b = ref_fm.fundamental_estimate(few, few + 1)
+    assert F is None and a.shape == (5, 2) and ref_mvg.fundamental_estimate.fallbacks == 1
     # `warp` of the reference dispatches through its module globals: it now reaches the swapped warp_homography
     assert ref_pj.warp.__globals__["warp_homography"] is ref_pj.warp_homography
 
