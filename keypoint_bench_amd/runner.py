@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-ROW_WIDTH = 8   # floats per pair row: [valid, v0 .. v6]
+ROW_WIDTH = 16  # floats per pair row: [valid, v0 .. v14] (the widest row: visual_odometer's R, t, step length = 13)
 
 
 # ------------------------------------------------------------------------------------------ config
@@ -152,6 +152,10 @@ def aggregate(task_type, rows, params=None):
     if task_type in ("FundamentalMatrix", "FundamentalMatrixRansac"):  # rows: [error, ratio, num]
         return {"fundamental_error": float(rows[:, 0].mean()), "fundamental_radio": float(rows[:, 1].mean()),
                 "fundamental_num": float(rows[:, 2].mean())}
+    if task_type == "visual_odometer":    # rows: [R (9), t (3), ground-truth step length] per frame; the chain is composed here
+        from .tasks.visual_odometer import compose
+        r_est, t_est = compose(rows[:, :13])
+        return {"r_est": r_est, "t_est": t_est}
     if task_type == "match_stats":        # rows: [n0, n1, matches]
         return {"mean_kps": float(rows[:, :2].mean()), "mean_matches": float(rows[:, 2].mean())}
     raise NotImplementedError(task_type)
@@ -314,13 +318,14 @@ class PairRunner:
         return r
 
     # ---- one frame of a sequence (model_interface.py:217-228, 261-276)
-    def sequence_step(self, batch, idx):
+    def sequence_step(self, batch, idx, task_type="FundamentalMatrix"):
         from .tasks.FundamentalMatrix import fundamental_matrix
         cur = dict(batch)
         img = as_image(batch["image0"], self.device)
         cur["image0"] = img[None] if img.dim() == 3 else img
-        f = torch.as_tensor(batch["fundamental"], dtype=torch.float32).to(self.device)
-        cur["fundamental"] = f[None] if f.dim() == 2 else f                       # what DataLoader collation adds
+        if "fundamental" in batch:
+            f = torch.as_tensor(batch["fundamental"], dtype=torch.float32).to(self.device)
+            cur["fundamental"] = f[None] if f.dim() == 2 else f                       # what DataLoader collation adds
         if self.last_batch is None:
             self.last_batch = cur
         with torch.no_grad():
@@ -329,6 +334,12 @@ class PairRunner:
         last_img = self.last_batch["image0"]
         self.last_batch = cur
         mp = self.params["matcher_params"]
+        if task_type == "visual_odometer":    # 283-298: the per-frame motion; the chain is composed from the gathered rows
+            from .tasks.visual_odometer import relative_motion, step_length
+            R, t = relative_motion(idx, last_img, cur, s0, s1, d0, d1, self.matcher, self.params)
+            r = list(R.reshape(9)) + list(t.reshape(3)) + [step_length(cur)]
+            self.results.append(r)
+            return r
         if mp["type"] == "optical_flow":      # 262-267: the tracker works on the two images
             res = fundamental_matrix(idx, last_img, cur, s0, s1, last_img, cur["image0"], self.matcher, self.params)
         else:
@@ -403,7 +414,7 @@ class PairRunner:
         return [out[i] for i in indices]
 
     # ---- batched sequence (BASELINE configs[3]: brute-force branch)
-    def _run_sequence(self, dataset, indices):
+    def _run_sequence(self, dataset, indices, task_type="FundamentalMatrix"):
         from .pipeline import SequencePipeline
         from .tasks.FundamentalMatrix import epipolar_error
         mp = self.params["matcher_params"]
@@ -420,7 +431,7 @@ class PairRunner:
                 prev["image0"] = img[None] if img.dim() == 3 else img
                 self.last_batch = prev
             for i in indices:
-                rows.append(self.sequence_step(dataset[i], i))
+                rows.append(self.sequence_step(dataset[i], i, task_type))
             return rows
         first = as_image(dataset[indices[0]]["image0"], self.device)
         H, W = first.shape[-2:]
@@ -429,16 +440,24 @@ class PairRunner:
         images = torch.empty((F, 3, H, W), dtype=torch.float32, device=self.device)
         if indices[0] > 0:
             pipe.prime(as_image(dataset[indices[0] - 1]["image0"], self.device))
-        th = self.params["FundamentalMatrix_params"]["th"]
+        vo = task_type == "visual_odometer"
+        th = None if vo else self.params["FundamentalMatrix_params"]["th"]
         for c0 in range(0, len(indices), F):
             chunk = indices[c0:c0 + F]
             f = len(chunk)
-            fm = []
+            fm, items = [], []
             for j, i in enumerate(chunk):
                 item = dataset[i]
                 images[j].copy_(as_image(item["image0"], self.device).reshape(3, H, W), non_blocking=True)
-                fm.append(torch.as_tensor(item["fundamental"], dtype=torch.float32).reshape(9))
+                items.append(item)
+                if not vo:
+                    fm.append(torch.as_tensor(item["fundamental"], dtype=torch.float32).reshape(9))
             pipe.run(images[:f], first=(chunk[0] == 0))
+            if vo:
+                from .tasks.visual_odometer import relative_motion_batch
+                rows.extend(relative_motion_batch(pipe, items, chunk))
+                self.batched_pairs += f
+                continue
             fmat = torch.stack(fm).to(self.device)
             _, stats = epipolar_error(pipe.m0[:f], pipe.m1[:f], fmat, W, H, 0, th, k_dev=pipe.k)      # FundamentalMatrix.py:120-122: mode 0
             st, kk = stats.cpu().numpy(), pipe.k[:f].tolist()
@@ -461,7 +480,7 @@ class PairRunner:
         shard = shard_chunk if sequence else shard_indices
         indices = shard(n, rank, world)
         if sequence:
-            self.results = self._run_sequence(dataset, indices)
+            self.results = self._run_sequence(dataset, indices, "visual_odometer" if task_type == "visual_odometer" else "FundamentalMatrix")
         else:
             if not self.user_task:
                 self.task_fn = TASKS.get(task_type, self.task_fn)

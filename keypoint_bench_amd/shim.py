@@ -212,6 +212,7 @@ def _table():
     from .models.lightglue import LightGlue
     from .tasks import repeatability as rp
     from .tasks import FundamentalMatrix as fm
+    from .tasks import visual_odometer as vo
     from .utils import extracter as ex, matcher as ma, mvg, projection as pj
     fn, net = "fn", "net"
     return [
@@ -226,6 +227,7 @@ def _table():
         ("tasks.FundamentalMatrix", "fundamental_matrix", fn, fm.fundamental_matrix, fm.in_contract),
         ("tasks.FundamentalMatrix", "fundamental_matrix_ransac", fn, fm.fundamental_matrix_ransac, fm.ransac_in_contract),
         ("utils.mvg", "fundamental_estimate", fn, mvg.fundamental_estimate, _c_first),
+        ("tasks.visual_odometer", "visual_odometry", fn, vo.visual_odometry, vo.in_contract),
         ("models.ALike", "ALNet", net, ALNet, None),
         ("models.SuperPoint", "SuperPointNet", net, SuperPointNet, None),
         ("models.XFeat", "XFeatModel", net, XFeatModel, None),

@@ -50,11 +50,13 @@ def _seeds(seeds, B, dev):
     return torch.from_numpy((np.asarray(seeds, np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32).reshape(B).copy()).to(dev)
 
 
-def estimate_pose(m0, m1, scale, K0, K1, thresh=1.0, conf=0.99999, k_dev=None, seeds=None, seed=0, max_iters=1000):
+def estimate_pose(m0, m1, scale, K0, K1, thresh=1.0, conf=0.99999, k_dev=None, seeds=None, seed=0, max_iters=1000, recover_all=False, dist=1e9):
     """tasks/AUC.py:40-64 (`estimate_pose`) for B pairs in two launches: cv2.findEssentialMat(RANSAC) + cv2.recoverPose restated
     (PARITY UNPINNED, see the module docstring).  m0, m1 [B, K, c>=2] matched rows, normalised; scale [B, 4] -> pixels;
     K0, K1 [B, 3, 3] (or [3, 3]) intrinsics.  Returns (Rt [B, 12] float64 = R row-major, t; mask [B, K] uint8 = cv2's `mask`
-    after recoverPose; good [B] int32 = recoverPose's count (0: no pose); info [B, 4] = found, RANSAC inliers, hypotheses, 0)."""
+    after recoverPose; good [B] int32 = recoverPose's count (0: no pose); info [B, 4] = found, RANSAC inliers, hypotheses, 0).
+    recover_all: recoverPose is called WITHOUT the RANSAC mask, on every match (tasks/visual_odometer.py:76-77); dist: its
+    distanceThresh (1e9 at AUC.py:60, cv2's default 50 at visual_odometer.py:76)."""
     a = m0.detach().to(torch.float32).contiguous()
     b = m1.detach().to(torch.float32).contiguous()
     if a.dim() == 2:
@@ -88,7 +90,9 @@ def estimate_pose(m0, m1, scale, K0, K1, thresh=1.0, conf=0.99999, k_dev=None, s
     ctx.check(ctx.lib.kpb_find_essential(ctx.handle, ptr(a), a.shape[2], ptr(b), b.shape[2], B, K, ptr(k_dev), ptr(sc), ptr(cam_d), 1 if f32 else 0, ptr(thr_d),
                                          ptr(_seeds(seeds, B, dev)), ctypes.c_uint32(int(seed) & 0xFFFFFFFF), float(conf), int(max_iters), ptr(E),
                                          ptr(mask), ptr(info), ptr(pts)))
-    ctx.check(ctx.lib.kpb_recover_pose(ctx.handle, ptr(E), ptr(pts), ptr(mask), B, K, ptr(k_dev), ptr(info), 1e9, ptr(rt), ptr(mask2), ptr(good)))
+    if recover_all:
+        mask.fill_(1)
+    ctx.check(ctx.lib.kpb_recover_pose(ctx.handle, ptr(E), ptr(pts), ptr(mask), B, K, ptr(k_dev), ptr(info), float(dist), ptr(rt), ptr(mask2), ptr(good)))
     return rt, mask2[:, :K], good, info
 
 

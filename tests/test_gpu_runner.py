@@ -95,3 +95,62 @@ def test_sequence_rows_batched_equal_single_and_chunks_reproduce_them(dense):
                 got[idx] = rows
                 assert np.array_equal(rows.view(np.uint32), rows1[idx, :3].view(np.uint32)), (world, rank, mode_batch)
         assert np.array_equal(got, rows1[:, :3])
+
+
+# ------------------------------------------------------------------------------------------------ visual odometer
+def vo_dataset(n, h=96, w=128):
+    """Frames sliding over one canvas (a camera translating sideways over a fronto-parallel plane), with the fields
+    datasets/euroc.py:184-196 hands out; poses as plain 7-vectors (pypose is absent here)."""
+    canvas, _ = synthetic.image_pair(321, h + 40, w + 60)
+    ds = []
+    for i in range(n):
+        pos = [0.05 * i, 0.02 * i, 0.0, 0, 0, 0, 1]
+        last = [0.05 * max(i - 1, 0), 0.02 * max(i - 1, 0), 0.0, 0, 0, 0, 1]
+        ds.append({"image0": canvas[:, 2 * i:2 * i + h, 5 * i:5 * i + w].copy(), "dataset": "Euroc", "fx": 120.0, "fy": 120.0, "cx": 63.5, "cy": 47.5,
+                   "ground_truth": np.asarray(pos, np.float32), "last_ground_truth": np.asarray(last, np.float32)})
+    return ds
+
+
+def test_visual_odometer_rows_batched_equal_single_and_chunks_reproduce_them():
+    from oracle import geometry_ref as g
+    import oracle
+    ds = vo_dataset(7)
+    prm = params("visual_odometer")
+    single = runner.PairRunner(prm, device=DEV, batch=1)
+    agg1, rows1 = single.run(ds)
+    assert single.batched_pairs == 0 and rows1.shape[0] == 7
+    batched = runner.PairRunner(prm, device=DEV, batch=4)
+    aggb, rowsb = batched.run(ds)
+    assert batched.batched_pairs == 7
+    assert np.array_equal(rows1.view(np.uint32), rowsb.view(np.uint32)), (rows1, rowsb)
+    assert np.array_equal(agg1["t_est"], aggb["t_est"]) and agg1["r_est"].shape == (8, 3, 3) and agg1["t_est"].shape == (8, 3, 1)
+    # rotations are rotations; the camera slides sideways: the composed path has moved, mostly in the image plane
+    for R in agg1["r_est"]:
+        assert abs(np.linalg.det(R) - 1) < 1e-5 and np.abs(R @ R.T - np.eye(3)).max() < 1e-5
+    assert np.array_equal(agg1["t_est"][1], np.zeros((3, 1)))          # frame 0 pairs with itself: zero step length, no update
+    end = agg1["t_est"][-1].ravel()
+    assert np.linalg.norm(end) > 0.1 and abs(end[2]) < 0.5 * np.linalg.norm(end[:2]) + 0.05, end
+    # what ranks of a 2- and 3-rank run would compute on their chunks (one-frame overlap), batched and not
+    for world in (2, 3):
+        for rank in range(world):
+            idx = runner.shard_chunk(len(ds), rank, world)
+            for mode_batch in (1, 4):
+                r = runner.PairRunner(prm, device=DEV, batch=mode_batch)
+                rows = np.asarray(r._run_sequence(ds, idx, "visual_odometer"), np.float32)
+                assert np.array_equal(rows.view(np.uint32), rows1[idx, :13].view(np.uint32)), (world, rank, mode_batch)
+    # frame pair (2, 3) against the same steps taken with the oracle's pieces
+    net = runner.build_model(prm)
+    t = lambda a: torch.from_numpy(a)[None].to(DEV)
+    s0, d0 = net(t(ds[2]["image0"]))
+    s1, d1 = net(t(ds[3]["image0"]))
+    k0, _ = oracle.detection(s0[0, 0].cpu().numpy(), EP)
+    k1, _ = oracle.detection(s1[0, 0].cpu().numpy(), EP)
+    m0, m1 = oracle.brute_force_matcher(k0, k1, d0[0].cpu().numpy(), d1[0].cpu().numpy(), BF)
+    px = np.array([127, 95], np.float32)
+    c, f = np.array([63.5, 47.5]), 120.0
+    x0, x1 = ((m0[:, :2] * px).astype(np.float64) - c) / f, ((m1[:, :2] * px).astype(np.float64) - c) / f
+    E, mask, info = g.find_essential_ransac(x0, x1, seed=3, threshold=1.0 / f, prob=0.999)
+    n, R, tt, _ = g.recover_pose(E, x0, x1, np.ones(len(x0), np.uint8), dist=50.0)
+    np.testing.assert_allclose(rows1[3, :9].reshape(3, 3), R, atol=2e-5)
+    np.testing.assert_allclose(rows1[3, 9:12], tt, atol=2e-5)
+    assert abs(rows1[3, 12] - np.hypot(0.05, 0.02)) < 1e-6

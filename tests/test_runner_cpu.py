@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 
 from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from keypoint_bench_amd import runner
 
 
@@ -67,6 +69,59 @@ def test_two_rank_gather_over_gloo(n_items):
     for o in outs:
         assert o["rows"] == want, "rank %d" % o["rank"]
         assert abs(o["agg"]["mean_matches"] - np.mean([w[2] for w in want])) < 1e-6
+
+
+def _reference_chain(rows):
+    """model_interface.py:116-117, 296-297 with tasks/visual_odometer.py:84-91 written out."""
+    r_est, t_est = [np.eye(3)], [np.zeros([3, 1])]
+    for row in np.asarray(rows, np.float64):
+        R, t, scale = row[:9].reshape(3, 3), row[9:12].reshape(3, 1), row[12]
+        R_est, T_est = r_est[-1], t_est[-1]
+        if scale >= 0.001:
+            R_est = r_est[-1].dot(R)
+            T_est = t_est[-1] + float(scale) * r_est[-1].dot(t)
+        r_est.append(R_est)
+        t_est.append(T_est)
+    return np.stack(r_est), np.stack(t_est)
+
+
+def test_visual_odometer_rows_compose_to_the_reference_chain():
+    from vo_rows import vo_rows
+    from keypoint_bench_amd.tasks.visual_odometer import compose, step_length
+    rows = np.asarray(vo_rows(11), np.float32)
+    agg = runner.aggregate("visual_odometer", rows)
+    r, t = _reference_chain(rows)
+    assert np.array_equal(agg["r_est"], r) and np.array_equal(agg["t_est"], t) and r.shape == (12, 3, 3) and t.shape == (12, 3, 1)
+    assert np.array_equal(r[1], r[0]) and np.array_equal(t[1], t[0])               # frame 0 stands still
+    r2, t2 = compose(rows)
+    assert np.array_equal(r2, r) and np.array_equal(t2, t)
+
+    class Pose:                     # pypose LieTensors answer .tensor() (datasets/euroc.py:188-189)
+        def __init__(self, v): self.v = torch.tensor(v, dtype=torch.float32)
+        def tensor(self): return self.v
+    b = {"ground_truth": Pose([1.0, 2.0, 2.0, 0, 0, 0, 1]), "last_ground_truth": Pose([0.0, 0.0, 0.0, 0, 0, 0, 1])}
+    assert step_length(b) == 3.0
+    assert step_length({"ground_truth": np.array([0.0, 0.0, 1.0]), "last_ground_truth": torch.zeros(3)}) == 1.0
+
+
+def test_two_rank_sequence_chunks_over_gloo():
+    """A sequence task on two ranks: contiguous chunks, one all-gather of 13-wide rows, the chain composed on each rank."""
+    import json
+    import subprocess
+    from vo_rows import vo_rows
+    n = 9
+    port = _free_port()
+    worker = os.path.join(ROOT, "tests", "_gloo_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(n), "vo"], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    r, t = _reference_chain(np.asarray(vo_rows(n), np.float32))
+    for p in procs:
+        so, se = p.communicate(timeout=300)
+        assert p.returncode == 0, se[-2000:]
+        o = json.loads([l for l in so.splitlines() if l.startswith("RESULT ")][0][7:])
+        assert o["rows"] == vo_rows(n)
+        np.testing.assert_array_equal(np.asarray(o["t_end"]), t[-1].ravel())
+        np.testing.assert_array_equal(np.asarray(o["r_end"]), r[-1].ravel())
 
 
 def test_crop32_and_config_loading(tmp_path):

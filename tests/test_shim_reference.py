@@ -71,7 +71,7 @@ def test_install_swaps_rebinds_and_keeps_the_originals(reference_on_path):
     want = {"utils.extracter.detection", "utils.extracter.fast_nms", "utils.matcher.brute_force_matcher", "utils.matcher.optical_flow_tensor",
             "utils.matcher.OpticalFlow", "utils.projection.warp_homography", "utils.projection.warp_se3", "tasks.repeatability.val_key_points",
             "tasks.FundamentalMatrix.fundamental_matrix", "tasks.FundamentalMatrix.fundamental_matrix_ransac", "utils.mvg.fundamental_estimate",
-            "models.ALike.ALNet", "models.SuperPoint.SuperPointNet", "models.XFeat.XFeatModel",
+            "tasks.visual_odometer.visual_odometry", "models.ALike.ALNet", "models.SuperPoint.SuperPointNet", "models.XFeat.XFeatModel",
             "models.disk.DISK", "models.lightglue.LightGlue"}
     assert set(swapped) == want
     assert shim.installed()["skipped"] == {}
