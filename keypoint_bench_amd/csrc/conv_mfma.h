@@ -24,6 +24,9 @@ struct ConvM {
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
     int istride, ostride, ooff;   // floats between consecutive input / output pixels, channel offset of the output
     float unscale = 1.0f;         // conv_mfma_h: 1 / (ACT_SCALE x the layer's weight scale)
+    const float* xw = nullptr;    // conv_mfma_h<XC>: [tap][CIN] fp32 weights / ACT_SCALE of ONE extra output channel (index xco) taken on the VALU
+    float xb = 0.0f;              // its bias
+    int xco = 0;
 };
 
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2>
@@ -182,7 +185,12 @@ __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
     lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
 
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1>
+// XC: one more output channel than the tiles hold (DISK's 129 = 4 x 32 + 1) is accumulated on the VALU from the same LDS
+// tile, one output pixel per thread (MT = 2: 256 pixels) of the workgroup that owns the first NTB tiles, instead of spending a
+// 32-wide MFMA tile on it.
+// (Tried, r02: requesting the weight fragments of tap t + 1 before the MFMAs of tap t in a second register set -- 12-15 %
+// slower on every layer; the extra 32-64 VGPRs cost a wave per SIMD and the other waves already cover the L2 latency.)
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false>
 __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 {
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
@@ -202,6 +210,8 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][tap][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)T * a.NCH * NKB * 4 * 32;
 
+    static_assert(!XC || (MT == 2 && S == 1 && !POOL_OUT), "conv_mfma_h: the extra channel maps one pixel of a 16x16 tile to each thread");
+    float xacc = 0.0f;
     f32x16 acc[MT][NTB];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -287,6 +297,25 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bl[n][kb], acc[m][n], 0, 0, 0);
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
                     }
+            if (XC && nb == 0) {       // the extra channel at pixel (tid / 16, tid % 16): hi + lo restores the staged activation, weights are wave-uniform
+                const unsigned char* xp = &tile[(((tid >> 4) + ky) * IW + (tid & 15) + kx) * PITCH];
+                const float* xw = a.xw + (size_t)tap * a.CIN + ch * CC;
+#pragma unroll
+                for (int q = 0; q < CC / 8; ++q) {
+                    const cm_h8 vh = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + 16 * q));
+                    const cm_h8 vl = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + PLANE + 16 * q));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xacc = fmaf((float)vh[e] + (float)vl[e], xw[8 * q + e], xacc);
+                }
+            }
+        }
+    }
+    if (XC && nb == 0) {
+        const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
+        if (gy < a.H && gx < a.W) {
+            float o = xacc + a.xb;
+            if (a.relu) o = relu(o);
+            a.out[(size_t)b * a.H * a.W * a.ostride + a.ooff + ((size_t)gy * a.W + gx) * a.ostride + a.xco] = o;
         }
     }
 

@@ -342,7 +342,12 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 5, 1>), g1, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) {
+            // 129 = 4 x 32 + 1 (DISK up_3): four MFMA tiles (two workgroups of two: 64 accumulator registers, three waves per SIMD,
+            // weight fragments reused by two M tiles) and the score channel on the VALU of the first workgroup
+            a.nblk = 2; a.xw = net->wp((L.name + ".xw").c_str()); a.xb = net->wscale.at(L.name + ".xb"); a.xco = L.cout - 1;
+            KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 2, 2, true>), dim3(cdiv(a.W, 16), cdiv(a.H, 16), B * 2), block, 0, st, a);
+        }
         else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no instance for ks=%d stride=%d cc=%d pool_in=%d pool_out=%d xf=%d", L.ks, S, CC, pool_in, pool_out, x);
         return KPB_OK;
     }
@@ -384,7 +389,17 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
 void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b)
 {
     if (L.mfma) {
-        if (conv_mfma_use_h16()) {
+        if (conv_mfma_use_h16() && L.ntb == 5) {       // cout = 4 x 32 + 1: the last channel goes to the VALU side of conv_mfma_h<XC>
+            const int T = L.ks * L.ks, co = L.cout - 1;
+            const float sc = weight_scale_h(w, (size_t)co * L.cin * T);
+            ws.put(L.name + ".w", pack_mfma_h(w, co, L.cin, L.ks, L.cc, 2, sc));
+            ws.wscale[L.name + ".w"] = sc;
+            std::vector<float> xw((size_t)T * L.cin);
+            for (int c = 0; c < L.cin; ++c)
+                for (int t = 0; t < T; ++t) xw[(size_t)t * L.cin + c] = w[((size_t)co * L.cin + c) * T + t] / ACT_SCALE;
+            ws.put(L.name + ".xw", xw);
+            ws.wscale[L.name + ".xb"] = b ? b[co] : 0.0f;     // a host-side scalar, carried with the scales
+        } else if (conv_mfma_use_h16()) {
             const float sc = weight_scale_h(w, (size_t)L.cout * L.cin * L.ks * L.ks);
             ws.put(L.name + ".w", pack_mfma_h(w, L.cout, L.cin, L.ks, L.cc, L.ntb, sc));
             ws.wscale[L.name + ".w"] = sc;

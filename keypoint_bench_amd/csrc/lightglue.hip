@@ -219,6 +219,165 @@ __global__ __launch_bounds__(256) void lg_flash(FlashArgs a)
     }
 }
 
+// ---- the same attention on the f16 matrix pipe (split-f16 products, see conv_mfma.h): K and V are first re-laid in MFMA
+// operand order, split into (hi, lo) halves, by lg_kv_frags -- once per attention call instead of once per query tile --
+// so the flash loop loads every operand with one coalesced 16-byte load per lane and converts nothing but its own P.
+//   KF [S][NH][MP/32][kb 4][hi/lo][64 lanes] x 8 halves: lane (p, h) = K[32 blk + p][16 kb + 8 h + j]
+//   VF [S][NH][MP/32][nh 2][kb 2][hi/lo][64 lanes] x 8 halves: lane (p, h) = V[key(kb, h, j)][32 nh + p],
+//      key(kb, h, j) = 32 blk + 16 kb + 8 (j >> 2) + 4 h + (j & 3): exactly the keys whose probabilities registers
+//      8 kb .. 8 kb + 7 of the S^T accumulator hold in lane half h, so P needs no shuffle to become the A operand.
+// Keys past the sequence's count are written as zeros (P is zero there too; garbage times zero could be NaN).
+__device__ __forceinline__ void cm_split8(const float* f, cm_h8& hi, cm_h8& lo)
+{
+    uint2 h0, l0, h1, l1;
+    cm_split4(make_float4(f[0], f[1], f[2], f[3]), h0, l0);
+    cm_split4(make_float4(f[4], f[5], f[6], f[7]), h1, l1);
+    hi = __builtin_bit_cast(cm_h8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    lo = __builtin_bit_cast(cm_h8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+
+struct FragArgs {
+    const float* k; const float* v; uint4* kf; uint4* vf;
+    const int* cnt; const int* active;
+    int MP, cross;
+};
+
+__global__ __launch_bounds__(256) void lg_kv_frags(FragArgs a)
+{
+    const int s = blockIdx.z, head = blockIdx.y, blk = blockIdx.x;
+    // the fragments of sequence s are read by the queries of sequence s (self) or s ^ 1 (cross)
+    if (!a.active[a.cross ? (s ^ 1) : s]) return;
+    const int n = a.cnt[s];
+    if (blk * 32 >= n) return;
+    const int t = threadIdx.x, lane = t & 63, p = lane & 31, h = lane >> 5, NB = a.MP / 32;
+    const size_t fb = (((size_t)s * NH + head) * NB + blk) * 8 * 64;
+    {
+        const int kb = t >> 6, key = 32 * blk + p;
+        float f[8];
+        const float* src = a.k + ((size_t)s * a.MP + key) * D + head * HD + 16 * kb + 8 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = key < n ? src[j] : 0.0f;
+        cm_h8 hi, lo;
+        cm_split8(f, hi, lo);
+        a.kf[fb + (kb * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+        a.kf[fb + (kb * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+    }
+    {
+        const int nh = (t >> 6) & 1, kb = t >> 7;
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int key = 32 * blk + 16 * kb + 8 * (j >> 2) + 4 * h + (j & 3);
+            f[j] = key < n ? a.v[((size_t)s * a.MP + key) * D + head * HD + 32 * nh + p] : 0.0f;
+        }
+        cm_h8 hi, lo;
+        cm_split8(f, hi, lo);
+        a.vf[fb + ((nh * 2 + kb) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+        a.vf[fb + ((nh * 2 + kb) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+    }
+}
+
+struct FlashHArgs {
+    const float* q; const uint4* kf; const uint4* vf; float* out;
+    const int* cnt; const int* active;
+    int MP, cross; float scale;
+};
+
+__global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
+{
+    const int s = blockIdx.z, head = blockIdx.y;
+    if (!a.active[s]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, p = lane & 31, h = lane >> 5;
+    const int q0 = (blockIdx.x * 4 + wv) * 32;
+    const int nq = a.cnt[s];
+    if (q0 >= nq) return;
+    const int kv = a.cross ? (s ^ 1) : s;
+    const int nk = a.cnt[kv], NB = a.MP / 32;
+    cm_h8 Qh[4], Ql[4];
+    {
+        const float* qp = a.q + ((size_t)s * a.MP + q0 + p) * D + head * HD + 8 * h;       // rows past nq stay inside the padded buffer
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * kb), t1 = *reinterpret_cast<const float4*>(qp + 16 * kb + 4);
+            const float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            cm_split8(f, Qh[kb], Ql[kb]);
+        }
+    }
+    f32x16 O0 = {0}, O1 = {0};
+    float m_run = -INFINITY, l_run = 0.0f;
+    const uint4* kfb = a.kf + ((size_t)kv * NH + head) * NB * 8 * 64 + lane;
+    const uint4* vfb = a.vf + ((size_t)kv * NH + head) * NB * 8 * 64 + lane;
+    for (int k0 = 0; k0 < nk; k0 += 32) {
+        const uint4* kf = kfb + (size_t)(k0 >> 5) * 8 * 64;
+        const uint4* vf = vfb + (size_t)(k0 >> 5) * 8 * 64;
+        cm_h8 Kh[4], Kl[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            Kh[kb] = __builtin_bit_cast(cm_h8, kf[(kb * 2 + 0) * 64]);
+            Kl[kb] = __builtin_bit_cast(cm_h8, kf[(kb * 2 + 1) * 64]);
+        }
+        // V of this block goes out now too: it lands while the scores and the softmax are worked on
+        cm_h8 Vh[2][2], Vl[2][2];
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                Vh[nh][kb] = __builtin_bit_cast(cm_h8, vf[((nh * 2 + kb) * 2 + 0) * 64]);
+                Vl[nh][kb] = __builtin_bit_cast(cm_h8, vf[((nh * 2 + kb) * 2 + 1) * 64]);
+            }
+        f32x16 st = {0};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {       // S^T: rows = keys, col = query p
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kl[kb], Qh[kb], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[kb], Ql[kb], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[kb], Qh[kb], st, 0, 0, 0);
+        }
+        float sc[16], mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sc[r] = key < nk ? st[r] * a.scale : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_run == -INFINITY) ? 0.0f : expf(m_run - m_new);
+        float ps = 0.0f, pr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { pr[r] = (sc[r] == -INFINITY) ? 0.0f : expf(sc[r] - m_new); ps += pr[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+            O0[r] *= ar; O1[r] *= ar;
+        }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {       // registers 8 kb .. 8 kb + 7 are this lane half's keys of k-block kb
+            cm_h8 Ph, Pl;
+            cm_split8(pr + 8 * kb, Ph, Pl);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl, Vh[0][kb], O0, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vl[0][kb], O0, 0, 0, 0);
+            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vh[0][kb], O0, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl, Vh[1][kb], O1, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vl[1][kb], O1, 0, 0, 0);
+            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vh[1][kb], O1, 0, 0, 0);
+        }
+    }
+    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    float* op = a.out + (size_t)s * a.MP * D + head * HD + p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float ir = __shfl(inv, qi, 64);
+        if (q0 + qi < nq) {
+            op[(size_t)(q0 + qi) * D] = O0[r] * ir;
+            op[(size_t)(q0 + qi) * D + 32] = O1[r] * ir;
+        }
+    }
+}
+
 // ffn.1 + ffn.2: LayerNorm(512, eps 1e-5, affine) then exact GELU, in place (lightglue.py:166-170)
 __global__ __launch_bounds__(256) void lg_ln_gelu(float* hbuf, const float* g, const float* bta, const int* cnt, const int* active, int MP)
 {
@@ -655,7 +814,8 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
                  o_din = take(T * C), o_cat0 = take(T * 512), o_cat1 = take(T * 512), o_qkv = take(T * 768), o_q = take(T * D), o_k = take(T * D),
                  o_v = take(T * D), o_ctx = take(T * D), o_h1 = take(T * 512), o_y = take(T * D), o_conf = take(T), o_msc = take(T), o_z = take(T),
                  o_md = take(T * D), o_sim = take((size_t)B * MP * MP), o_mx = take(T), o_lg = take(T), o_bv = take(T),
-                 o_ind0 = take(T), o_ind1 = take(T), o_dst = take(T), o_bi = take(T), o_ints = take((size_t)8 * S + 64);
+                 o_ind0 = take(T), o_ind1 = take(T), o_dst = take(T), o_bi = take(T), o_ints = take((size_t)8 * S + 64),
+                 o_kf = take(T * D), o_vf = take(T * D);      // K / V in MFMA operand order, (hi, lo) halves: 4 bytes per element
     const bool fresh = need * sizeof(float) > lg->ws.cap;
     if (int rc = kpb_reserve(ctx, lg->ws, need * sizeof(float))) return rc;
     float* base = static_cast<float*>(lg->ws.p);
@@ -667,6 +827,7 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
           *mxo = base + o_mx, *lgo = base + o_lg, *bestv = base + o_bv;
     int *ind[2] = {reinterpret_cast<int*>(base + o_ind0), reinterpret_cast<int*>(base + o_ind1)}, *dst = reinterpret_cast<int*>(base + o_dst),
         *besti = reinterpret_cast<int*>(base + o_bi), *ints = reinterpret_cast<int*>(base + o_ints);
+    uint4 *kfrag = reinterpret_cast<uint4*>(base + o_kf), *vfrag = reinterpret_cast<uint4*>(base + o_vf);
     int *cnt = ints, *cnt_orig = ints + S, *newcnt = ints + 2 * S, *active_seq = ints + 3 * S, *fin_seq = ints + 4 * S, *active_pair = ints + 5 * S,
         *fin_pair = ints + 5 * S + B, *stop = ints + 6 * S;
 
@@ -699,15 +860,29 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
         // self attention (lightglue.py:173-185)
         if ((rc = lg_linear(ctx, lg, "lg_Wqkv", L + ".Wqkv", 256, 768, c, 512, qkv, 768, 0, S, MP, active_seq))) return rc;
         KPB_LAUNCH(ctx, "lg_rotary", lg_rotary, dim3(cdiv(max_k * 128, 256), S), dim3(256), 0, st, qkv, cs, sn, q, k, v, cnt, active_seq, MP);
-        FlashArgs fa{q, k, v, cx, cnt, active_seq, MP, 0, 0.125f};
-        KPB_LAUNCH(ctx, "lg_flash_self", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
+        if (conv_mfma_use_h16()) {
+            FragArgs fr{k, v, kfrag, vfrag, cnt, active_seq, MP, 0};
+            KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
+            FlashHArgs fa{q, kfrag, vfrag, cx, cnt, active_seq, MP, 0, 0.125f};
+            KPB_LAUNCH(ctx, "lg_flash_self", lg_flash_h, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
+        } else {
+            FlashArgs fa{q, k, v, cx, cnt, active_seq, MP, 0, 0.125f};
+            KPB_LAUNCH(ctx, "lg_flash_self", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
+        }
         if ((rc = lg_linear(ctx, lg, "lg_out_proj", L + ".sout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq))) return rc;
         if ((rc = ffn(L, ".s", c))) return rc;
         // cross attention (lightglue.py:216-243)
         if ((rc = lg_linear(ctx, lg, "lg_to_qk", L + ".toqk", 256, 256, c, 512, q, 256, 0, S, MP, active_seq))) return rc;
         if ((rc = lg_linear(ctx, lg, "lg_to_v", L + ".tov", 256, 256, c, 512, v, 256, 0, S, MP, active_seq))) return rc;
-        FlashArgs fc{q, q, v, cx, cnt, active_seq, MP, 1, 0.125f};
-        KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
+        if (conv_mfma_use_h16()) {
+            FragArgs fr{q, v, kfrag, vfrag, cnt, active_seq, MP, 1};
+            KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
+            FlashHArgs fc{q, kfrag, vfrag, cx, cnt, active_seq, MP, 1, 0.125f};
+            KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash_h, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
+        } else {
+            FlashArgs fc{q, q, v, cx, cnt, active_seq, MP, 1, 0.125f};
+            KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
+        }
         if ((rc = lg_linear(ctx, lg, "lg_to_out", L + ".toout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq))) return rc;
         if ((rc = ffn(L, ".c", c))) return rc;
         // confidences, stop / prune decision (lightglue.py:557-579)
