@@ -168,10 +168,13 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 // by ACT_SCALE when they are staged (exact), and the accumulator is scaled back in the epilogue (ConvM::unscale).
 // Activations beyond 65504 / ACT_SCALE = 4094 would saturate; image-normalised feature maps are orders below that.
 //
-// LDS: two planes (hi, lo) of [IH*IW] pixels x CC halves, pixel pitch 2*CC + 16 bytes = an odd number of 16-byte
-// slots, so the 16 pixels one ds_read_b128 group touches fall on distinct 4-bank sets.  A wave owns MT 32-pixel M tiles
-// (two output rows each) and reuses every weight fragment it loads (L1/L2-resident, 1 KB per wave-load) MT times;
-// MT = 2 keeps the fragment stream under the L1 rate once the MFMA time has shrunk five-fold.
+// LDS: one image [IH][IW] of pixels, each [hi: CC halves | lo: CC halves | 16 bytes pad] = 4*CC + 16 bytes = an odd number
+// of 16-byte slots, rows padded to a multiple of 256 bytes.  A ds_read_b128 is served in 16-lane groups (lanes {0-3, 12-15,
+// 20-27} and so on); with lane = (pixel row p >> 4, column p & 15) those are 8 pixels of one row and 8 of the next, and with
+// an odd pixel pitch and a row pitch of 0 mod 256 bytes their sixteen 16-byte slots are distinct (stride 1).  The first
+// r02 layout (two planes, pitch 2*CC + 16, rows unpadded) measured SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 50 %.
+// A wave owns MT 32-pixel M tiles (two output rows each) and reuses every weight fragment it loads (1 KB per wave-load,
+// L2-resident) MT times.
 typedef _Float16 cm_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
 constexpr float ACT_SCALE = 16.0f;
@@ -195,10 +198,11 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 {
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
-    constexpr int PITCH = 2 * CC + 16, PLANE = IH * IW * PITCH;     // bytes
+    constexpr int PITCH = 4 * CC + 16, LO = 2 * CC;                 // bytes per pixel, offset of its lo halves
+    constexpr int ROWP = (IW * PITCH + 255) / 256 * 256;            // bytes per tile row
     constexpr int NLD = (IH * IW * Q + 255) / 256;
-    static_assert(2 * PLANE <= 65536, "conv_mfma_h: input tile exceeds the static LDS window");
-    __shared__ __attribute__((aligned(16))) unsigned char tile[2 * PLANE];
+    static_assert(IH * ROWP <= 65536, "conv_mfma_h: input tile exceeds the static LDS window");
+    __shared__ __attribute__((aligned(256))) unsigned char tile[IH * ROWP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
     const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * 16;
@@ -257,10 +261,11 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                 const int idx = tid + k * 256;
                 const int pix = idx / Q, q = idx - pix * Q;
                 if (idx < IH * IW * Q) {
+                    const int y = pix / IW, x = pix - y * IW;
                     uint2 hi, lo;
                     cm_split4(make_float4(buf[k].x * ACT_SCALE, buf[k].y * ACT_SCALE, buf[k].z * ACT_SCALE, buf[k].w * ACT_SCALE), hi, lo);
-                    *reinterpret_cast<uint2*>(&tile[pix * PITCH + 8 * q]) = hi;
-                    *reinterpret_cast<uint2*>(&tile[PLANE + pix * PITCH + 8 * q]) = lo;
+                    *reinterpret_cast<uint2*>(&tile[y * ROWP + x * PITCH + 8 * q]) = hi;
+                    *reinterpret_cast<uint2*>(&tile[y * ROWP + x * PITCH + LO + 8 * q]) = lo;
                 }
             }
         }
@@ -280,11 +285,11 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int orow = 2 * (wv * MT + m) + (p >> 4);
-                const unsigned char* ap = &tile[((orow * S + ky) * IW + ocol * S + kx) * PITCH + h * KC * 2];
+                const unsigned char* ap = &tile[(orow * S + ky) * ROWP + (ocol * S + kx) * PITCH + h * KC * 2];
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
-                    Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + PLANE + 16 * kb));
+                    Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + LO + 16 * kb));
                 }
             }
 #pragma unroll
@@ -298,12 +303,12 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
                     }
             if (XC && nb == 0) {       // the extra channel at pixel (tid / 16, tid % 16): hi + lo restores the staged activation, weights are wave-uniform
-                const unsigned char* xp = &tile[(((tid >> 4) + ky) * IW + (tid & 15) + kx) * PITCH];
+                const unsigned char* xp = &tile[((tid >> 4) + ky) * ROWP + ((tid & 15) + kx) * PITCH];
                 const float* xw = a.xw + (size_t)tap * a.CIN + ch * CC;
 #pragma unroll
                 for (int q = 0; q < CC / 8; ++q) {
                     const cm_h8 vh = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + 16 * q));
-                    const cm_h8 vl = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + PLANE + 16 * q));
+                    const cm_h8 vl = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + LO + 16 * q));
 #pragma unroll
                     for (int e = 0; e < 8; ++e) xacc = fmaf((float)vh[e] + (float)vl[e], xw[8 * q + e], xacc);
                 }
