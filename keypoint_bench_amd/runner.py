@@ -171,12 +171,82 @@ def crop32(img):
     return img[..., : H - H % 32, : W - W % 32]
 
 
+def is_decoded_u8(v):
+    """A decoded image as cv2.imread / PIL hand it over: uint8 [H, W, 3] (the dataset has not run its own transform)."""
+    return getattr(v, "dtype", None) in (np.uint8, torch.uint8) and getattr(v, "ndim", 0) == 3 and v.shape[-1] == 3
+
+
 def as_image(v, device):
-    """Dataset items hold numpy arrays [C,H,W] (datasets/hpatches.py:74-83: no DataLoader collation here) or tensors."""
+    """Dataset items hold numpy arrays [C,H,W] (datasets/hpatches.py:74-83: no DataLoader collation here) or tensors;
+    a uint8 [H,W,3] array is a decoded image and gets the datasets' transform (RGB order kept, / 255, HWC -> CHW:
+    megadepth.py:312-313 ToTensor) on the device."""
+    if is_decoded_u8(v):
+        from .utils.preprocess import to_tensor_resized
+        return to_tensor_resized(v, device=device)[0]
     t = torch.as_tensor(v)
     if t.dtype != torch.float32:
         t = t.float()
     return t.to(device, non_blocking=True)
+
+
+def _host_array(v):
+    """numpy view of a host-resident image (numpy array or CPU tensor), None for anything already on a device."""
+    if isinstance(v, np.ndarray):
+        return v
+    if torch.is_tensor(v) and not v.is_cuda:
+        return v.detach().numpy()
+    return None
+
+
+def crop32_host(a):
+    """crop32 for host arrays: float [.., H, W] or decoded uint8 [H, W, 3]."""
+    if is_decoded_u8(a):
+        H, W = a.shape[:2]
+        return a[: H - H % 32, : W - W % 32]
+    return crop32(a)
+
+
+class HostStager:
+    """SURVEY 8(f)2, host half: a ring of pinned staging buffers filled by a pool of copy threads.  While the device works
+    on batch k, batch k + 1 is gathered from the dataset items into the other pinned buffer (numpy copies release the GIL);
+    each batch then crosses PCIe as ONE asynchronous copy.  Decoded uint8 images travel as they are (a quarter of the
+    bytes) and become fp32 CHW on the device (csrc/preprocess.hip)."""
+
+    def __init__(self, slots=3, workers=None):
+        import concurrent.futures
+        import threading
+        self.slots = slots
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers or max(2, min(16, len(os.sched_getaffinity(0)))))
+        import queue
+        self.free = queue.Queue()
+        for i in range(slots):
+            self.free.put(i)
+        self.order = queue.Queue()          # slots in the order they were handed out = the order they come back
+        self.bufs = {}
+
+    def acquire(self, shape, dtype):
+        """Blocks until a slot is free; returns (slot id, pinned tensor of `shape`).  Pinning is slow (about a second per
+        GB), so a slot keeps its buffer and serves smaller requests of the same dtype from it."""
+        slot = self.free.get()
+        self.order.put(slot)
+        n = int(np.prod(shape))
+        buf = self.bufs.get((slot, dtype))
+        if buf is None or buf.numel() < n:
+            buf = torch.empty((n,), dtype=dtype).pin_memory()
+            self.bufs[(slot, dtype)] = buf
+        return slot, buf[:n].view(tuple(shape))
+
+    def release(self):
+        """Gives back the oldest slot still out (slots are consumed in the order they were filled)."""
+        self.free.put(self.order.get())
+
+    def fill(self, pinned, arrays):
+        """pinned[j] <- arrays[j] for every j, in parallel."""
+        dst = pinned.numpy()
+        list(self.pool.map(lambda ja: np.copyto(dst[ja[0]], ja[1].reshape(dst.shape[1:])), enumerate(arrays)))
+
+    def close(self):
+        self.pool.shutdown(wait=True)
 
 
 def is_sequence_item(item):
@@ -301,6 +371,8 @@ class PairRunner:
         self.last_batch = None
         self._pipes = {}
         self.batched_pairs = 0
+        self.staged_batches = 0
+        self._stager = None
 
     # ---- single pair (model_interface.py:189-212 + the task call)
     def test_step(self, batch, idx):
@@ -360,16 +432,26 @@ class PairRunner:
                                 torch.empty((2 * B, 3, H, W), dtype=torch.float32, device=self.device))
         return self._pipes[key]
 
-    def _flush(self, group, task_type):
-        """group: list of (index, item, img0, img1) with equal cropped shapes."""
+    def _flush(self, group, task_type, staged=None):
+        """group: list of (index, item, img0, img1) with equal cropped shapes.  staged: device tensor [2f, ...] holding the
+        group's images -- views 0 first, then views 1 -- when the HostStager path has brought them over."""
         fn, match, covis = BATCHED_TASKS[task_type]
         f = len(group)
-        H, W = group[0][2].shape[-2:]
+        u8 = is_decoded_u8(group[0][2])
+        H, W = group[0][2].shape[:2] if u8 else group[0][2].shape[-2:]
         B = self.batch if f > self.batch // 2 else f        # a short tail gets a pipeline of its own size
         pipe, images = self._pipe(B, H, W, match)
-        for j, (_, _, a, b) in enumerate(group):
-            images[j].copy_(a.reshape(3, H, W), non_blocking=True)
-            images[B + j].copy_(b.reshape(3, H, W), non_blocking=True)
+        if staged is not None:      # the group's images, already on the device (copied on the staging stream)
+            if u8:                  # decoded bytes: the datasets' transform on the device
+                from .utils.preprocess import to_tensor_resized
+                staged = to_tensor_resized(staged, device=self.device)
+            images[:f].copy_(staged[:f].reshape(f, 3, H, W))
+            images[B:B + f].copy_(staged[f:].reshape(f, 3, H, W))
+            self.staged_batches += 1
+        else:
+            for j, (_, _, a, b) in enumerate(group):
+                images[j].copy_(a.reshape(3, H, W), non_blocking=True)
+                images[B + j].copy_(b.reshape(3, H, W), non_blocking=True)
         for j in range(f, B):                               # pad with the last pair; its rows are dropped
             images[j].copy_(images[f - 1])
             images[B + j].copy_(images[B + f - 1])
@@ -384,7 +466,11 @@ class PairRunner:
         if task_type == "FundamentalMatrixRansac":          # the batched rows are the brute-force branch without cv2 drawing
             mp = self.params["matcher_params"]
             batched = batched and mp["type"] == "brute_force" and not mp.get("save_result") and not self.params["extractor_params"].get("save_result")
-        out, group, shape = {}, [], None
+        out = {}
+        host = batched and len(indices) > 0 and _host_array(dataset[indices[0]]["image0"]) is not None
+        if host:
+            return self._run_pairs_staged(dataset, indices, task_type)
+        group, shape = [], None
 
         def flush():
             nonlocal group
@@ -411,6 +497,110 @@ class PairRunner:
             if len(group) == self.batch:
                 flush()
         flush()
+        return [out[i] for i in indices]
+
+    def _run_pairs_staged(self, dataset, indices, task_type):
+        """The batched pair path for HOST-resident dataset items (numpy arrays / CPU tensors, fp32 CHW or decoded uint8 HWC):
+        a producer thread walks the dataset, groups pairs of equal cropped shape and gathers each group into a pinned
+        buffer of the HostStager while the main thread runs the previous group on the device.  Rows are those of the
+        device-resident path; pairs the batched path does not take (ragged views, se3 warps for the homography tasks) go
+        through `test_step` on the main thread, in order."""
+        import queue
+        import threading
+        if self._stager is None:
+            self._stager = HostStager()
+        st = self._stager
+        q = queue.Queue(maxsize=1)
+
+        def shape_of(a):
+            return tuple(a.shape[:2]) if is_decoded_u8(a) else tuple(a.shape[-2:])
+
+        def produce():
+            try:
+                group, key = [], None
+
+                def emit():
+                    nonlocal group
+                    if group:
+                        u8 = is_decoded_u8(group[0][2])
+                        f = len(group)
+                        shp = (2 * f,) + (tuple(group[0][2].shape) if u8 else (3,) + shape_of(group[0][2]))
+                        _, pinned = st.acquire(shp, torch.uint8 if u8 else torch.float32)
+                        st.fill(pinned, [g[2] for g in group] + [g[3] for g in group])
+                        q.put(("batch", group, pinned))
+                    group = []
+
+                for i in indices:
+                    item = dataset[i]
+                    a, b = _host_array(item["image0"]), _host_array(item["image1"])
+                    single = a is None or b is None or (task_type not in ("AUC", "FundamentalMatrixRansac") and not _homo_only(item))
+                    if not single:
+                        a, b = crop32_host(a), crop32_host(b)
+                        if a.dtype != b.dtype or shape_of(a) != shape_of(b) or (a.dtype != np.uint8 and a.dtype != np.float32):
+                            single = True
+                    if single:
+                        emit()
+                        q.put(("single", i, item))
+                        continue
+                    k = (a.dtype, shape_of(a))
+                    if key is not None and k != key:
+                        emit()
+                    key = k
+                    group.append((i, item, a, b))
+                    if len(group) == self.batch:
+                        emit()
+                emit()
+                q.put(("end", None, None))
+            except BaseException as e:          # surfaces on the main thread
+                q.put(("error", e, None))
+
+        out = {}
+        copy_stream = torch.cuda.Stream(self.device)
+        pending = None          # (group, device tensor, copy-done event): its PCIe copy runs under the previous group's kernels
+
+        def start_copy(group, pinned):
+            main = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(copy_stream):
+                dev = pinned.to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            dev.record_stream(main)
+            return group, dev, ev
+
+        def finish(p):
+            group, dev, ev = p
+            ev.synchronize()        # the copy has left the pinned slot: the producer may refill it
+            st.release()
+            rows = self._flush(group, task_type, staged=dev)
+            for (i, _, _, _), r in zip(group, rows):
+                out[i] = r
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        try:
+            while True:
+                kind, x, y = q.get()
+                if kind == "error":
+                    raise x
+                nxt = start_copy(x, y) if kind == "batch" else None
+                if pending is not None:
+                    finish(pending)
+                pending = nxt
+                if kind == "end":
+                    break
+                if kind == "single":
+                    out[x] = self.test_step(y, x)
+        finally:
+            if pending is not None:             # only on an error path: give the slot back
+                st.release()
+            while th.is_alive():                # drain so that the producer can finish if the consumer failed
+                try:
+                    kind, x, y = q.get(timeout=0.1)
+                    if kind == "batch":
+                        st.release()
+                except queue.Empty:
+                    pass
+            th.join()
         return [out[i] for i in indices]
 
     # ---- batched sequence (BASELINE configs[3]: brute-force branch)

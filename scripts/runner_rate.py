@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=32)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--host", action="store_true")
+    ap.add_argument("--u8", action="store_true", help="with --host: items are decoded uint8 [H,W,3] images (a quarter of the PCIe bytes)")
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--tasks", nargs="+", default=["match_stats", "repeatability", "MHA", "AUC"])
     args = ap.parse_args()
@@ -33,6 +34,8 @@ def main():
     H, W = 480, 640
     h01 = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
     views = [synthetic.image_pair(5000 + i, H, W) for i in range(args.distinct)]
+    if args.u8:
+        views = [tuple(np.ascontiguousarray((v.transpose(1, 2, 0) * 255.0 + 0.5).astype(np.uint8)) for v in pair) for pair in views]
     if not args.host:
         views = [(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)) for a, b in views]
     ds = []
@@ -44,7 +47,7 @@ def main():
         ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
                    "warp01_params": dict(mode="homo", homography_matrix=h01, width=W, height=H, intrinsics0=K, intrinsics1=K, pose01=T01),
                    "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(h01).astype(np.float32), width=W, height=H)})
-    out = {"pairs": args.pairs, "batch": args.batch, "items": "host numpy" if args.host else "device tensors",
+    out = {"pairs": args.pairs, "batch": args.batch, "items": ("host uint8 HWC" if args.u8 else "host numpy fp32 CHW") if args.host else "device tensors",
            "descriptors": "dense-map" if args.dense else "keypoint-only"}
     for task in args.tasks:
         params = {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),

@@ -154,3 +154,29 @@ def test_visual_odometer_rows_batched_equal_single_and_chunks_reproduce_them():
     np.testing.assert_allclose(rows1[3, :9].reshape(3, 3), R, atol=2e-5)
     np.testing.assert_allclose(rows1[3, 9:12], tt, atol=2e-5)
     assert abs(rows1[3, 12] - np.hypot(0.05, 0.02)) < 1e-6
+
+
+def test_host_items_are_staged_through_pinned_buffers_and_decoded_uint8_images_equal_their_fp32_form():
+    """numpy items take the HostStager path (pinned ring, one PCIe copy per batch, copy under compute); a
+    decoded uint8 [H,W,3] image gives the rows of its ToTensor form (megadepth.py:312-313) handed over as fp32 CHW."""
+    ds = pair_dataset(10, shapes=((96, 128), (96, 128), (64, 96)))
+    u8, f32, dev = [], [], []
+    for it in ds:
+        a = np.ascontiguousarray((it["image0"].transpose(1, 2, 0) * 255.0 + 0.5).astype(np.uint8))
+        b = np.ascontiguousarray((it["image1"].transpose(1, 2, 0) * 255.0 + 0.5).astype(np.uint8))
+        u8.append(dict(it, image0=a, image1=b))
+        fa = np.ascontiguousarray((a.astype(np.float32) / np.float32(255)).transpose(2, 0, 1))
+        fb = np.ascontiguousarray((b.astype(np.float32) / np.float32(255)).transpose(2, 0, 1))
+        f32.append(dict(it, image0=fa, image1=fb))
+        dev.append(dict(it, image0=torch.from_numpy(fa).to(DEV), image1=torch.from_numpy(fb).to(DEV)))
+    rows = {}
+    for name, d in (("u8", u8), ("f32", f32), ("dev", dev)):
+        r = runner.PairRunner(params("repeatability"), device=DEV, batch=4)
+        _, rows[name] = r.run(d)
+        assert r.batched_pairs == 10
+        assert (r.staged_batches == 0) == (name == "dev"), (name, r.staged_batches)
+    assert np.array_equal(rows["f32"].view(np.uint32), rows["dev"].view(np.uint32))
+    assert np.array_equal(rows["u8"].view(np.uint32), rows["f32"].view(np.uint32))
+    single = runner.PairRunner(params("repeatability"), device=DEV, batch=1)
+    _, rows1 = single.run(u8)                     # the single-pair path takes decoded images too
+    assert np.array_equal(rows1.view(np.uint32), rows["u8"].view(np.uint32))
