@@ -185,9 +185,9 @@ def test_lightglue_restatement_matches_reference():
     import make_golden_lightglue as mk
     g = load_golden("lightglue.npz")
     for name in g["cases"]:
-        dim, scale, seed = (int(v) for v in g[name + ".cfg"])
+        dim, scale, seed, n0, n1 = (int(v) for v in g[name + ".cfg"])
         t = {k: torch.from_numpy(v) for k, v in weights.tensors_lightglue(weights.random_lightglue_state_dict(seed, dim, str(g[name + ".variant"]))).items()}
-        dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale)
+        dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale, n0=n0, n1=n1)
         with torch.no_grad():
             m0, m1, out = R.match(t, torch.from_numpy(p0), torch.from_numpy(p1), torch.from_numpy(dm0), torch.from_numpy(dm1), {"w": 320, "h": 240}, scale)
         np.testing.assert_array_equal(out["matches"].numpy(), g[name + ".matches"], err_msg=name)
