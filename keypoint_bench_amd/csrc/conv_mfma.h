@@ -372,6 +372,112 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 1x1 / Linear
+// A 1x1 convolution has no taps to amortise the staging of conv_mfma_h over: per 32-channel slab it pays a global-load
+// latency, two barriers and a weight-fragment latency for 24 MFMAs.  gemm_h is the same product as a software pipeline
+// over the slabs: the rows (pixels / tokens) of slab c + 1 are already in registers (global loads issued before the MFMAs
+// of slab c) and go into the OTHER of two LDS buffers behind them, so there is one barrier per slab and the loads fly
+// under the matrix work.  Workgroup = 256 rows x 32 NTB columns; wave = 64 rows (two M tiles); weights in pack_mfma_h's
+// KS = 1 order; LDS rows as in conv_mfma_h (hi | lo | pad, 144 bytes: nine 16-byte slots, conflict-free).
+template <int NTB>
+__global__ __launch_bounds__(256) void gemm_h(ConvM a)
+{
+    constexpr int CC = 32, KC = 16, NKB = 2, Q = CC / 4, PITCH = 4 * CC + 16, LO = 2 * CC, ROWS = 256, BUF = ROWS * PITCH, NLD = ROWS * Q / 256;
+    __shared__ __attribute__((aligned(256))) unsigned char tile[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
+    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
+    if (a.active && !a.active[b]) return;
+    const int nrows = a.H * a.W, r0 = blockIdx.x * ROWS;
+    const float* in = a.in + (size_t)b * nrows * a.istride;
+    const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][chunk][kb][hi/lo][h][32] x 8 halves
+    const size_t ntile_stride = (size_t)a.NCH * NKB * 4 * 32;
+
+    f32x16 acc[2][NTB];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    float4 buf[NLD];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256, row = idx / Q, q = idx - row * Q;
+            buf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < nrows) buf[k] = *reinterpret_cast<const float4*>(in + (size_t)(r0 + row) * a.istride + ch * CC + 4 * q);
+        }
+    };
+    auto stage = [&](int which) {
+        unsigned char* t = tile + which * BUF;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256, row = idx / Q, q = idx - row * Q;
+            uint2 hi, lo;
+            cm_split4(make_float4(buf[k].x * ACT_SCALE, buf[k].y * ACT_SCALE, buf[k].z * ACT_SCALE, buf[k].w * ACT_SCALE), hi, lo);
+            *reinterpret_cast<uint2*>(&t[row * PITCH + 8 * q]) = hi;
+            *reinterpret_cast<uint2*>(&t[row * PITCH + LO + 8 * q]) = lo;
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    // (Also requesting the next slab's weight fragments a slab ahead costs 94 more VGPRs and the second wave per SIMD: 1.7x slower.)
+    for (int ch = 0; ch < a.NCH; ++ch) {
+        const bool more = ch + 1 < a.NCH;
+        if (more) fetch(ch + 1);
+        const uint4* bp = wq + (((size_t)nt0 * a.NCH + ch) * NKB * 4 + h) * 32 + p;
+        cm_h8 Bh[NTB][NKB], Bl[NTB][NKB], Ah[2][NKB], Al[2][NKB];
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                Bh[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 0) * 32]);
+                Bl[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 2) * 32]);
+            }
+        const unsigned char* t = tile + (ch & 1) * BUF;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const unsigned char* ap = t + (64 * wv + 32 * m + p) * PITCH + h * KC * 2;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
+                Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + LO + 16 * kb));
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bl[n][kb], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
+                }
+        if (more) stage((ch + 1) & 1);      // the other buffer: its last readers passed the barrier of slab ch - 1
+        __syncthreads();
+    }
+
+    float* out = a.out + (size_t)b * nrows * a.ostride + a.ooff;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+            const int co = (nt0 + n) * 32 + p;
+            const float bias = a.bias[co];
+            if (co >= a.COUT) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + 64 * wv + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = fmaf(acc[m][n][r], a.unscale, bias);
+                if (a.relu) v = relu(v);
+                if (row < nrows) out[(size_t)row * a.ostride + co] = v;
+            }
+        }
+}
+
 // power of two that brings max|w| into [2^12, 2^13); 1 for an all-zero layer
 inline float weight_scale_h(const float* w, size_t n)
 {

@@ -705,7 +705,9 @@ int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name
     a.istride = istride; a.ostride = ostride; a.ooff = ooff;
     if (conv_mfma_use_h16()) {
         a.unscale = 1.0f / (ACT_SCALE * lg->wscale.at(name + ".w"));
-        KPB_LAUNCH(ctx, tag, (conv_mfma_h<1, 1, 32, false, false, false, 2, 2>), dim3(1, cdiv(MP, 256), S * a.nblk), dim3(256), 0, ctx->stream, a);
+        static const int pipe = kpb_env_int("KPB_GEMM_PIPE", 1);
+        if (pipe) KPB_LAUNCH(ctx, tag, (gemm_h<2>), dim3(cdiv(MP, 256), 1, S * a.nblk), dim3(256), 0, ctx->stream, a);
+        else KPB_LAUNCH(ctx, tag, (conv_mfma_h<1, 1, 32, false, false, false, 2, 2>), dim3(1, cdiv(MP, 256), S * a.nblk), dim3(256), 0, ctx->stream, a);
     } else
         KPB_LAUNCH(ctx, tag, (conv_mfma<1, 1, 32, false, false, false, 2>), dim3(1, MP / 128, S * a.nblk), dim3(256), 0, ctx->stream, a);
     return KPB_OK;
