@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void conv3x3_h16(H16Args a)
 struct Block2Args {
     const float* p1;     // [B][H][W][8]
     float* x2; float* a2; float* S2;
+    float* p2;           // [B][H/4][W/4][16] = max_pool2d(x2, 4, 4) (ALike.py:141), what block 3 reads; when given, x2 itself is not written
     const uint4* w1pk;   // pack_h16(b2c1.w, 8, null): 3 k-blocks
     const uint4* w2pk;   // pack_h16(b2c2.w, 16, b2ds.w): 5 k-blocks
     const uint4* wapk;   // pack_1x1_h16(agg2.w): 1 k-block
@@ -725,15 +726,18 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         }
     }
     __syncthreads();
-    // conv2 + identity branch + ReLU -> x2; agg2 + ReLU -> a2, S2.  16 groups of 16 pixels per tile, four per wave
+    // conv2 + identity branch + ReLU -> x2; agg2 + ReLU -> a2, S2.  16 groups of 16 pixels per tile, four per wave: a wave owns
+    // four rows of one 16-column half, so the 4 x 4 max-pool block 3 starts with is a running maximum over its four groups and
+    // two lane exchanges, and only the pooled map (a sixteenth of x2) goes to HBM.
     const float4 bsum = *reinterpret_cast<const float4*>(a.bsum + 4 * g), wsg = *reinterpret_cast<const float4*>(a.wsg + 4 * g);
     float* x2 = a.x2 + (size_t)b * P * 16;
     float* a2 = a.a2 + (size_t)b * P * 16;
     float* S2 = a.S2 + (size_t)b * P;
     uint2* xh = reinterpret_cast<uint2*>(&xs[wv][0][0][0]);
+    float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);        // x2 >= 0 (ReLU): zero is the neutral element of the pool
 #pragma unroll 1
-    for (int gi = 4 * wv; gi < 4 * wv + 4; ++gi) {
-        const int row = gi >> 1, col0 = (gi & 1) * 16;
+    for (int k4 = 0; k4 < 4; ++k4) {
+        const int row = 4 * (wv >> 1) + k4, col0 = (wv & 1) * 16;
         const int mbase = row * MW + col0 + px;
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -753,7 +757,8 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         const int gy = ty0 + row, gx = tx0 + col0 + px;
         const bool ok = gy < a.H && gx < a.W;
         const float4 v = make_float4(relu(acc[0] + bsum.x), relu(acc[1] + bsum.y), relu(acc[2] + bsum.z), relu(acc[3] + bsum.w));
-        if (ok) *reinterpret_cast<float4*>(x2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = v;
+        if (ok && !a.p2) *reinterpret_cast<float4*>(x2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = v;
+        pm = make_float4(fmaxf(pm.x, v.x), fmaxf(pm.y, v.y), fmaxf(pm.z, v.z), fmaxf(pm.w, v.w));
         {   // the x2 group, split, to this wave's LDS strip with the channel octets as slots: the B operand of agg2
             uint2 hi, lo;
             split4(v, hi, lo);
@@ -776,6 +781,15 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         sg += __shfl_xor(sg, 16, 64);
         sg += __shfl_xor(sg, 32, 64);
         if (g == 0 && ok) S2[(size_t)gy * a.W + gx] = sg;
+    }
+    if (a.p2) {     // columns: lanes px, px ^ 1, px ^ 2, px ^ 3 hold the four pixels of a pooled cell
+        pm.x = fmaxf(pm.x, __shfl_xor(pm.x, 1, 64)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, 1, 64));
+        pm.z = fmaxf(pm.z, __shfl_xor(pm.z, 1, 64)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, 1, 64));
+        pm.x = fmaxf(pm.x, __shfl_xor(pm.x, 2, 64)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, 2, 64));
+        pm.z = fmaxf(pm.z, __shfl_xor(pm.z, 2, 64)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, 2, 64));
+        const int gy = ty0 + 4 * (wv >> 1), gx = tx0 + (wv & 1) * 16 + px;
+        if ((px & 3) == 0 && gy < a.H && gx < a.W)
+            *reinterpret_cast<float4*>(a.p2 + (size_t)b * (P / 16) * 16 + ((size_t)(gy >> 2) * (a.W >> 2) + (gx >> 2)) * 16 + 4 * g) = pm;
     }
 }
 
@@ -1553,7 +1567,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     const size_t n_s = B * (P / 4 + P / 64 + P / 1024) + 64;
     const size_t n_e = desc_out_dev ? B * (P / 64 + P / 1024) * ESTRIDE : 0;
     const size_t n_p1 = B * (P / 4) * 8;
-    const size_t total = n_x1 + n_p1 + 3 * n_2 + 3 * n_3 + n_a3 + 3 * n_4 + n_a4 + n_s + n_e;
+    const size_t total = n_x1 + n_p1 + 3 * n_2 + 6 * n_3 + n_a3 + 5 * n_4 + n_a4 + n_s + n_e;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
@@ -1563,6 +1577,9 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     t4 = p; p += n_4; x4 = p; p += n_4; a4 = p; p += n_a4;
     float* r3 = p; p += n_3;
     float* r4 = p; p += n_4;
+    float* t3r3 = p; p += 2 * n_3;      // conv_mfma_h form of blocks 3 / 4: conv1's output and the identity branch side by side per pixel
+    float* t4r4 = p; p += 2 * n_4;
+    float* p2 = p; p += n_3 / 2;        // max_pool2d(x2, 4): [B][H/8][W/8][16]
     S2 = p; p += B * (P / 4); S3 = p; p += B * (P / 64); S4 = p; p += B * (P / 1024) + 64;
     E3 = E4 = nullptr;
     if (desc_out_dev) { E3 = p; p += B * (P / 64) * ESTRIDE; E4 = p; p += B * (P / 1024) * ESTRIDE; }
@@ -1578,11 +1595,15 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
 
     ConvArgs c;
+    bool p2_valid = false;
     // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
     c = ConvArgs{p1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};      // pooled by block1
     static const int h16 = kpb_env_int("KPB_CONV_H16", 1), fuse2 = kpb_env_int("KPB_BLOCK2_FUSED", 1);
     if (h16 && fuse2) {
-        Block2Args b2{p1, x2, a2, S2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
+        static const int b34 = kpb_env_int("KPB_BLOCK34_H16", 1);
+        const bool pooled = b34 && conv_mfma_use_h16();     // block 3 then reads the pooled map this kernel leaves
+        p2_valid = pooled;
+        Block2Args b2{p1, x2, a2, S2, pooled ? p2 : nullptr, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
                       reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2};
         KPB_LAUNCH(ctx, "alike_block2", alike_block2, dim3(cdiv(W / 2, 32), cdiv(H / 2, 8), batch), dim3(256), 0, st, b2);
     } else if (h16) {
@@ -1596,33 +1617,65 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), p1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
         launch_conv<16, 16, 1, true, 8, 1>(ctx, "conv3x3_b2c2", st, c, batch);
     }
+    // blocks 3 and 4 @ H/8, H/32 (141-144).  conv_mfma_h form: conv1 reads the previous block's output max-pooled 4 x 4 while it
+    // stages it, and carries the identity branch ds(pooled input) as 32 / 64 more output channels whose weights sit on the
+    // centre tap only (no ReLU on those tiles); conv2 then reads conv1's half of that buffer and adds the other half.
+    static const int b34h = kpb_env_int("KPB_BLOCK34_H16", 1);
+    auto block_h = [&](const char* n1, const char* n2, const float* in, float* tr, float* xo, int cin, int cout, int Hi, int Wi, bool prepooled) {
+        const std::string k1 = std::string(n1) + ".h", k2 = std::string(n2) + ".wp";
+        ConvM m;
+        m.in = in; m.out = tr; m.wp = wp(k1.c_str()); m.bias = wp((std::string(n1) + ".hb").c_str()); m.xf = nullptr; m.active = nullptr; m.res = nullptr;
+        m.Hi = prepooled ? Hi / 4 : Hi; m.Wi = prepooled ? Wi / 4 : Wi; m.H = Hi / 4; m.W = Wi / 4;
+        m.CIN = cin; m.COUT = 2 * cout; m.NCH = 1; m.relu = 2; m.relu_nt = cout / 32;
+        m.nblk = cout / 32; m.istride = cin; m.ostride = 2 * cout; m.ooff = 0;
+        m.unscale = 1.0f / (ACT_SCALE * wscale.at(k1));
+        const dim3 grid(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk);
+        const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
+        if (cin == 16 && prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 2>), grid, dim3(256), 0, st, m);
+        else if (cin == 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, true, false, false, 2, 2, false, 4>), grid, dim3(256), 0, st, m);
+        else KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 2, 2, false, 4>), grid, dim3(256), 0, st, m);
+        ConvM c2;
+        c2.in = tr; c2.out = xo; c2.wp = wp(k2.c_str()); c2.bias = wp((std::string(n2) + ".bp").c_str()); c2.xf = nullptr; c2.active = nullptr;
+        c2.res = tr + cout; c2.rstride = 2 * cout;
+        c2.Hi = Hi / 4; c2.Wi = Wi / 4; c2.H = Hi / 4; c2.W = Wi / 4; c2.CIN = cout; c2.COUT = cout; c2.NCH = cout / 32; c2.relu = 0; c2.nblk = 1;
+        c2.istride = 2 * cout; c2.ostride = cout; c2.ooff = 0;
+        c2.unscale = 1.0f / (ACT_SCALE * wscale.at(k2));
+        const dim3 g2(cdiv(c2.W, 16), cdiv(c2.H, 16), batch);
+        if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), g2, dim3(256), 0, st, c2);
+        else KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, dim3(256), 0, st, c2);
+    };
+    if (b34h && conv_mfma_use_h16()) {
+        block_h("b3c1", "b3c2", p2_valid ? p2 : x2, t3r3, x3, 16, 32, H / 2, W / 2, p2_valid);
+        block_h("b4c1", "b4c2", x3, t4r4, x4, 32, 64, H / 8, W / 8, false);
+    } else {
     // block3 @ H/8 (141-142): pool4
-    c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
-    launch_conv<16, 32, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b3c1", st, c, batch);        // 80 columns at 480x640: 16-wide tiles divide them
-    {   // conv2 of block3 on the MFMA kernel, identity branch precomputed (ALike.py:72-80)
-        ConvM m;
-        m.in = t3; m.out = x3; m.wp = wp("b3c2.wp"); m.bias = wp("b3c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r3;
-        m.Hi = H / 8; m.Wi = W / 8; m.H = H / 8; m.W = W / 8; m.CIN = 32; m.COUT = 32; m.NCH = 1; m.relu = 0; m.nblk = 1;
-        m.istride = 32; m.ostride = 32; m.ooff = 0;
-        if (conv_mfma_use_h16()) {
-            m.unscale = 1.0f / (ACT_SCALE * wscale.at("b3c2.wp"));
-            KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
-        } else
-            KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
-    }
-    // block4 @ H/32 (143-144): pool4
-    c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, wp("b4ds.w"), wp("b4ds.b"), r4, H / 32, W / 32};
-    launch_conv<32, 64, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b4c1", st, c, batch);
-    {
-        ConvM m;
-        m.in = t4; m.out = x4; m.wp = wp("b4c2.wp"); m.bias = wp("b4c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r4;
-        m.Hi = H / 32; m.Wi = W / 32; m.H = H / 32; m.W = W / 32; m.CIN = 64; m.COUT = 64; m.NCH = 2; m.relu = 0; m.nblk = 1;
-        m.istride = 64; m.ostride = 64; m.ooff = 0;
-        if (conv_mfma_use_h16()) {
-            m.unscale = 1.0f / (ACT_SCALE * wscale.at("b4c2.wp"));
-            KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
-        } else
-            KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+        c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
+        launch_conv<16, 32, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b3c1", st, c, batch);        // 80 columns at 480x640: 16-wide tiles divide them
+        {   // conv2 of block3 on the MFMA kernel, identity branch precomputed (ALike.py:72-80)
+            ConvM m;
+            m.in = t3; m.out = x3; m.wp = wp("b3c2.wp"); m.bias = wp("b3c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r3;
+            m.Hi = H / 8; m.Wi = W / 8; m.H = H / 8; m.W = W / 8; m.CIN = 32; m.COUT = 32; m.NCH = 1; m.relu = 0; m.nblk = 1;
+            m.istride = 32; m.ostride = 32; m.ooff = 0;
+            if (conv_mfma_use_h16()) {
+                m.unscale = 1.0f / (ACT_SCALE * wscale.at("b3c2.wp"));
+                KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
+            } else
+                KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+        }
+        // block4 @ H/32 (143-144): pool4
+        c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, wp("b4ds.w"), wp("b4ds.b"), r4, H / 32, W / 32};
+        launch_conv<32, 64, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b4c1", st, c, batch);
+        {
+            ConvM m;
+            m.in = t4; m.out = x4; m.wp = wp("b4c2.wp"); m.bias = wp("b4c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r4;
+            m.Hi = H / 32; m.Wi = W / 32; m.H = H / 32; m.W = W / 32; m.CIN = 64; m.COUT = 64; m.NCH = 2; m.relu = 0; m.nblk = 1;
+            m.istride = 64; m.ostride = 64; m.ooff = 0;
+            if (conv_mfma_use_h16()) {
+                m.unscale = 1.0f / (ACT_SCALE * wscale.at("b4c2.wp"));
+                KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
+            } else
+                KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+        }
     }
     // aggregation 1x1 + ReLU (147-150), each with its share of the score logit; agg1 is fused into the head
     if (!(h16 && fuse2))
@@ -1730,6 +1783,24 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
             ws.put(name, pack_mfma(w, cout, cin, 3, 32, ntb));
         }
     };
+    auto put_c1ds = [&](const char* name, const float* w1, const float* b1, const float* wds, const float* bds, int cout, int cin) {
+        // OIHW [2 cout][cin][3][3]: rows 0 .. cout-1 = conv1, rows cout .. = the 1x1 identity branch on the centre tap
+        std::vector<float> w((size_t)2 * cout * cin * 9, 0.0f), bb(2 * cout);
+        memcpy(w.data(), w1, (size_t)cout * cin * 9 * sizeof(float));
+        for (int o = 0; o < cout; ++o) {
+            for (int c = 0; c < cin; ++c) w[((size_t)(cout + o) * cin + c) * 9 + 4] = wds[(size_t)o * cin + c];
+            bb[o] = b1[o]; bb[cout + o] = bds[o];
+        }
+        const float sc = weight_scale_h(w.data(), w.size());
+        const std::string k = std::string(name) + ".h";
+        ws.put(k, pack_mfma_h(w.data(), 2 * cout, cin, 3, cin == 16 ? 16 : 32, 2, sc));
+        ws.wscale[k] = sc;
+        ws.put(std::string(name) + ".hb", bb);
+    };
+    if (conv_mfma_use_h16()) {
+        put_c1ds("b3c1", bl.get("b3c1.w", {c3, c2, 3, 3}), bl.get("b3c1.b", {c3}), bl.get("b3ds.w", {c3, c2}), bl.get("b3ds.b", {c3}), 32, 16);
+        put_c1ds("b4c1", bl.get("b4c1.w", {c4, c3, 3, 3}), bl.get("b4c1.b", {c4}), bl.get("b4ds.w", {c4, c3}), bl.get("b4ds.b", {c4}), 64, 32);
+    }
     put_mfma("b3c2.wp", bl.get("b3c2.w", {c3, c3, 3, 3}), 32, 32, 1);
     ws.put("b3c2.bp", pad_bias(bl.get("b3c2.b", {c3}), 32, 32));
     put_mfma("b4c2.wp", bl.get("b4c2.w", {c4, c4, 3, 3}), 64, 64, 2);

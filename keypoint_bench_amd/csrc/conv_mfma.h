@@ -24,6 +24,8 @@ struct ConvM {
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
     int istride, ostride, ooff;   // floats between consecutive input / output pixels, channel offset of the output
     float unscale = 1.0f;         // conv_mfma_h: 1 / (ACT_SCALE x the layer's weight scale)
+    int relu_nt = 0;              // conv_mfma_h with relu == 2: only the first relu_nt 32-wide output tiles get the ReLU
+    int rstride = 0;              // floats between consecutive pixels of `res` (0: COUT)
     const float* xw = nullptr;    // conv_mfma_h<XC>: [tap][CIN] fp32 weights / ACT_SCALE of ONE extra output channel (index xco) taken on the VALU
     float xb = 0.0f;              // its bias
     int xco = 0;
@@ -193,7 +195,8 @@ __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
 // 32-wide MFMA tile on it.
 // (Tried, r02: requesting the weight fragments of tap t + 1 before the MFMAs of tap t in a second register set -- 12-15 %
 // slower on every layer; the extra 32-64 VGPRs cost a wave per SIMD and the other waves already cover the L2 latency.)
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false>
+// PF: with POOL_IN the input is max-pooled PF x PF (2 or 4) while it is staged (ALike.py:139-143).
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2>
 __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 {
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
     const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * 16;
-    const int Hc = POOL_IN ? a.Hi / 2 : a.Hi, Wc = POOL_IN ? a.Wi / 2 : a.Wi;
+    const int Hc = POOL_IN ? a.Hi / PF : a.Hi, Wc = POOL_IN ? a.Wi / PF : a.Wi;
     const int iy0 = ty0 * S - PAD, ix0 = tx0 * S - PAD;
     if (a.active && !a.active[b]) return;
     const float* in = a.in + (size_t)b * a.Hi * a.Wi * a.istride;
@@ -236,12 +239,16 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (idx < IH * IW * Q && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
                     if (POOL_IN) {
-                        const float* s = in + ((size_t)(2 * gy) * a.Wi + 2 * gx) * a.istride + ch * CC + 4 * q;
-                        const float4 v00 = *reinterpret_cast<const float4*>(s), v01 = *reinterpret_cast<const float4*>(s + a.istride);
-                        const float4 v10 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.istride);
-                        const float4 v11 = *reinterpret_cast<const float4*>(s + (size_t)a.Wi * a.istride + a.istride);
-                        v.x = fmaxf(fmaxf(v00.x, v01.x), fmaxf(v10.x, v11.x)); v.y = fmaxf(fmaxf(v00.y, v01.y), fmaxf(v10.y, v11.y));
-                        v.z = fmaxf(fmaxf(v00.z, v01.z), fmaxf(v10.z, v11.z)); v.w = fmaxf(fmaxf(v00.w, v01.w), fmaxf(v10.w, v11.w));
+                        const float* s = in + ((size_t)(PF * gy) * a.Wi + PF * gx) * a.istride + ch * CC + 4 * q;
+                        v = *reinterpret_cast<const float4*>(s);
+#pragma unroll
+                        for (int py = 0; py < PF; ++py)
+#pragma unroll
+                            for (int px = 0; px < PF; ++px) {
+                                if (py == 0 && px == 0) continue;
+                                const float4 w4 = *reinterpret_cast<const float4*>(s + ((size_t)py * a.Wi + px) * a.istride);
+                                v.x = fmaxf(v.x, w4.x); v.y = fmaxf(v.y, w4.y); v.z = fmaxf(v.z, w4.z); v.w = fmaxf(v.w, w4.w);
+                            }
                     } else {
                         v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.istride + ch * CC + 4 * q);
                     }
@@ -336,12 +343,13 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 v[r] = fmaf(acc[m][n][r], a.unscale, bias);
-                if (a.relu) v[r] = relu(v[r]);
+                if (a.relu == 1 || (a.relu == 2 && nt0 + n < a.relu_nt)) v[r] = relu(v[r]);
             }
             if (co >= a.COUT) continue;
             if (!POOL_OUT) {
                 float* out = a.out + (size_t)b * a.H * a.W * a.ostride + a.ooff;
-                const float* res = a.res ? a.res + (size_t)b * a.H * a.W * a.COUT : nullptr;
+                const int rs = a.rstride ? a.rstride : a.COUT;
+                const float* res = a.res ? a.res + (size_t)b * a.H * a.W * rs : nullptr;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                     if (gy < a.H && gx < a.W) {
                         float o = v[r];
                         if (res) {
-                            o += res[((size_t)gy * a.W + gx) * a.COUT + co];
+                            o += res[((size_t)gy * a.W + gx) * rs + co];
                             o = relu(o);
                         }
                         out[((size_t)gy * a.W + gx) * a.ostride + co] = o;
