@@ -7,11 +7,14 @@ GPU (pair index i goes to rank i mod W); every rank emits one fixed-width fp32 r
 all-gather (RCCL on GPUs, gloo in the CPU tests) moves the rows; rank 0 reduces them exactly as
 on_test_end would.  There is no other communication: weights are replicated and pairs are independent.
 
-Tasks: ``repeatability`` runs entirely on the device (detection, covisibility warp, val_key_points).  The other
-metric functions of tasks/*.py need cv2 (RANSAC) and stay the reference's own code; pass them in through
-``task_fn`` (or let ``install()`` swap this package's kernels under an importable reference checkout so that
-main.py runs unchanged).  ``match_stats`` is a dependency-free task used by bench.py and the tests: it returns
-[n_kps0, n_kps1, n_matches].
+Tasks (`task_type`): ``repeatability``, ``MHA``, ``AUC``, ``FundamentalMatrix``, ``FundamentalMatrixRansac`` and
+``visual_odometer`` run on the device end to end, the robust-geometry stages included (csrc/geometry.hip restates the
+OpenCV calls of the reference's tasks; parity unpinned, see utils/mvg.py); ``match_stats`` is a dependency-free task used
+by bench.py and the tests: it returns [n_kps0, n_kps1, n_matches].  Any other metric function can be passed in through
+``task_fn`` (it then runs pair by pair), and ``install()`` swaps this package's kernels under an importable reference
+checkout so that main.py runs unchanged.  Without a ``task_fn`` pairs are batched through PairPipeline / SequencePipeline
+and the task is evaluated for a whole batch on the device; host-resident dataset items travel through a pinned staging
+ring (HostStager) so that their PCIe copy runs under the previous batch's kernels.
 """
 import os
 

@@ -180,3 +180,21 @@ def test_host_items_are_staged_through_pinned_buffers_and_decoded_uint8_images_e
     single = runner.PairRunner(params("repeatability"), device=DEV, batch=1)
     _, rows1 = single.run(u8)                     # the single-pair path takes decoded images too
     assert np.array_equal(rows1.view(np.uint32), rows["u8"].view(np.uint32))
+
+
+def test_a_failing_dataset_item_surfaces_from_the_staging_thread():
+    """An exception raised while the producer thread reads the dataset reaches the caller (no hang, no lost slot), and the
+    runner works again afterwards."""
+    good = pair_dataset(6)
+
+    class Broken(list):
+        def __getitem__(self, i):
+            if i == 4:
+                raise OSError("unreadable image")
+            return list.__getitem__(self, i)
+
+    r = runner.PairRunner(params("match_stats"), device=DEV, batch=2)
+    with pytest.raises(OSError, match="unreadable image"):
+        r.run(Broken(good))
+    _, rows = r.run(good)
+    assert rows.shape[0] == 6 and r.staged_batches > 0
