@@ -195,7 +195,9 @@ __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
 // 32-wide MFMA tile on it.
 // (Tried, r02: requesting the weight fragments of tap t + 1 before the MFMAs of tap t in a second register set -- 12-15 %
 // slower on every layer; the extra 32-64 VGPRs cost a wave per SIMD and the other waves already cover the L2 latency.
-// The same for the one-tile layer b3c2 alone, where the second set is 16 registers: 0.58 -> 0.71 ms.)
+// The same for the one-tile layer b3c2 alone, where the second set is 16 registers: 0.58 -> 0.71 ms.  Fetching a tap's fragments
+// once per workgroup, a tap ahead, through a double-buffered LDS strip (one barrier per tap, 4-8 registers): +1-3 % -- the
+// weight round trip is not what keeps the matrix pipe at 46 %.)
 // PF: with POOL_IN the input is max-pooled PF x PF (2 or 4) while it is staged (ALike.py:139-143).
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2>
 __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
