@@ -197,7 +197,9 @@ __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
 // slower on every layer; the extra 32-64 VGPRs cost a wave per SIMD and the other waves already cover the L2 latency.
 // The same for the one-tile layer b3c2 alone, where the second set is 16 registers: 0.58 -> 0.71 ms.  Fetching a tap's fragments
 // once per workgroup, a tap ahead, through a double-buffered LDS strip (one barrier per tap, 4-8 registers): +1-3 % -- the
-// weight round trip is not what keeps the matrix pipe at 46 %.)
+// weight round trip is not what keeps the matrix pipe at 46 %.  Nor is the slab staging: a persistent form that fetches the next
+// slab (or the next tile's first slab) into registers before the taps of the current one ran 2 % faster on conv1b at two
+// waves per SIMD and 20 % slower on DISK's up_3 (the 44 registers of the slab in flight cost the third wave).)
 // PF: with POOL_IN the input is max-pooled PF x PF (2 or 4) while it is staged (ALike.py:139-143).
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2>
 __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
