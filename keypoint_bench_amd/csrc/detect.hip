@@ -268,7 +268,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
             t[i] = v;
         }
     }
-    for (int i = tid; i < ROWS * EP; i += NMS_THREADS) e[i] = 0.0f;
+    for (int i = LH * EP + tid; i < ROWS * EP; i += NMS_THREADS) e[i] = 0.0f;      // pad rows only: rows < LH are rewritten by every horizontal pass
     if (tid == 0) { s_n[0] = 0; s_n[1] = 0; s_changed = 0; s_over = 0; }
     __syncthreads();
     if (neg && first) a.negflag[img] = 1;    // only the input map may not be negative; later sweeps use the sign themselves
