@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""How often does the whole GPU path (split-f16 MFMA net -> NMS / top-K -> sampling -> fp64 match) return exactly what the
+fp32 CPU chain (oracle/: torch-fp32 ALIKE-t restatement + C detection / sampling / match) returns on full-size pairs?
+The stages are bit-exact on equal inputs; the net's score map differs from the CPU's by ~1e-6, which can flip an NMS decision
+between near-equal neighbours.  Prints, over `pairs` synthetic 640x480 pairs: max score / descriptor differences, the
+number of images whose keypoint index sets are identical, and the number of pairs whose match sets are identical.
+    python scripts/parity_sweep.py [pairs]        (GPU box; the oracle is the checker, never the product)"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+EP = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
+BF = dict(metric="euclidean", max_distance=5, cross_check=True)
+
+
+def cpu_pair(i):
+    torch.set_num_threads(1)
+    import oracle
+    from oracle import alike_ref
+    from keypoint_bench_amd import synthetic, weights
+    t = {k: torch.from_numpy(v) for k, v in weights.load_alike_t().items()}
+    out = []
+    for v in synthetic.image_pair(i, 480, 640):
+        with torch.no_grad():
+            s, d = alike_ref.alnet_forward(torch.from_numpy(v)[None], t)
+        k, idx = oracle.detection(s[0, 0].numpy(), EP)
+        out.append((s[0, 0].numpy(), k, idx, oracle.sample(d[0].numpy(), k)))
+    pairs, _ = oracle.match(out[0][3], out[1][3], BF["max_distance"], BF["cross_check"])
+    return out, pairs
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    import multiprocessing as mp
+    import oracle
+    oracle.build()
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
+        ref = pool.map(cpu_pair, range(n))
+    print("cpu chain: %.0f s" % (time.time() - t0))
+    from keypoint_bench_amd import synthetic
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.utils.extracter import detection
+    from keypoint_bench_amd.utils.matcher import match_descriptors, sample_descriptors
+    net = alike_t().eval()
+    same_kps = same_matches = same_order = 0
+    diffm = 0
+    ds = dd = 0.0
+    nk = nm = diffk = 0
+    for i in range(n):
+        views = synthetic.image_pair(i, 480, 640)
+        feats, gidx, widx = [], [], []
+        for j, v in enumerate(views):
+            s, d = net(torch.from_numpy(v)[None].cuda())
+            k = detection(s, EP)
+            want_s, want_k, want_idx, want_f = ref[i][0][j]
+            ds = max(ds, float(np.abs(s[0, 0].cpu().numpy() - want_s).max()))
+            got_idx = (np.round(k[:, 1].cpu().numpy() * 480 - 0.5).astype(np.int64) * 640 + np.round(k[:, 0].cpu().numpy() * 640 - 0.5).astype(np.int64))
+            a, b = set(got_idx.tolist()), set(np.asarray(want_idx).tolist())
+            same_kps += a == b
+            diffk += len(a ^ b)
+            nk += len(b)
+            f = sample_descriptors(k, d)
+            if a == b and np.array_equal(got_idx, np.asarray(want_idx)):
+                dd = max(dd, float(np.abs(f.cpu().numpy() - want_f).max()))
+            feats.append(f)
+            gidx.append(got_idx)
+            widx.append(np.asarray(want_idx))
+            same_order += np.array_equal(got_idx, np.asarray(want_idx))
+        pairs = match_descriptors(feats[0], feats[1], max_distance=BF["max_distance"], cross_check=BF["cross_check"]).cpu().numpy()
+        # rows are ordered by score: a 1e-6 score difference may permute near-equal rows, so matches are compared as pixel pairs
+        got_m = set(zip(gidx[0][pairs[:, 0]].tolist(), gidx[1][pairs[:, 1]].tolist()))
+        want_m = set(zip(widx[0][ref[i][1][:, 0]].tolist(), widx[1][ref[i][1][:, 1]].tolist()))
+        same_matches += got_m == want_m
+        diffm += len(got_m ^ want_m)
+        nm += len(ref[i][1])
+    print("pairs %d: max |score diff| %.2e, max |descriptor diff| (identical keypoint lists) %.2e" % (n, ds, dd))
+    print("images with identical keypoint sets: %d / %d (%d of %d keypoints differ), in identical row order: %d; pairs with identical match sets "
+          "(as pixel pairs): %d / %d (%d of %d matches differ)" % (same_kps, 2 * n, diffk // 2, nk, same_order, same_matches, n, diffm // 2, nm))
+
+
+if __name__ == "__main__":
+    main()
