@@ -451,10 +451,9 @@ class PairRunner:
             images[:f].copy_(staged[:f].reshape(f, 3, H, W))
             images[B:B + f].copy_(staged[f:].reshape(f, 3, H, W))
             self.staged_batches += 1
-        else:
-            for j, (_, _, a, b) in enumerate(group):
-                images[j].copy_(a.reshape(3, H, W), non_blocking=True)
-                images[B + j].copy_(b.reshape(3, H, W), non_blocking=True)
+        else:               # device-resident items: ONE gather kernel per view instead of 2 f copy launches
+            torch.stack([g[2].reshape(3, H, W) for g in group], out=images[:f])
+            torch.stack([g[3].reshape(3, H, W) for g in group], out=images[B:B + f])
         for j in range(f, B):                               # pad with the last pair; its rows are dropped
             images[j].copy_(images[f - 1])
             images[B + j].copy_(images[B + f - 1])
