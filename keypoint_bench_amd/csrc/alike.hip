@@ -694,8 +694,11 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         // all rows go to two extra groups: slot k of extra group e is position ((16 e + k) / 2, 32 + (k & 1))
         const float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + 4 * g);
         uint2* midh = reinterpret_cast<uint2*>(mid);
-#pragma unroll 1
-        for (int gi = wv; gi < 2 * MH + 2; gi += 4) {
+        // fixed trip count (the last round is empty for waves 2 and 3) so that two groups can be in flight per wave
+#pragma unroll 2
+        for (int it = 0; it < (2 * MH + 2 + 3) / 4; ++it) {
+            const int gi = wv + 4 * it;
+            if (gi >= 2 * MH + 2) break;
             const bool extra = gi >= 2 * MH;
             const int k = extra ? 16 * (gi - 2 * MH) + px : 0;
             const int y = extra ? k >> 1 : gi >> 1, x = extra ? 32 + (k & 1) : 16 * (gi & 1) + px;
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     float* S2 = a.S2 + (size_t)b * P;
     uint2* xh = reinterpret_cast<uint2*>(&xs[wv][0][0][0]);
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);        // x2 >= 0 (ReLU): zero is the neutral element of the pool
-#pragma unroll 1
+#pragma unroll 2
     for (int k4 = 0; k4 < 4; ++k4) {
         const int row = 4 * (wv >> 1) + k4, col0 = (wv & 1) * 16;
         const int mbase = row * MW + col0 + px;
