@@ -48,7 +48,7 @@ def mfma_peak(kernel):
         return PEAK_SPLIT_TFLOPS
     if kernel.startswith("match_approx"):
         return PEAK_SPLIT_TFLOPS
-    if kernel in ("conv3x3_b3c2", "conv3x3_b4c2") or kernel.startswith(("sp_conv", "xf_", "disk_", "lg_")):
+    if kernel in ("conv3x3_b3c1", "conv3x3_b3c2", "conv3x3_b4c1", "conv3x3_b4c2") or kernel.startswith(("sp_conv", "xf_", "disk_", "lg_")):
         return PEAK_SPLIT_TFLOPS if env("KPB_CONVM_H16", "1") != "0" else PEAK_F32_TFLOPS
     return PEAK_F32_TFLOPS
 
