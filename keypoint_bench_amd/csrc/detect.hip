@@ -693,20 +693,28 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
     int n = 0;
     constexpr int VPT = 16;
     const bool vec = ((P & 3) == 0) && ((reinterpret_cast<uintptr_t>(map) & 15) == 0);
-    for (int c0 = 0; c0 < P; c0 += SEL_THREADS * VPT) {
+    float vn[VPT];                  // the next round's pixels are requested before this round's block scan (one load latency hidden per round)
+    auto fetch = [&](int c0) {
         const int i0 = c0 + tid * VPT;
-        float v[VPT];
 #pragma unroll
         for (int q = 0; q < VPT / 4; ++q) {
             const int iq = i0 + 4 * q;
             if (vec && iq + 3 < P) {
                 const float4 f = *reinterpret_cast<const float4*>(map + iq);
-                v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+                vn[4 * q] = f.x; vn[4 * q + 1] = f.y; vn[4 * q + 2] = f.z; vn[4 * q + 3] = f.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[4 * q + j] = (iq + j < P) ? map[iq + j] : 0.0f;
+                for (int j = 0; j < 4; ++j) vn[4 * q + j] = (iq + j < P) ? map[iq + j] : 0.0f;
             }
         }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < P; c0 += SEL_THREADS * VPT) {
+        const int i0 = c0 + tid * VPT;
+        float v[VPT];
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) v[j] = vn[j];
+        if (c0 + SEL_THREADS * VPT < P) fetch(c0 + SEL_THREADS * VPT);
         if (a.signed_map) {     // confirmed maxima are stored negated; at the fixed point nothing else is alive, and pixels the
                                 // top-K pruning of nms_tail left unresolved (positive) are by construction not among the top_k
 #pragma unroll
