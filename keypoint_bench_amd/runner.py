@@ -435,9 +435,12 @@ class PairRunner:
                                 torch.empty((2 * B, 3, H, W), dtype=torch.float32, device=self.device))
         return self._pipes[key]
 
-    def _flush(self, group, task_type, staged=None):
+    def _flush(self, group, task_type, staged=None, between=None):
         """group: list of (index, item, img0, img1) with equal cropped shapes.  staged: device tensor [2f, ...] holding the
-        group's images -- views 0 first, then views 1 -- when the HostStager path has brought them over."""
+        group's images -- views 0 first, then views 1 -- when the HostStager path has brought them over.  between: called after
+        the batch's kernels are enqueued and before the host waits for them (the previous batch's host-side row arithmetic
+        runs there, under this batch's kernels).  Returns the rows, or a zero-argument callable that computes them from host
+        copies of the device results (tasks with a host half: MHA corner errors, AUC pose angles)."""
         fn, match, covis = BATCHED_TASKS[task_type]
         f = len(group)
         u8 = is_decoded_u8(group[0][2])
@@ -458,7 +461,10 @@ class PairRunner:
             images[j].copy_(images[f - 1])
             images[B + j].copy_(images[B + f - 1])
         items = [g[1] for g in group]
-        pipe.run(images, _covis_tables(items, B, self.device) if covis else None)
+        pipe.enqueue(images, _covis_tables(items, B, self.device) if covis else None)
+        if between is not None:
+            between()
+        pipe.finish()
         rows = fn(pipe, items, self.params, [g[0] for g in group])
         self.batched_pairs += f
         return rows
@@ -473,12 +479,23 @@ class PairRunner:
         if host:
             return self._run_pairs_staged(dataset, indices, task_type)
         group, shape = [], None
+        late = []               # [(group, callable)]: rows whose host half is still to run (under the next batch's kernels)
+
+        def settle():
+            while late:
+                g, fn_rows = late.pop(0)
+                for (i, _, _, _), r in zip(g, fn_rows()):
+                    out[i] = r
 
         def flush():
             nonlocal group
             if group:
-                for (i, _, _, _), r in zip(group, self._flush(group, task_type)):
-                    out[i] = r
+                res = self._flush(group, task_type, between=settle)
+                if callable(res):
+                    late.append((group, res))
+                else:
+                    for (i, _, _, _), r in zip(group, res):
+                        out[i] = r
             group = []
 
         for i in indices:
@@ -499,6 +516,7 @@ class PairRunner:
             if len(group) == self.batch:
                 flush()
         flush()
+        settle()
         return [out[i] for i in indices]
 
     def _run_pairs_staged(self, dataset, indices, task_type):
@@ -569,13 +587,24 @@ class PairRunner:
             dev.record_stream(main)
             return group, dev, ev
 
+        late = []
+
+        def settle():
+            while late:
+                g, fn_rows = late.pop(0)
+                for (i, _, _, _), r in zip(g, fn_rows()):
+                    out[i] = r
+
         def finish(p):
             group, dev, ev = p
             ev.synchronize()        # the copy has left the pinned slot: the producer may refill it
             st.release()
-            rows = self._flush(group, task_type, staged=dev)
-            for (i, _, _, _), r in zip(group, rows):
-                out[i] = r
+            res = self._flush(group, task_type, staged=dev, between=settle)
+            if callable(res):
+                late.append((group, res))
+            else:
+                for (i, _, _, _), r in zip(group, res):
+                    out[i] = r
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
@@ -592,6 +621,7 @@ class PairRunner:
                     break
                 if kind == "single":
                     out[x] = self.test_step(y, x)
+            settle()
         finally:
             if pending is not None:             # only on an error path: give the slot back
                 st.release()

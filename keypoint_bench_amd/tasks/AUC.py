@@ -70,8 +70,11 @@ def auc_batch(pipe, items, params, indices=None):
     seeds = list(indices if indices is not None else range(f)) + [0] * (B - f)
     rt, mask, good, _ = estimate_pose(pipe.m0, pipe.m1, [pipe.W - 1, pipe.H - 1, pipe.W - 1, pipe.H - 1], K0, K1, thresh=1., k_dev=pipe.k, seeds=seeds)
     rt, mask, good = rt.cpu().numpy(), mask.cpu().numpy(), good.cpu().numpy()
-    rows = []
-    for b in range(f):
-        r = _row(rt[b], good[b], mask[b], items[b]["warp01_params"])
-        rows.append([float(r["AUC"]), float(r["inliers"])])
+
+    def rows():                 # the host half (135-154), on host copies: the runner runs it under the next batch's kernels
+        out = []
+        for b in range(f):
+            r = _row(rt[b], good[b], mask[b], items[b]["warp01_params"])
+            out.append([float(r["AUC"]), float(r["inliers"])])
+        return out
     return rows

@@ -58,7 +58,7 @@ def mha(idx, img_0, score_map_0, desc_map_0, img_1, score_map_1, desc_map_1, war
 
 def mha_batch(pipe, items, params, indices=None):
     """`mha` for the pairs a PairPipeline run with the covisibility stage has just processed (pipe.matched(), pipe.k):
-    one RANSAC launch for the batch, one read-back of the homographies."""
+    one RANSAC launch for the batch, one read-back of the homographies.  Returns a callable that computes the rows."""
     th = params["MHA_params"]["th"]
     f, B = len(items), pipe.B
     hw = [_hw(it["warp01_params"]) for it in items]
@@ -67,12 +67,16 @@ def mha_batch(pipe, items, params, indices=None):
     m0, m1 = pipe.matched()
     H, _, info = find_homography(m0, m1, scale, k_dev=pipe.k, seeds=seeds)
     H, info = H.cpu().numpy(), info.cpu().numpy()
-    rows = []
-    for b in range(f):
-        if info[b, 0] == 0:
-            rows.append([0.0 for _ in th])
-            continue
-        h, w = hw[b]
-        hits, _ = corner_hits(H[b], _real_h(items[b]["warp01_params"]), h, w, pipe.H, pipe.W, th)
-        rows.append(hits)
+    Hp, Wp = pipe.H, pipe.W
+
+    def rows():                 # the host half (50-70), on host copies: the runner runs it under the next batch's kernels
+        out = []
+        for b in range(f):
+            if info[b, 0] == 0:
+                out.append([0.0 for _ in th])
+                continue
+            h, w = hw[b]
+            hits, _ = corner_hits(H[b], _real_h(items[b]["warp01_params"]), h, w, Hp, Wp, th)
+            out.append(hits)
+        return out
     return rows
