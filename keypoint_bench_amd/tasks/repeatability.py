@@ -71,8 +71,12 @@ def repeatability(idx, img_0, score_map_0, img_1, score_map_1, warp01, warp10, p
 
 def homography_tables(warps, dev):
     """Stacks the 'homo' warp dicts of B pairs: (hmat [B, 9] fp32, wh [B, 2] int32 = width, height, scale [B])."""
-    hm = torch.stack([torch.as_tensor(w["homography_matrix"], dtype=torch.float32).reshape(9).cpu() for w in warps]).to(dev)
-    wh = torch.tensor([[_scalar(w["width"]), _scalar(w["height"])] for w in warps], dtype=torch.int32).to(dev)
+    import numpy as np
+
+    def mat(v):     # numpy items stay in numpy (one host array, one upload per table instead of a tensor per pair)
+        return (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)).astype(np.float32, copy=False).reshape(9)
+    hm = torch.from_numpy(np.stack([mat(w["homography_matrix"]) for w in warps])).to(dev)
+    wh = torch.from_numpy(np.array([[_scalar(w["width"]), _scalar(w["height"])] for w in warps], np.int32)).to(dev)
     return hm.contiguous(), wh.contiguous(), [_scale(w) for w in warps]
 
 

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--pairs", type=int, default=256)
+    ap.add_argument("--pairs", type=int, default=1024, help="pairs per run (four batches by default: the host halves of a batch run under the next batch)")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--distinct", type=int, default=32)
     ap.add_argument("--repeat", type=int, default=3)
