@@ -435,12 +435,10 @@ class PairRunner:
                                 torch.empty((2 * B, 3, H, W), dtype=torch.float32, device=self.device))
         return self._pipes[key]
 
-    def _flush(self, group, task_type, staged=None, between=None):
-        """group: list of (index, item, img0, img1) with equal cropped shapes.  staged: device tensor [2f, ...] holding the
-        group's images -- views 0 first, then views 1 -- when the HostStager path has brought them over.  between: called after
-        the batch's kernels are enqueued and before the host waits for them (the previous batch's host-side row arithmetic
-        runs there, under this batch's kernels).  Returns the rows, or a zero-argument callable that computes them from host
-        copies of the device results (tasks with a host half: MHA corner errors, AUC pose angles)."""
+    def _begin(self, group, task_type, staged=None):
+        """Enqueues one batch (image gather, net, detection, [covisibility], descriptors, match) and returns without waiting.
+        group: list of (index, item, img0, img1) with equal cropped shapes.  staged: device tensor [2f, ...] holding the group's
+        images -- views 0 first, then views 1 -- when the HostStager path has brought them over."""
         fn, match, covis = BATCHED_TASKS[task_type]
         f = len(group)
         u8 = is_decoded_u8(group[0][2])
@@ -462,12 +460,24 @@ class PairRunner:
             images[B + j].copy_(images[B + f - 1])
         items = [g[1] for g in group]
         pipe.enqueue(images, _covis_tables(items, B, self.device) if covis else None)
+        return fn, pipe, items, [g[0] for g in group]
+
+    def _end(self, token):
+        """Waits for the batch `_begin` enqueued (NMS convergence check) and evaluates the task on it.  Returns the rows, or a
+        zero-argument callable that computes them from host copies of the device results (tasks with a host half: MHA corner
+        errors, AUC pose angles)."""
+        fn, pipe, items, idxs = token
+        pipe.finish()
+        rows = fn(pipe, items, self.params, idxs)
+        self.batched_pairs += len(items)
+        return rows
+
+    def _flush(self, group, task_type, staged=None, between=None):
+        """`_begin`, then `between()` (the previous batch's host-side row arithmetic, under this batch's kernels), then `_end`."""
+        token = self._begin(group, task_type, staged)
         if between is not None:
             between()
-        pipe.finish()
-        rows = fn(pipe, items, self.params, [g[0] for g in group])
-        self.batched_pairs += f
-        return rows
+        return self._end(token)
 
     def _run_pairs(self, dataset, indices, task_type):
         batched = (not self.user_task) and task_type in BATCHED_TASKS and self.batch > 1 and hasattr(self.model, "_handle")
@@ -480,6 +490,7 @@ class PairRunner:
             return self._run_pairs_staged(dataset, indices, task_type)
         group, shape = [], None
         late = []               # [(group, callable)]: rows whose host half is still to run (under the next batch's kernels)
+        inflight = None         # (group, token): a batch whose kernels are running while the next group is being collected
 
         def settle():
             while late:
@@ -487,27 +498,40 @@ class PairRunner:
                 for (i, _, _, _), r in zip(g, fn_rows()):
                     out[i] = r
 
-        def flush():
-            nonlocal group
-            if group:
-                res = self._flush(group, task_type, between=settle)
+        def land():
+            nonlocal inflight
+            if inflight is not None:
+                g, token = inflight
+                inflight = None
+                res = self._end(token)
                 if callable(res):
-                    late.append((group, res))
+                    late.append((g, res))
                 else:
-                    for (i, _, _, _), r in zip(group, res):
+                    for (i, _, _, _), r in zip(g, res):
                         out[i] = r
+
+        def flush():
+            nonlocal group, inflight
+            if group:
+                land()                                              # the pipeline's buffers are free again
+                inflight = (group, self._begin(group, task_type))
+                settle()                                            # host halves of the batch before, under this batch's kernels
             group = []
+
+        def single(item, i):        # the drop-in path shares the context (one detection in flight at a time): land first
+            flush()
+            land()
+            settle()
+            out[i] = self.test_step(item, i)
 
         for i in indices:
             item = dataset[i]
             if not batched or (task_type not in ("AUC", "FundamentalMatrixRansac") and not _homo_only(item)):
-                flush()
-                out[i] = self.test_step(item, i)
+                single(item, i)
                 continue
             a, b = crop32(as_image(item["image0"], self.device)), crop32(as_image(item["image1"], self.device))
             if a.shape[-2:] != b.shape[-2:]:                # the two views differ in size: single-pair path
-                flush()
-                out[i] = self.test_step(item, i)
+                single(item, i)
                 continue
             if shape is not None and a.shape[-2:] != shape:
                 flush()
@@ -516,6 +540,7 @@ class PairRunner:
             if len(group) == self.batch:
                 flush()
         flush()
+        land()
         settle()
         return [out[i] for i in indices]
 
