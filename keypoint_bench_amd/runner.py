@@ -693,12 +693,26 @@ class PairRunner:
             chunk = indices[c0:c0 + F]
             f = len(chunk)
             fm, items = [], []
-            for j, i in enumerate(chunk):
+            for i in chunk:
                 item = dataset[i]
-                images[j].copy_(as_image(item["image0"], self.device).reshape(3, H, W), non_blocking=True)
                 items.append(item)
                 if not vo:
                     fm.append(torch.as_tensor(item["fundamental"], dtype=torch.float32).reshape(9))
+            frames = [it["image0"] for it in items]
+            host = [_host_array(v) for v in frames]
+            if all(h is not None and h.dtype == np.float32 for h in host):      # host frames: one pinned gather, one PCIe copy
+                if self._stager is None:
+                    self._stager = HostStager()
+                _, pinned = self._stager.acquire((f, 3, H, W), torch.float32)
+                self._stager.fill(pinned, host)
+                images[:f].copy_(pinned, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+                self._stager.release()
+            elif all(torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32 for v in frames):    # device frames: one gather kernel
+                torch.stack([v.reshape(3, H, W) for v in frames], out=images[:f])
+            else:
+                for j, v in enumerate(frames):
+                    images[j].copy_(as_image(v, self.device).reshape(3, H, W), non_blocking=True)
             pipe.run(images[:f], first=(chunk[0] == 0))
             if vo:
                 from .tasks.visual_odometer import relative_motion_batch

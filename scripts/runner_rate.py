@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--u8", action="store_true", help="with --host: items are decoded uint8 [H,W,3] images (a quarter of the PCIe bytes)")
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--tasks", nargs="+", default=["match_stats", "repeatability", "MHA", "AUC"])
+    ap.add_argument("--sequence", action="store_true", help="a sequence dataset instead (frames sliding over one canvas): FundamentalMatrix and visual_odometer tasks")
+    ap.add_argument("--model", default="Alike", choices=["Alike", "XFeat"])
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -47,14 +49,31 @@ def main():
         ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
                    "warp01_params": dict(mode="homo", homography_matrix=h01, width=W, height=H, intrinsics0=K, intrinsics1=K, pose01=T01),
                    "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(h01).astype(np.float32), width=W, height=H)})
+    if args.sequence:
+        canvas, _ = synthetic.image_pair(4242, H + 64, W + 64)
+        rng = np.random.default_rng(3)
+        ds = []
+        for i in range(args.pairs):
+            dy, dx = (i * 3) % 64, (i * 5) % 64
+            fr = np.ascontiguousarray(canvas[:, dy:dy + H, dx:dx + W])
+            ds.append({"image0": fr if args.host else torch.from_numpy(fr).to(dev), "dataset": "TartanAir",
+                       "fundamental": rng.normal(size=(3, 3)).astype(np.float32), "fx": 500.0, "fy": 500.0, "cx": 319.5, "cy": 239.5,
+                       "ground_truth": np.array([0.05 * i, 0, 0, 0, 0, 0, 1], np.float32),
+                       "last_ground_truth": np.array([0.05 * max(i - 1, 0), 0, 0, 0, 0, 0, 1], np.float32)})
+        if args.tasks == ["match_stats", "repeatability", "MHA", "AUC"]:
+            args.tasks = ["FundamentalMatrix", "visual_odometer"]
     out = {"pairs": args.pairs, "batch": args.batch, "items": ("host uint8 HWC" if args.u8 else "host numpy fp32 CHW") if args.host else "device tensors",
            "descriptors": "dense-map" if args.dense else "keypoint-only"}
     for task in args.tasks:
-        params = {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),
+        params = {"model_type": args.model, "task_type": task, "XFeat_params": {}, "FundamentalMatrix_params": {"th": 3.0}, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),
                   "extractor_params": dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0),
                   "matcher_params": {"type": "brute_force", "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
                   "repeatability_params": {"th": 3}, "MHA_params": {"th": [3, 5, 7]}, "AUC_params": {"th": [5, 10, 20]}}
-        r = runner.PairRunner(params, device=dev, batch=args.batch, dense_descriptors=args.dense)
+        model = None
+        if args.model == "XFeat":       # its checkpoint is not in the reference tree: seeded stand-in weights, as in bench.py
+            from keypoint_bench_amd.models.XFeat import xfeat_random
+            model = xfeat_random(9).eval()
+        r = runner.PairRunner(params, model=model, device=dev, batch=args.batch, dense_descriptors=args.dense)
         try:
             agg, _ = r.run(ds)            # warm-up: allocations, first-shape workspaces
         except (ImportError, NotImplementedError) as e:
@@ -68,7 +87,7 @@ def main():
             torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
         out[task] = {"pairs_per_s": round(args.pairs / best, 1), "ms_per_pair": round(1e3 * best / args.pairs, 4), "batched_pairs": r.batched_pairs,
-                     "aggregate": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in agg.items()}}
+                     "aggregate": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in agg.items() if not hasattr(v, "shape")}}
         del r
         torch.cuda.empty_cache()
     print(json.dumps(out))
