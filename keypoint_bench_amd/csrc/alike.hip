@@ -1644,7 +1644,9 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         c2.istride = 2 * cout; c2.ostride = cout; c2.ooff = 0;
         c2.unscale = 1.0f / (ACT_SCALE * wscale.at(k2));
         const dim3 g2(cdiv(c2.W, 16), cdiv(c2.H, 16), batch);
-        if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), g2, dim3(256), 0, st, c2);
+        static const int mt1 = kpb_env_int("KPB_B3C2_MT1", 1);      // a one-tile layer: 8-row tiles, five workgroups per CU (0.58 -> 0.49 ms)
+        if (cout == 32 && mt1) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch), dim3(256), 0, st, c2);
+        else if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), g2, dim3(256), 0, st, c2);
         else KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, dim3(256), 0, st, c2);
     };
     if (b34h && conv_mfma_use_h16()) {
