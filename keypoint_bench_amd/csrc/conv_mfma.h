@@ -392,10 +392,10 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 // of slab c) and go into the OTHER of two LDS buffers behind them, so there is one barrier per slab and the loads fly
 // under the matrix work.  Workgroup = 256 rows x 32 NTB columns; wave = 64 rows (two M tiles); weights in pack_mfma_h's
 // KS = 1 order; LDS rows as in conv_mfma_h (hi | lo | pad, 144 bytes: nine 16-byte slots, conflict-free).
-template <int NTB>
+template <int NTB, int MT = 2>
 __global__ __launch_bounds__(256) void gemm_h(ConvM a)
 {
-    constexpr int CC = 32, KC = 16, NKB = 2, Q = CC / 4, PITCH = 4 * CC + 16, LO = 2 * CC, ROWS = 256, BUF = ROWS * PITCH, NLD = ROWS * Q / 256;
+    constexpr int CC = 32, KC = 16, NKB = 2, Q = CC / 4, PITCH = 4 * CC + 16, LO = 2 * CC, ROWS = 128 * MT, BUF = ROWS * PITCH, NLD = ROWS * Q / 256;
     __shared__ __attribute__((aligned(256))) unsigned char tile[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
@@ -405,9 +405,9 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)a.NCH * NKB * 4 * 32;
 
-    f32x16 acc[2][NTB];
+    f32x16 acc[MT][NTB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTB; ++n)
 #pragma unroll
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
         const bool more = ch + 1 < a.NCH;
         if (more) fetch(ch + 1);
         const uint4* bp = wq + (((size_t)nt0 * a.NCH + ch) * NKB * 4 + h) * 32 + p;
-        cm_h8 Bh[NTB][NKB], Bl[NTB][NKB], Ah[2][NKB], Al[2][NKB];
+        cm_h8 Bh[NTB][NKB], Bl[NTB][NKB], Ah[MT][NKB], Al[MT][NKB];
 #pragma unroll
         for (int n = 0; n < NTB; ++n)
 #pragma unroll
@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
             }
         const unsigned char* t = tile + (ch & 1) * BUF;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const unsigned char* ap = t + (64 * wv + 32 * m + p) * PITCH + h * KC * 2;
+        for (int m = 0; m < MT; ++m) {
+            const unsigned char* ap = t + (32 * MT * wv + 32 * m + p) * PITCH + h * KC * 2;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NTB; ++n) {
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
 
     float* out = a.out + (size_t)b * nrows * a.ostride + a.ooff;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
             const int co = (nt0 + n) * 32 + p;
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
             if (co >= a.COUT) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = r0 + 64 * wv + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = r0 + 32 * MT * wv + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = fmaf(acc[m][n][r], a.unscale, bias);
                 if (a.relu) v = relu(v);
                 if (row < nrows) out[(size_t)row * a.ostride + co] = v;

@@ -345,7 +345,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x && mt1 >= 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 1>), g1, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2>), dim3(cdiv(a.H * a.W, 256), 1, B * a.nblk), block, 0, st, a);
+        else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2, 1>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 2, 2>), g2, block, 0, st, a);
