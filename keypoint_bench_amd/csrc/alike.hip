@@ -1634,7 +1634,9 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         m.unscale = 1.0f / (ACT_SCALE * wscale.at(k1));
         const dim3 grid(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk);
         const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
-        if (cin == 16 && prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 2>), grid, dim3(256), 0, st, m);
+        static const int c1mt1 = kpb_env_int("KPB_B3C1_MT1", 1);      // a small layer: 8-row tiles (0.36 -> 0.32 ms)
+        if (cin == 16 && prepooled && c1mt1) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+        else if (cin == 16 && prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 2>), grid, dim3(256), 0, st, m);
         else if (cin == 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, true, false, false, 2, 2, false, 4>), grid, dim3(256), 0, st, m);
         else KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 2, 2, false, 4>), grid, dim3(256), 0, st, m);
         ConvM c2;
