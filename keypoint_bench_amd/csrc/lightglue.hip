@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void lg_flash(FlashArgs a)
 //      key(kb, h, j) = 32 blk + 16 kb + 8 (j >> 2) + 4 h + (j & 3): exactly the keys whose probabilities registers
 //      8 kb .. 8 kb + 7 of the S^T accumulator hold in lane half h, so P needs no shuffle to become the A operand.
 // Keys past the sequence's count are written as zeros (P is zero there too; garbage times zero could be NaN).
-// (Two query tiles per wave, to load each K / V fragment once for 64 queries, need 357 registers: one wave per SIMD, 20 % slower.)
+// (Two query tiles per wave, to load each K / V fragment once for 64 queries, need 357 registers: one wave per SIMD, 20 % slower.
+// Fetching a key block's fragments once per workgroup through a double-buffered LDS strip, a barrier per block: 13 % slower --
+// the L1 is not the bound; the chain S -> softmax -> P -> P V inside a wave is.)
 __device__ __forceinline__ void cm_split8(const float* f, cm_h8& hi, cm_h8& lo)
 {
     uint2 h0, l0, h1, l1;
