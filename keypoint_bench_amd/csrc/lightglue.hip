@@ -351,10 +351,12 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        if (__ballot(alpha != 1.0f)) {      // once the running maxima have settled every alpha is exactly 1: skip the 16 lane exchanges
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
-            O0[r] *= ar; O1[r] *= ar;
+            for (int r = 0; r < 16; ++r) {
+                const float ar = __shfl(alpha, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+                O0[r] *= ar; O1[r] *= ar;
+            }
         }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {       // registers 8 kb .. 8 kb + 7 are this lane half's keys of k-block kb
