@@ -215,7 +215,7 @@ int kpb_find_homography(kpb_ctx* ctx, const float* m0_dev, int cols0, const floa
  * (w-1, h-1) and side 1 with image 1's).  cam_dev [batch][8] float64 = (cx0, cy0, fx0, fy0, cx1, cy1, fx1, fy1): pixels are
  * normalised as (p - c) / f (AUC.py:47-48) -- in float32 when cam_f32 != 0 (the datasets hand float32 intrinsics over and
  * numpy then stays in float32), in float64 otherwise; thr_dev [batch] float64 = thresh / f_mean (AUC.py:44-45).
- * max_k <= 1024.  out_e_dev [batch][9] float64 (Frobenius norm 1; zeros when nothing was found), out_mask_dev [batch][max_k]
+ * max_k <= 4096 (the matches stay in LDS: 32 bytes each; config/config_vo.yaml asks top_k 2000).  out_e_dev [batch][9] float64 (Frobenius norm 1; zeros when nothing was found), out_mask_dev [batch][max_k]
  * inliers of that model, out_info_dev [batch][4] = (found, inliers, hypotheses evaluated, 0), out_pts_dev [batch][max_k][4]
  * float64 = the normalised coordinates (u0, v0, u1, v1), input of kpb_recover_pose. */
 int kpb_find_essential(kpb_ctx* ctx, const float* m0_dev, int cols0, const float* m1_dev, int cols1, int batch, int max_k,

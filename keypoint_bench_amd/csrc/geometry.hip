@@ -916,30 +916,29 @@ __global__ __launch_bounds__(RS_THREADS) void recover_pose(PoseArgs a)
     // depth signs for the four combinations (R1, t), (R2, t), (R1, -t), (R2, -t): z1 R x1 + t = z2 x2 in least squares
     const double* P = a.pts + (size_t)b * a.max_k * 4;
     double cnt[4] = {0, 0, 0, 0};
-    unsigned flags_local[4] = {0, 0, 0, 0};       // up to 4 points per thread (max_k <= 1024): bit c of entry j
-    int j = 0;
-    for (int i = tid; i < n; i += RS_THREADS, ++j) {
-        if (!min_[i]) continue;
+    // combination c of point i: both depths positive and below `dist`
+    auto in_front = [&](int i, int c) {
         const double u1 = P[4 * i], v1 = P[4 * i + 1], u2 = P[4 * i + 2], v2 = P[4 * i + 3];
-        for (int c = 0; c < 4; ++c) {
-            const double* R = Rs[c & 1];
-            const double sg = c < 2 ? 1.0 : -1.0;
-            const double ax = R[0] * u1 + R[1] * v1 + R[2], ay = R[3] * u1 + R[4] * v1 + R[5], az = R[6] * u1 + R[7] * v1 + R[8];
-            const double tx = sg * ts[0], ty = sg * ts[1], tz = sg * ts[2];
-            const double aa = ax * ax + ay * ay + az * az, ab = -(ax * u2 + ay * v2 + az), bb = u2 * u2 + v2 * v2 + 1.0;
-            const double ra = -(ax * tx + ay * ty + az * tz), rb = u2 * tx + v2 * ty + tz;
-            double det = aa * bb - ab * ab;
-            if (!(fabs(det) > 1e-300)) det = 1e-300;
-            const double z1 = (ra * bb - ab * rb) / det, z2 = (aa * rb - ab * ra) / det;
-            const bool good = z1 > 0 && z1 < a.dist && z2 > 0 && z2 < a.dist;
-            if (good) { cnt[c] += 1.0; if (j < 4) flags_local[j] |= 1u << c; }
-        }
+        const double* R = Rs[c & 1];
+        const double sg = c < 2 ? 1.0 : -1.0;
+        const double ax = R[0] * u1 + R[1] * v1 + R[2], ay = R[3] * u1 + R[4] * v1 + R[5], az = R[6] * u1 + R[7] * v1 + R[8];
+        const double tx = sg * ts[0], ty = sg * ts[1], tz = sg * ts[2];
+        const double aa = ax * ax + ay * ay + az * az, ab = -(ax * u2 + ay * v2 + az), bb = u2 * u2 + v2 * v2 + 1.0;
+        const double ra = -(ax * tx + ay * ty + az * tz), rb = u2 * tx + v2 * ty + tz;
+        double det = aa * bb - ab * ab;
+        if (!(fabs(det) > 1e-300)) det = 1e-300;
+        const double z1 = (ra * bb - ab * rb) / det, z2 = (aa * rb - ab * ra) / det;
+        return z1 > 0 && z1 < a.dist && z2 > 0 && z2 < a.dist;
+    };
+    for (int i = tid; i < n; i += RS_THREADS) {
+        if (!min_[i]) continue;
+        for (int c = 0; c < 4; ++c) cnt[c] += in_front(i, c) ? 1.0 : 0.0;
     }
     block_sum_n<4>(cnt, scratch);
     int bestc = 0;
     for (int c = 1; c < 4; ++c) if (cnt[c] > cnt[bestc]) bestc = c;       // ties keep the earlier combination
-    j = 0;
-    for (int i = tid; i < n; i += RS_THREADS, ++j) if (j < 4 && (flags_local[j] >> bestc) & 1u) mout[i] = 1;
+    // the winning combination's mask: the same arithmetic again (any number of points per thread, nothing kept in between)
+    for (int i = tid; i < n; i += RS_THREADS) if (min_[i] && in_front(i, bestc)) mout[i] = 1;
     if (tid < 9) a.Rt[12 * b + tid] = Rs[bestc & 1][tid];
     if (tid < 3) a.Rt[12 * b + 9 + tid] = (bestc < 2 ? 1.0 : -1.0) * ts[tid];
     if (tid == 0) a.good[b] = (int)cnt[bestc];
@@ -1155,11 +1154,20 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_essential(
     if (batch <= 0 || max_k < 0 || cols0 < 2 || cols1 < 2 || !scale_dev || !cam_dev || !thr_dev || !out_e_dev || !out_info_dev ||
         (max_k && (!m0_dev || !m1_dev || !out_mask_dev || !out_pts_dev)) || max_iters < 1)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: bad argument");
-    if (max_k > 1024) return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: at most 1024 matches per pair");
+    const size_t lds = (size_t)max_k * 4 * sizeof(double);
+    if (lds > 128 * 1024)      // the matches live in LDS for the whole search (config_vo.yaml's top_k 2000 needs 64 KB)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: at most 4096 matches per pair (got %d)", max_k);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
+    if (lds > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_essential), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            raised = true;
+        }
+    }
     EssArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, cam_dev, cam_f32, thr_dev, seed_dev, seed, prob, max_iters, out_e_dev, out_mask_dev,
               out_info_dev, out_pts_dev};
-    KPB_LAUNCH(ctx, "ransac_essential", ransac_essential, dim3(batch), dim3(RS_THREADS), (size_t)max_k * 4 * sizeof(double), ctx->stream, a);
+    KPB_LAUNCH(ctx, "ransac_essential", ransac_essential, dim3(batch), dim3(RS_THREADS), lds, ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
@@ -1169,7 +1177,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_recover_pose(
     const int32_t* info_dev, double dist, double* out_rt_dev, uint8_t* out_mask_dev, int32_t* out_good_dev)
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_recover_pose: null context");
-    if (batch <= 0 || max_k < 0 || max_k > 1024 || !e_dev || !info_dev || !out_rt_dev || !out_good_dev || (max_k && (!pts_dev || !mask_dev || !out_mask_dev)))
+    if (batch <= 0 || max_k < 0 || !e_dev || !info_dev || !out_rt_dev || !out_good_dev || (max_k && (!pts_dev || !mask_dev || !out_mask_dev)))
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_recover_pose: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     PoseArgs a{e_dev, pts_dev, mask_dev, max_k, k_dev, info_dev, dist, out_rt_dev, out_mask_dev, out_good_dev};

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-ROW_WIDTH = 16  # floats per pair row: [valid, v0 .. v14] (the widest row: visual_odometer's R, t, step length = 13)
+ROW_WIDTH = 16  # float64 values per pair row: [valid, v0 .. v14] (the widest row: visual_odometer's R, t, step length = 13)
 
 
 # ------------------------------------------------------------------------------------------ config
@@ -87,10 +87,12 @@ def rows_per_rank(n_items, world):
 
 def pack_rows(values, n_items, rank, world):
     """values: list of per-pair value lists (<= ROW_WIDTH-1 floats each), in shard order.
-    Returns a [rows_per_rank, ROW_WIDTH] float32 array, padded rows have valid = 0."""
-    out = np.zeros((rows_per_rank(n_items, world), ROW_WIDTH), np.float32)
+    Returns a [rows_per_rank, ROW_WIDTH] float64 array, padded rows have valid = 0.  Rows stay float64 end to end: the
+    reference keeps its per-pair results (pose errors, the visual-odometry R / t it chains over thousands of frames) in
+    float64, and 128 bytes per pair is nothing to the one all-gather."""
+    out = np.zeros((rows_per_rank(n_items, world), ROW_WIDTH), np.float64)
     for j, v in enumerate(values):
-        v = np.asarray(v, np.float32).ravel()
+        v = np.asarray(v, np.float64).ravel()
         assert v.size <= ROW_WIDTH - 1
         out[j, 0] = 1.0
         out[j, 1:1 + v.size] = v
@@ -101,17 +103,17 @@ def gather_rows(local_rows, n_items, device=None, shard=shard_indices):
     """One all-gather of the fixed-width rows; returns [n_items, ROW_WIDTH-1] in item order on every rank.
     `shard` is the rule the ranks used to pick their items (shard_indices or shard_chunk)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
-    t = torch.from_numpy(np.ascontiguousarray(local_rows, np.float32))
+    t = torch.from_numpy(np.ascontiguousarray(local_rows, np.float64))
     if world == 1:
         allr = t[None]
     else:
         if device is not None:
             t = t.to(device)
-        buf = torch.empty((world * t.shape[0], t.shape[1]), dtype=torch.float32, device=t.device)
+        buf = torch.empty((world * t.shape[0], t.shape[1]), dtype=torch.float64, device=t.device)
         dist.all_gather_into_tensor(buf, t)     # concatenation along dim 0: rank r owns rows [r*R, (r+1)*R)
         allr = buf.cpu().reshape(world, t.shape[0], t.shape[1])
     allr = allr.numpy()
-    out = np.zeros((n_items, ROW_WIDTH - 1), np.float32)
+    out = np.zeros((n_items, ROW_WIDTH - 1), np.float64)
     for r in range(world):
         idx = shard(n_items, r, world)
         rows = allr[r][: len(idx)]
@@ -240,8 +242,13 @@ class HostStager:
         return slot, buf[:n].view(tuple(shape))
 
     def release(self):
-        """Gives back the oldest slot still out (slots are consumed in the order they were filled)."""
-        self.free.put(self.order.get())
+        """Gives back the oldest slot still out (slots are consumed in the order they were filled).  Never blocks: a release
+        with no slot out is a caller's accounting error and is ignored rather than turned into a hang."""
+        import queue
+        try:
+            self.free.put(self.order.get_nowait())
+        except queue.Empty:
+            pass
 
     def fill(self, pinned, arrays):
         """pinned[j] <- arrays[j] for every j, in parallel."""
@@ -379,15 +386,17 @@ class PairRunner:
 
     # ---- single pair (model_interface.py:189-212 + the task call)
     def test_step(self, batch, idx):
-        img0 = crop32(as_image(batch["image0"], self.device))
-        img1 = crop32(as_image(batch["image1"], self.device))
-        if img0.dim() == 3:
-            img0, img1 = img0[None], img1[None]
+        raw0, raw1 = as_image(batch["image0"], self.device), as_image(batch["image1"], self.device)
+        if raw0.dim() == 3:
+            raw0, raw1 = raw0[None], raw1[None]
+        img0, img1 = crop32(raw0), crop32(raw1)
         with torch.no_grad():
             s0, d0 = self.model(img0)     # model_interface.py:205-207
             s1, d1 = self.model(img1)
         kw = {"matcher": self.matcher} if self.task_fn is fund_ransac_row else {}
-        r = self.task_fn(idx, img0, s0, d0, img1, s1, d1, batch.get("warp01_params", {}), batch.get("warp10_params", {}),
+        # the tasks get the UNCROPPED images, as model_interface.py:242-259 hands batch['image0'] / batch['image1'] over
+        # (MHA.py:59-60 takes its resize factors from their shape)
+        r = self.task_fn(idx, raw0, s0, d0, raw1, s1, d1, batch.get("warp01_params", {}), batch.get("warp10_params", {}),
                          self.params, **kw)
         self.results.append(r)
         return r
@@ -602,6 +611,7 @@ class PairRunner:
         out = {}
         copy_stream = torch.cuda.Stream(self.device)
         pending = None          # (group, device tensor, copy-done event): its PCIe copy runs under the previous group's kernels
+        held = []               # copies whose pinned slot has not been given back yet (slot ownership, explicit)
 
         def start_copy(group, pinned):
             main = torch.cuda.current_stream(self.device)
@@ -610,7 +620,9 @@ class PairRunner:
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             dev.record_stream(main)
-            return group, dev, ev
+            p = (group, dev, ev)
+            held.append(p)
+            return p
 
         late = []
 
@@ -624,6 +636,7 @@ class PairRunner:
             group, dev, ev = p
             ev.synchronize()        # the copy has left the pinned slot: the producer may refill it
             st.release()
+            held.remove(p)          # from here on a failing task must not give the slot back a second time
             res = self._flush(group, task_type, staged=dev, between=settle)
             if callable(res):
                 late.append((group, res))
@@ -648,8 +661,13 @@ class PairRunner:
                     out[x] = self.test_step(y, x)
             settle()
         finally:
-            if pending is not None:             # only on an error path: give the slot back
+            for p in held:                      # only on an error path: slots whose copy was started but never consumed
+                try:
+                    p[2].synchronize()
+                except Exception:
+                    pass
                 st.release()
+            held.clear()
             while th.is_alive():                # drain so that the producer can finish if the consumer failed
                 try:
                     kind, x, y = q.get(timeout=0.1)

@@ -28,6 +28,14 @@ def _hw(warp01):
     return np.asarray(_scalar(warp01["height"])), np.asarray(_scalar(warp01["width"]))        # 40: .cpu().numpy() 0-d arrays
 
 
+def _raw_hw(img):
+    """(H, W) of a dataset image as the reference's `mha` sees it: the UNCROPPED batch['image0'] (model_interface.py:249-251
+    passes it, not the x32 crop the network ran on; MHA.py:59-60 reads img_0.shape[2:4]).  Decoded uint8 items are [H, W, 3]."""
+    if getattr(img, "ndim", 0) == 3 and img.shape[-1] == 3 and str(getattr(img, "dtype", "")).endswith("uint8"):
+        return int(img.shape[0]), int(img.shape[1])
+    return int(img.shape[-2]), int(img.shape[-1])
+
+
 def _real_h(warp01):
     return torch.as_tensor(warp01["homography_matrix"]).detach().cpu().numpy()
 
@@ -67,7 +75,7 @@ def mha_batch(pipe, items, params, indices=None):
     m0, m1 = pipe.matched()
     H, _, info = find_homography(m0, m1, scale, k_dev=pipe.k, seeds=seeds)
     H, info = H.cpu().numpy(), info.cpu().numpy()
-    Hp, Wp = pipe.H, pipe.W
+    raw = [_raw_hw(it["image0"]) for it in items]      # resize factors come from the uncropped image 0 (MHA.py:59-60)
 
     def rows():                 # the host half (50-70), on host copies: the runner runs it under the next batch's kernels
         out = []
@@ -76,7 +84,7 @@ def mha_batch(pipe, items, params, indices=None):
                 out.append([0.0 for _ in th])
                 continue
             h, w = hw[b]
-            hits, _ = corner_hits(H[b], _real_h(items[b]["warp01_params"]), h, w, Hp, Wp, th)
+            hits, _ = corner_hits(H[b], _real_h(items[b]["warp01_params"]), h, w, raw[b][0], raw[b][1], th)
             out.append(hits)
         return out
     return rows

@@ -74,8 +74,9 @@ def _compare_lightglue(got_pairs, got_scores, out):
         assert abs(s - 0.1) < 2e-3, "match %s (score %.4f) differs and is not at the threshold" % (r, s)
     common = sorted(set(ws) & set(gs))
     assert len(common) >= 0.97 * len(ws)
+    if common:      # the scores of the matches both sides report (test_gpu_lightglue.py holds the same bound on the small fixtures)
+        np.testing.assert_allclose([gs[r] for r in common], [ws[r] for r in common], rtol=5e-3, atol=2e-5)
     return len(ws)
-    np.testing.assert_allclose([gs[r] for r in common], [ws[r] for r in common], rtol=5e-3, atol=2e-5)
 
 
 @pytest.mark.parametrize("name,dim,scale", [("disk", 128, 1), ("superpoint", 256, 8)])

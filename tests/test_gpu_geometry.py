@@ -103,6 +103,36 @@ def test_runner_mha_batched_equals_single_pair_rows():
     assert aggb["MHA"] == agg1["MHA"] and len(aggb["MHA"]) == 5
 
 
+def test_mha_resize_factors_come_from_the_uncropped_image(monkeypatch):
+    """model_interface.py:249-251 hands the UNCROPPED batch['image0'] to mha, and MHA.py:59-60 takes resize_h / resize_w from its
+    shape; the network runs on the x32 crop.  100 x 132 images: both runner paths must use 100 and 132, not 96 and 128."""
+    from keypoint_bench_amd import runner, synthetic
+    from keypoint_bench_amd.tasks import MHA
+    EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=300, min_score=0.0)
+    prm = {"model_type": "Alike", "task_type": "MHA", "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64), "extractor_params": EP,
+           "matcher_params": {"type": "brute_force", "brute_force_params": dict(metric="euclidean", max_distance=5, cross_check=True)},
+           "MHA_params": {"th": [1, 3, 5]}}
+    ds = []
+    for i in range(3):
+        v0, v1 = synthetic.image_pair(720 + i, 100, 132)
+        hm = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
+        ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
+                   "warp01_params": dict(mode="homo", homography_matrix=hm, width=np.int64(120), height=np.int64(90)),
+                   "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(hm).astype(np.float32), width=120, height=90)})
+    seen = []
+    real = MHA.corner_hits
+
+    def spy(H, real_H, h, w, resize_h, resize_w, th):
+        seen.append((int(h), int(w), int(resize_h), int(resize_w)))
+        return real(H, real_H, h, w, resize_h, resize_w, th)
+
+    monkeypatch.setattr(MHA, "corner_hits", spy)
+    _, rows1 = runner.PairRunner(prm, device=DEV, batch=1).run(ds)
+    _, rowsb = runner.PairRunner(prm, device=DEV, batch=4).run(ds)
+    assert len(seen) == 6 and set(seen) == {(90, 120, 100, 132)}, seen
+    assert np.array_equal(rows1, rowsb)
+
+
 # ------------------------------------------------------------------------------------------------ essential matrix / AUC
 def test_batched_essential_and_pose_equal_oracle_and_ground_truth():
     from keypoint_bench_amd.utils.mvg import estimate_pose
@@ -148,6 +178,39 @@ def test_batched_essential_and_pose_equal_oracle_and_ground_truth():
         T[:3, :3], T[:3, 3] = gt[b][0], gt[b][1]
         et, eR = g.compute_pose_error(T, R, t)
         assert abs(np.linalg.det(R) - 1) < 1e-9 and et < 6.0 and eR < 2.5, (b, et, eR)
+
+
+
+def test_essential_at_config_vo_top_k_2000():
+    """config/config_vo.yaml sets top_k 2000: more matches than the 1 024 the r02 kernels took.  Same sampler and solver as the
+    numpy restatement, so the same hypothesis count, and the pose of the analytic scene."""
+    from keypoint_bench_amd.utils.mvg import estimate_pose
+    from test_oracle_geometry import scene
+    K, n, f, W, H = 2000, 1900, 500.0, 640, 480
+    Kc = np.array([[f, 0, 319.5], [0, f, 239.5], [0, 0, 1.0]])
+    x1, x2, R, t, inl = scene(n, 0.7, 0.4, 77)
+    m0, m1 = np.zeros((2, K, 3), np.float32), np.zeros((2, K, 3), np.float32)
+    m0[:, :n, :2] = ((x1 * f + [319.5, 239.5]) / [W - 1, H - 1]).astype(np.float32)
+    m1[:, :n, :2] = ((x2 * f + [319.5, 239.5]) / [W - 1, H - 1]).astype(np.float32)
+    kk = np.array([n, 1500], np.int32)
+    t_ = lambda a: torch.from_numpy(a).to(DEV)
+    scale = np.array([W - 1, H - 1, W - 1, H - 1], np.float32)
+    rt, mask, good, info = estimate_pose(t_(m0), t_(m1), scale, Kc, Kc, thresh=1.0, k_dev=t_(kk), seeds=[5, 6])
+    rt, mask, good, info = rt.cpu().numpy(), mask.cpu().numpy(), good.cpu().numpy(), info.cpu().numpy()
+    for b in range(2):
+        nb = int(kk[b])
+        px0 = (m0[b, :nb, :2] * scale[:2]).astype(np.float32)
+        px1 = (m1[b, :nb, :2] * scale[2:]).astype(np.float32)
+        k0 = (px0 - Kc[[0, 1], [2, 2]][None]) / Kc[[0, 1], [0, 1]][None]
+        k1 = (px1 - Kc[[0, 1], [2, 2]][None]) / Kc[[0, 1], [0, 1]][None]
+        E, me, ie = g.find_essential_ransac(k0, k1, seed=5 + b, threshold=1.0 / f)
+        assert info[b, 0] == 1 and info[b, 2] == ie["iters"] and abs(int(info[b, 1]) - ie["inliers"]) <= 1, (b, info[b], ie)
+        assert mask[b, nb:].sum() == 0 and mask[b, 1024:nb].sum() > 100          # points past the old limit take part
+        assert abs(int(good[b]) - int(mask[b].sum())) == 0
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        et, eR = g.compute_pose_error(T, rt[b, :9].reshape(3, 3), rt[b, 9:])
+        assert et < 6.0 and eR < 2.5, (b, et, eR)
 
 
 @pytest.mark.parametrize("case", range(4))

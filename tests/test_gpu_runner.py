@@ -198,3 +198,29 @@ def test_a_failing_dataset_item_surfaces_from_the_staging_thread():
         r.run(Broken(good))
     _, rows = r.run(good)
     assert rows.shape[0] == 6 and r.staged_batches > 0
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("fail_at", [0, 2])
+def test_a_failing_batched_task_raises_instead_of_hanging(monkeypatch, fail_at):
+    """A batched task that throws (fundamental_ransac_batch, relative_motion_batch and the kernels do, on purpose) on a
+    staged batch -- the last one included, when no further slot is outstanding -- reaches the caller; the staging ring's slot
+    accounting survives it and the same runner works afterwards."""
+    good = pair_dataset(6)
+    calls = {"n": 0}
+    fn, match, covis = runner.BATCHED_TASKS["match_stats"]
+
+    def flaky(pipe, items, params, indices=None):
+        calls["n"] += 1
+        if calls["n"] - 1 == fail_at:
+            raise RuntimeError("task failed on batch %d" % fail_at)
+        return fn(pipe, items, params, indices)
+
+    monkeypatch.setitem(runner.BATCHED_TASKS, "match_stats", (flaky, match, covis))
+    r = runner.PairRunner(params("match_stats"), device=DEV, batch=2)        # three staged batches: fail_at 2 = the last
+    with pytest.raises(RuntimeError, match="task failed"):
+        r.run(good)
+    st = r._stager
+    assert st.free.qsize() == st.slots and st.order.qsize() == 0            # every slot is back
+    _, rows = r.run(good)
+    assert rows.shape[0] == 6 and np.isfinite(rows[:, :3]).all()
