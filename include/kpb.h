@@ -29,12 +29,15 @@ extern "C" {
 #define KPB_VERSION 1
 
 #define KPB_OK 0
-#define KPB_E_INVALID (-1)      /* bad argument / unsupported size */
+#define KPB_E_INVALID (-1)      /* bad argument: a caller's mistake, never a reason to route the call elsewhere */
 #define KPB_E_HIP (-2)          /* a HIP runtime call failed */
 #define KPB_E_NOMEM (-3)        /* workspace allocation failed */
 #define KPB_E_NEGATIVE (-4)     /* score map holds negative values: outside this path's contract */
 #define KPB_E_NOT_CONVERGED (-5)/* NMS sweeps exhausted (only from the *_nosync pipeline paths) */
 #define KPB_E_WEIGHTS (-6)      /* malformed weight blob */
+#define KPB_E_UNSUPPORTED (-7)  /* a well-formed request beyond a documented limit of the kernels (nms_dist, top_k, matches per pair,
+                                   tracker window ...): the one code, with KPB_E_NEGATIVE, on which install() hands the call
+                                   to the reference's own function */
 
 #define KPB_MAX_NMS_DIST 16
 #define KPB_MAX_TOPK 8192       /* bound of the on-chip sort, applies only when top_k < H*W */

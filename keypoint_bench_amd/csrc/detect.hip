@@ -971,8 +971,10 @@ extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx,
                             float* out_map_dev)
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_fast_nms: null context");
-    if (!score_dev || !out_map_dev || batch <= 0 || H <= 0 || W <= 0 || nms_dist < 0 || nms_dist > KPB_MAX_NMS_DIST)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_fast_nms: bad argument (nms_dist must be 0..%d)", KPB_MAX_NMS_DIST);
+    if (!score_dev || !out_map_dev || batch <= 0 || H <= 0 || W <= 0)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_fast_nms: bad argument");
+    if (nms_dist < 0 || nms_dist > KPB_MAX_NMS_DIST)
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_fast_nms: nms_dist %d outside 0..%d", nms_dist, KPB_MAX_NMS_DIST);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     const size_t bytes = (size_t)batch * H * W * sizeof(float);
     if (nms_dist == 0) {  // extracter.py:40-41
@@ -1046,10 +1048,10 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     if (!score_dev || !prm || !out_kps_dev || !out_n_dev || batch <= 0 || H <= 0 || W <= 0)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: bad argument");
     if (prm->nms_dist < 0 || prm->nms_dist > KPB_MAX_NMS_DIST)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: nms_dist %d outside 0..%d", prm->nms_dist, KPB_MAX_NMS_DIST);
-    if ((size_t)H * W >= (1u << 31)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: map too large");
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_detect: nms_dist %d outside 0..%d", prm->nms_dist, KPB_MAX_NMS_DIST);
+    if ((size_t)H * W >= (1u << 31)) return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_detect: map too large");
     if (prm->top_k <= 0 || (prm->top_k > KPB_MAX_TOPK && prm->top_k < H * W))
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: top_k %d outside 1..%d (or >= H*W)", prm->top_k, KPB_MAX_TOPK);
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_detect: top_k %d outside 1..%d (or >= H*W)", prm->top_k, KPB_MAX_TOPK);
     if (ctx->det_pending)   // one DetState per context: a second enqueue would drop the first call's convergence / sign check
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: the previous kpb_detect(sync=0) has not been completed by kpb_detect_check "
                                             "(its score map and outputs must stay alive until then)");

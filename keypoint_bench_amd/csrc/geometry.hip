@@ -481,7 +481,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_homography(
     if (batch <= 0 || max_k < 0 || cols0 < 2 || cols1 < 2 || !scale_dev || !prm || !out_h_dev || !out_info_dev || (max_k && (!m0_dev || !m1_dev || !out_mask_dev)))
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_homography: bad argument");
     if ((size_t)max_k * sizeof(float4) > 128 * 1024)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_homography: at most %d matches per pair", (int)(128 * 1024 / sizeof(float4)));
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_find_homography: at most %d matches per pair", (int)(128 * 1024 / sizeof(float4)));
     if (!(prm->threshold > 0.0) || prm->max_iters < 1) return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_homography: bad parameters");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     RansacArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, seed_dev, seed, prm->threshold, prm->confidence, prm->max_iters, prm->refine,
@@ -1130,7 +1130,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_fundamental(
     if (batch <= 0 || max_k < 0 || cols0 < 2 || cols1 < 2 || !scale_dev || !prm || !out_f_dev || !out_info_dev || (max_k && (!m0_dev || !m1_dev || !out_mask_dev)))
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_fundamental: bad argument");
     if ((size_t)max_k * sizeof(float4) > 128 * 1024)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_fundamental: at most %d matches per pair", (int)(128 * 1024 / sizeof(float4)));
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_find_fundamental: at most %d matches per pair", (int)(128 * 1024 / sizeof(float4)));
     if (!(prm->threshold > 0.0) || prm->max_iters < 1) return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_fundamental: bad parameters");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     FundArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, seed_dev, seed, prm->threshold, prm->confidence, prm->max_iters,
@@ -1156,7 +1156,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_essential(
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: bad argument");
     const size_t lds = (size_t)max_k * 4 * sizeof(double);
     if (lds > 128 * 1024)      // the matches live in LDS for the whole search (config_vo.yaml's top_k 2000 needs 64 KB)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_find_essential: at most 4096 matches per pair (got %d)", max_k);
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_find_essential: at most 4096 matches per pair (got %d)", max_k);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     if (lds > 48 * 1024) {
         static bool raised = false;

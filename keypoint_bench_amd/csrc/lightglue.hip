@@ -814,7 +814,7 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
     if (!pts0_dev || !pts1_dev || !desc0_dev || !desc1_dev || !prm || !out_pairs_dev || !out_scores_dev || !out_k_dev || batch <= 0 || max_k <= 0)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_match: bad argument");
     if (C != lg->input_dim) return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_match: descriptor maps have %d channels, the weights expect %d", C, lg->input_dim);
-    if (C > 256) return kpb_fail(ctx, KPB_E_INVALID, "kpb_lg_match: input_dim %d > 256", C);
+    if (C > 256) return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_lg_match: input_dim %d > 256", C);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     const int B = batch, S = 2 * B, MP = ((max_k + 127) / 128) * 128;
     const size_t T = (size_t)S * MP;

@@ -167,9 +167,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_lk_track(
     if (!img1_dev || !img2_dev || !prm || C <= 0 || H <= 20 || W <= 20 || n < 0 || pts_stride < 2)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_lk_track: bad argument");
     if (prm->win_size < 1 || prm->win_size > 31 || !(prm->win_size & 1) || prm->levels < 1 || prm->levels > 4 || prm->iterations < 0)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_lk_track: win_size must be odd and <= 31, levels 1..4");
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_lk_track: win_size must be odd and <= 31, levels 1..4");
     if ((H >> (prm->levels - 1)) < 2 || (W >> (prm->levels - 1)) < 2)
-        return kpb_fail(ctx, KPB_E_INVALID, "kpb_lk_track: image too small for %d levels", prm->levels);
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_lk_track: image too small for %d levels", prm->levels);
     if (n == 0) return KPB_OK;
     if (!pts1_dev || !pts2_dev || !unit_dev || !out_pts_dev || !out_err_dev)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_lk_track: null buffer");
@@ -187,7 +187,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_lk_track(
     hipStream_t st = ctx->stream;
     KPB_LAUNCH(ctx, "lk_init", lk_init, dim3(cdiv(n, 256)), dim3(256), 0, st, pts1_dev, pts2_dev, pts_stride, unit_dev, n, H, W, prm->distance, p1, p2, cur);
     const size_t lds = (size_t)4 * C * prm->win_size * prm->win_size * sizeof(float);
-    if (lds > 64 * 1024) return kpb_fail(ctx, KPB_E_INVALID, "kpb_lk_track: window of %d x %d x %d does not fit the patch buffer", prm->win_size, prm->win_size, C);
+    if (lds > 64 * 1024) return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_lk_track: window of %d x %d x %d does not fit the patch buffer", prm->win_size, prm->win_size, C);
     for (int lv = 0; lv < prm->levels; ++lv) {
         const int idx = prm->levels - lv - 1;
         const int k = idx == 0 ? 1 : 2 * idx;       // build_pyramid (45): level i > 0 is avg_pool2d(img, 2i, 2i) ...

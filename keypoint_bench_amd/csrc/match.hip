@@ -563,7 +563,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
         return KPB_OK;
     }
     if (!d0_dev || !d1_dev || !out_pairs_dev) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: null buffer");
-    if (max_m > 16384) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: max_m %d > 16384", max_m);
+    if (max_m > 16384) return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_match: max_m %d > 16384", max_m);
     const int tiles_i = cdiv(max_n, MTI), tiles_j = cdiv(max_m, MTJ);
     const size_t nr = (size_t)batch * tiles_j * max_n, nc = (size_t)batch * tiles_i * max_m;
     const size_t bytes = (nr + nc) * (sizeof(double) + sizeof(int)) + 64;

@@ -8,8 +8,11 @@ never from oracle/) and routes to it whatever lies outside the library's contrac
   * a score map with negative values -- models/Harris.py:13-22 returns cv2.cornerHarris responses, and the
     reference's NMS lets suppressed zeros win against negative neighbours.  The library finds this with a device-side
     flag raised by the NMS kernels themselves (KPB_E_NEGATIVE), not with a host scan of the map;
-  * arguments the kernels do not carry (fast_nms max_iter / min_value, a non-euclidean metric, nms_dist > 16,
-    ALIKE channel plans other than -t, DISK variants): KPB_E_INVALID / NotImplementedError.
+  * arguments the kernels do not carry (fast_nms max_iter / min_value, a non-euclidean metric, nms_dist > 16, more matches
+    than a RANSAC kernel holds, ALIKE channel plans other than -t, DISK variants): KPB_E_UNSUPPORTED / NotImplementedError.
+
+Nothing else falls through: KPB_E_INVALID (a malformed call) and every other library error RAISE -- an in-contract call that
+starts failing must not turn into a silent thousandfold slowdown on the reference's CPU code.
 
 So the Harris / repeatability configuration keeps running on the reference's code while ALIKE / SuperPoint / XFeat /
 DISK runs go through libkpb.so.  ``uninstall()`` restores every original.
@@ -22,7 +25,8 @@ import torch
 
 from ._lib import KpbError
 
-KPB_E_INVALID, KPB_E_NEGATIVE = -1, -4
+KPB_E_INVALID, KPB_E_NEGATIVE, KPB_E_UNSUPPORTED = -1, -4, -7
+FALLBACK_CODES = (KPB_E_NEGATIVE, KPB_E_UNSUPPORTED)       # the whitelist: documented out-of-contract reasons only
 
 _state = {"originals": {}, "swapped": [], "skipped": {}, "rebound": []}
 _ROOTS = ("utils", "models", "tasks")
@@ -49,7 +53,7 @@ def guarded(name, hip_fn, ref_fn, in_contract):
         try:
             return hip_fn(*a, **k)
         except KpbError as e:
-            if e.code not in (KPB_E_NEGATIVE, KPB_E_INVALID):
+            if e.code not in FALLBACK_CODES:
                 raise
             why = "negative scores" if e.code == KPB_E_NEGATIVE else str(e)
         except NotImplementedError as e:
