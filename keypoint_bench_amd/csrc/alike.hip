@@ -37,6 +37,15 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
 }
 
 
+// Largest value of a NON-NEGATIVE tensor, per image: a wave offers its maximum to the image's slot (float bits order like
+// unsigned integers for non-negative floats).  The slot is read first and the atomic skipped when it would not raise it -- after
+// the first few workgroups of an image almost every wave skips (a stale read only costs an unnecessary atomic).
+__device__ __forceinline__ void amax_commit(float lane_max, unsigned* slot, int lane)
+{
+    const unsigned bits = __float_as_uint(cm_wave_max(lane_max));
+    if (lane == 0 && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+}
+
 // ------------------------------------------------------------------------------------------------ block1
 constexpr int B1_TH = 32, B1_TW = 32;
 
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
 
 // ------------------------------------------------------------------------------------------------ block1 on the matrix cores
 // Same fusion as alike_block1 (3 -> 8 -> 8 through LDS), with BOTH convolutions moved from the fp32 vector ALUs to
-// v_mfma_f32_16x16x32_f16 on split operands (x = hi + lo halves, three MFMAs per product: conv3x3_h16 has the numerics).
+// v_mfma_f32_16x16x32_f16 on split operands (x = hi + lo halves, three MFMAs per product: alike_block2 has the numerics).
 // N = 8 output channels would waste half of a 16-wide MFMA, so one accumulator row stands for a PAIR of horizontally
 // adjacent pixels: N = (pixel of the pair s, output channel), and K runs over the 3 x 4 input window the pair shares; the
 // weight of window cell (ky, kx) for pixel s is w[ky][kx - s], zero outside the 3 x 3 kernel.
@@ -208,8 +217,11 @@ __global__ __launch_bounds__(256) void alike_block1(Block1Args a)
 // register kept per row pair.  16 x 32 tiles: 31 KB of LDS, five workgroups per CU.
 struct Block1HArgs {
     Block1Args b;
-    const uint4* w1pk;   // [2 kb][hi / lo][64 lanes] fragments of conv1 (pack_b1c1_pairs)
-    const uint4* w2pk;   // [3 kb][hi / lo][64 lanes] fragments of conv2 (pack_b1c2_pairs)
+    const uint4* w1pk;   // [2 kb][hi / lo][64 lanes] fragments of conv1 (pack_b1c1_pairs), scaled by 1 / inv_ws1
+    const uint4* w2pk;   // [3 kb][hi / lo][64 lanes] fragments of conv2 (pack_b1c2_pairs), scaled by 1 / inv_ws2
+    float inv_ws1, inv_ws2;     // reciprocals of the two power-of-two weight scales
+    float l1_c1, bmax_c1;       // max over output channels of sum |w| of conv1, max |bias|: |conv1 output| <= amax(input) l1 + bmax
+    unsigned* amax_x1;          // [B] float bits: largest x1 value of each image (x1 >= 0), read by block 2 and the head
 };
 
 constexpr int B1H_TH = 16;
@@ -242,9 +254,12 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         bhi[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 0) * 64 + lane]);
         blo[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 1) * 64 + lane]);
     }
+    __shared__ __attribute__((aligned(16))) float s_amax[4];
+    int e_img;      // exponent of this tile's largest |pixel|: the image is split at the scale that fits THIS tile (cm_scale_of)
     {   // stage the (TH+4) x 36 image tile split, three channels per position; all loads of a thread in flight first
         constexpr int PER = (NIN + 255) / 256;
         float buf[PER][3];
+        float am = 0.0f;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * 256;
@@ -253,17 +268,27 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             const bool ok = i < NIN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
 #pragma unroll
             for (int c = 0; c < 3; ++c) buf[k][c] = ok ? img[c * P + (size_t)gy * a.W + gx] : 0.0f;
+            am = fmaxf(fmaxf(am, fabsf(buf[k][0])), fmaxf(fabsf(buf[k][1]), fabsf(buf[k][2])));
         }
+        am = cm_wave_max(am);
+        if (lane == 0) s_amax[wv] = am;
+        __syncthreads();
+        const float4 q = *reinterpret_cast<const float4*>(s_amax);
+        e_img = cm_exp_of(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+        const float sc = cm_scale_of(e_img);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * 256;
             uint2 hi, lo;
-            split4(make_float4(buf[k][0], buf[k][1], buf[k][2], 0.0f), hi, lo);
+            split4(make_float4(buf[k][0] * sc, buf[k][1] * sc, buf[k][2] * sc, 0.0f), hi, lo);
             if (i < NIN) { inh[i] = hi; inh[NIN + i] = lo; }
         }
         if (tid < 2) inh[2 * NIN + tid] = make_uint2(0u, 0u);
     }
     __syncthreads();
+    // conv1's output is bounded by amax(tile) l1 + bmax: the intermediate map is split at the scale of that bound
+    const int e_mid = cm_exp_of(fmaf(__uint_as_float((unsigned)(e_img - 126 + 127) << 23), ha.l1_c1, ha.bmax_c1));
+    const float un1 = ha.inv_ws1 * cm_unscale_of(e_img), sc_mid = cm_scale_of(e_mid), un2 = ha.inv_ws2 * cm_unscale_of(e_mid);
     const int pr = lane & 15, g = lane >> 4;                         // this lane's pair slot (operand column and accumulator column)
     const int sN = g >> 1, c0 = 4 * (g & 1);                          // ... and what its accumulator holds: pixel sN of the pair, channels c0 .. c0 + 3
     {   // conv1 + ReLU on the MH x MW halo'd positions, 16 pairs per MFMA group: group gi < MH = pairs 0..15 of row gi; the 17th
@@ -289,7 +314,8 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             }
             const int gy = ty0 - 1 + y, gx = tx0 - 1 + 2 * pc + sN;
             const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;           // conv2 pads its INPUT (the ReLU'd map) with zeros
-            float4 v = make_float4(relu(acc[0] + bias1.x), relu(acc[1] + bias1.y), relu(acc[2] + bias1.z), relu(acc[3] + bias1.w));
+            float4 v = make_float4(relu(fmaf(acc[0], un1, bias1.x)) * sc_mid, relu(fmaf(acc[1], un1, bias1.y)) * sc_mid,
+                                   relu(fmaf(acc[2], un1, bias1.z)) * sc_mid, relu(fmaf(acc[3], un1, bias1.w)) * sc_mid);
             if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4(v, hi, lo);
@@ -307,6 +333,7 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
     const float4 bias2 = *reinterpret_cast<const float4*>(a.b2 + c0);
     const int H2 = a.H / 2, W2 = a.W / 2;
     float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
+    float xmax = 0.0f;                  // this lane's largest x1 value (x1 >= 0)
     const int gx = tx0 + 2 * pr + sN;
 #pragma unroll 1
     for (int rr = 0; rr < TH / 4; ++rr) {
@@ -322,8 +349,11 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bhi[kb], ihi, acc, 0, 0, 0);
         }
         const int gy = ty0 + row;
-        const float4 v = make_float4(relu(acc[0] + bias2.x), relu(acc[1] + bias2.y), relu(acc[2] + bias2.z), relu(acc[3] + bias2.w));
-        if (gy < a.H && gx < a.W) *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8 + c0) = v;
+        const float4 v = make_float4(relu(fmaf(acc[0], un2, bias2.x)), relu(fmaf(acc[1], un2, bias2.y)), relu(fmaf(acc[2], un2, bias2.z)), relu(fmaf(acc[3], un2, bias2.w)));
+        if (gy < a.H && gx < a.W) {
+            *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8 + c0) = v;
+            xmax = fmaxf(fmaxf(xmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        }
         if ((rr & 1) == 0) {
             keep = v;
         } else {        // max_pool2d(x1, 2, 2): the row pair in registers, the other pixel of the pair two lane groups away
@@ -334,11 +364,12 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             if (sN == 0 && py < H2 && pxl < W2) *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + py) * W2 + pxl) * 8 + c0) = m;
         }
     }
+    amax_commit(xmax, ha.amax_x1 + b, lane);
 }
 
 // conv1 of block 1, OIHW [8][3][3][3] -> alike_block1_h fragments [2 kb][hi / lo][64 lanes][8 halves]: lane (n = (s, cout), g),
 // piece 4 kb + g = (ky, half) for pieces 0..5; element j = (kx = 2 half + (j >> 2), cin = j & 3): w[cout][cin][ky][kx - s]
-std::vector<float> pack_b1c1_pairs(const float* w)
+std::vector<float> pack_b1c1_pairs(const float* w, float scale)
 {
     std::vector<uint16_t> hl((size_t)2 * 2 * 64 * 8, 0);
     for (int kb = 0; kb < 2; ++kb)
@@ -346,7 +377,7 @@ std::vector<float> pack_b1c1_pairs(const float* w)
             for (int j = 0; j < 8; ++j) {
                 const int n = l & 15, g = l >> 4, s2 = n >> 3, co = n & 7, piece = 4 * kb + g;
                 const int ky = piece >> 1, kx = 2 * (piece & 1) + (j >> 2) - s2, c = j & 3;
-                const float v = (piece < 6 && c < 3 && kx >= 0 && kx <= 2) ? w[((size_t)co * 3 + c) * 9 + ky * 3 + kx] : 0.0f;
+                const float v = (piece < 6 && c < 3 && kx >= 0 && kx <= 2) ? w[((size_t)co * 3 + c) * 9 + ky * 3 + kx] * scale : 0.0f;
                 _Float16 hi = (_Float16)v;
                 if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
                 const _Float16 lo = (_Float16)(v - (float)hi);
@@ -360,14 +391,14 @@ std::vector<float> pack_b1c1_pairs(const float* w)
 
 // conv2 of block 1, OIHW [8][8][3][3] -> alike_block1_h fragments [3 kb = ky][hi / lo][64 lanes][8 halves = cin]:
 // lane (n = (s, cout), g = kx of the 3 x 4 window) holds w[cout][cin][ky][kx - s] (zero outside the kernel)
-std::vector<float> pack_b1c2_pairs(const float* w)
+std::vector<float> pack_b1c2_pairs(const float* w, float scale)
 {
     std::vector<uint16_t> hl((size_t)3 * 2 * 64 * 8, 0);
     for (int kb = 0; kb < 3; ++kb)
         for (int l = 0; l < 64; ++l)
             for (int j = 0; j < 8; ++j) {
                 const int n = l & 15, g = l >> 4, s2 = n >> 3, co = n & 7, kx = g - s2;
-                const float v = (kx >= 0 && kx <= 2) ? w[((size_t)co * 8 + j) * 9 + kb * 3 + kx] : 0.0f;
+                const float v = (kx >= 0 && kx <= 2) ? w[((size_t)co * 8 + j) * 9 + kb * 3 + kx] * scale : 0.0f;
                 _Float16 hi = (_Float16)v;
                 if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
                 const _Float16 lo = (_Float16)(v - (float)hi);
@@ -514,128 +545,21 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------ conv3x3, split-f16 MFMA
-// The 3x3 convolutions of block 2 (8 -> 16 and 16 -> 16 at H/2) as implicit GEMMs on v_mfma_f32_16x16x32_f16 with every fp32
-// operand split into two half-precision terms (x = hi + lo, hi = f16(x) toward zero, lo = f16(x - hi); three MFMAs per
-// product, the lo.lo term dropped: relative 2^-22 per product, fp32 accumulation -- see alike_head_f16).  fp32 MFMA and the
-// fp32 VALU share one rate on gfx950 (157 TFLOP/s); the f16 matrix rate is 16x that, so even at three MFMAs per product
-// these layers leave the arithmetic roofline and become HBM-bound.
-//   M = 16 consecutive pixels of an image row, N = the 16 output channels, K = 32 per MFMA = four 16-byte pieces, piece
-//   kidx = (tap, channel octet): lane (row i, group g) of k-block kb supplies piece 4 kb + g of pixel pi(i).
-//   The input tile sits in LDS already split, as planes of 16-byte slots [hi | lo][octet][position]: a lane's A operand is
-//   ONE ds_read_b128 per plane, 16 consecutive slots per 16 lanes (conflict-free).  The weights of a lane (<= 5 k-blocks x
-//   hi / lo x 16 bytes) stay in registers for the whole kernel.  RES folds the block's identity branch -- the 1x1
-//   convolution of the pooled block input, ALike.py:76-79 -- in as one more 16-byte piece of K (free: K = 152 <= 160).
-//   pi(4 g + r) = g + 4 r: accumulator register r of the four lane groups then holds four ADJACENT pixels, so one store
-//   instruction writes 4 pixels x 16 channels = 256 contiguous bytes.
-struct H16Args {
-    const float* in;      // [B][H][W][CIN]
-    const float* res_in;  // RES: [B][H][W][8]
-    float* out;           // [B][H][W][16]
-    const uint4* wpk;     // [KB][hi / lo][64 lanes] fragments (pack_h16)
-    const float* bias;    // [16] (RES: conv bias + identity-branch bias)
-    int H, W;
-};
-
-
-template <int CIN, bool RES>
-__global__ __launch_bounds__(256) void conv3x3_h16(H16Args a)
-{
-    constexpr int OCT = CIN / 8, TH = 8, TW = 32, LW = TW + 2, NPOS = (TH + 2) * LW;
-    constexpr int NPL = OCT + (RES ? 1 : 0);                  // planes per half: input octets (+ the identity-branch input)
-    constexpr int NK = 9 * OCT + (RES ? 1 : 0), KB = (NK + 3) / 4;
-    constexpr int REGION = NPL * NPOS;                        // slots of the hi half; the lo half follows; then one zero slot
-    __shared__ __attribute__((aligned(16))) uint4 lds[2 * REGION + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
-    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
-    const float* in = a.in + (size_t)b * a.H * a.W * CIN;
-
-    // this lane's weight fragments: registers for the whole kernel
-    h8v bhi[KB], blo[KB];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        bhi[kb] = __builtin_bit_cast(h8v, a.wpk[(kb * 2 + 0) * 64 + lane]);
-        blo[kb] = __builtin_bit_cast(h8v, a.wpk[(kb * 2 + 1) * 64 + lane]);
-    }
-    // stage the (TH+2) x (TW+2) input tile, split, zero outside the image (the convolution's padding)
-    for (int i = tid; i < NPOS * (CIN / 4); i += 256) {
-        const int pos = i / (CIN / 4), q = i - pos * (CIN / 4);
-        const int y = pos / LW, x = pos - y * LW;
-        const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.W + gx) * CIN + 4 * q);
-        uint2 hi, lo;
-        split4(v, hi, lo);
-        uint2* dh = reinterpret_cast<uint2*>(&lds[(q >> 1) * NPOS + pos]) + (q & 1);
-        dh[0] = hi;
-        dh[2 * REGION] = lo;            // uint2 units: the lo half starts REGION uint4 slots later
-    }
-    if (RES) {      // the identity branch reads the centre pixels only
-        const float* rin = a.res_in + (size_t)b * a.H * a.W * 8;
-        for (int i = tid; i < TH * TW * 2; i += 256) {
-            const int px = i >> 1, q = i & 1;
-            const int y = px / TW, x = px - y * TW;
-            const int gy = ty0 + y, gx = tx0 + x;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.H && gx < a.W) v = *reinterpret_cast<const float4*>(rin + ((size_t)gy * a.W + gx) * 8 + 4 * q);
-            uint2 hi, lo;
-            split4(v, hi, lo);
-            uint2* dh = reinterpret_cast<uint2*>(&lds[OCT * NPOS + (y + 1) * LW + x + 1]) + q;
-            dh[0] = hi;
-            dh[2 * REGION] = lo;
-        }
-    }
-    if (tid == 0) lds[2 * REGION] = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-
-    const int i16 = lane & 15, g = lane >> 4;
-    const int px = (i16 >> 2) + 4 * (i16 & 3);                // pi(i): the pixel of the group this lane's A row stands for
-    int aoff[KB];                                             // slot offset of piece 4 kb + g relative to the group's first pixel; -1: no such piece
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        const int kidx = 4 * kb + g;
-        if (kidx < 9 * OCT) {
-            const int tap = kidx / OCT, o = kidx - tap * OCT;
-            aoff[kb] = o * NPOS + (tap / 3) * LW + (tap % 3);
-        } else if (RES && kidx == 9 * OCT) {
-            aoff[kb] = OCT * NPOS + LW + 1;
-        } else {
-            aoff[kb] = -1;
-        }
-    }
-    const float bias = a.bias[i16];
-    float* out = a.out + (size_t)b * a.H * a.W * 16;
-#pragma unroll 1
-    for (int gi = 4 * wv; gi < 4 * wv + 4; ++gi) {            // 16 groups of 16 pixels per tile, four per wave
-        const int row = gi >> 1, col0 = (gi & 1) * 16;
-        const int base = row * LW + col0 + px;
-        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-            const int at = aoff[kb] >= 0 ? base + aoff[kb] : 2 * REGION;
-            const h8v ahi = __builtin_bit_cast(h8v, lds[at]);
-            const h8v alo = __builtin_bit_cast(h8v, lds[aoff[kb] >= 0 ? at + REGION : 2 * REGION]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[kb], acc, 0, 0, 0);      // small terms first
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[kb], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[kb], acc, 0, 0, 0);
-        }
-        // D: lane holds channel i16 of pixels pi(4 g + r) = g + 4 r
-        const int gy = ty0 + row;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gx = tx0 + col0 + g + 4 * r;
-            if (gy < a.H && gx < a.W) out[((size_t)gy * a.W + gx) * 16 + i16] = relu(acc[r] + bias);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ block 2 + agg2, fused
 // ResBlock 8 -> 16 at H/2 (ALike.py:65-81, 139-140) and the aggregation 1x1 + ReLU of its output (147-148) in ONE kernel:
 //   conv1 (8 -> 16) + ReLU on the (TH+2) x (TW+2) halo'd positions, from the pooled block-1 tile in LDS, back into LDS split;
 //   conv2 (16 -> 16) + the block's 1x1 identity branch (one more K piece, read from the input tile already in LDS) + ReLU -> x2;
 //   agg2 (16 -> 16, no bias) + ReLU on x2 -> a2, and a2 . w_score -> S2 (the group's share of the score logit).
-// All three on v_mfma_f32_16x16x32_f16 with split operands (conv3x3_h16 has the numerics and the operand layout).  As
-// three kernels (r02: 0.77 + 1.80 + 1.00 ms per 512 images) the 16-channel intermediate t2 made a round trip through HBM and
+// All three are implicit GEMMs on v_mfma_f32_16x16x32_f16 with every fp32 operand split into two half-precision terms (x = hi +
+// lo, hi = f16(x) toward zero, lo = f16(x - hi); three MFMAs per product, the lo.lo term dropped: relative 2^-22 per product, fp32
+// accumulation -- see alike_head_f16):
+//   M = 16 consecutive pixels of an image row, N = the 16 output channels, K = 32 per MFMA = four 16-byte pieces, piece
+//   kidx = (tap, channel octet): lane (row i, group g) of k-block kb supplies piece 4 kb + g.  The input tile sits in LDS
+//   already split, as planes of 16-byte slots [hi | lo][octet][position]: a lane's operand is ONE ds_read_b128 per plane, 16
+//   consecutive slots per 16 lanes (conflict-free).  The weights of a lane (<= 5 k-blocks x hi / lo x 16 bytes) stay in registers
+//   for the whole kernel.  The block's identity branch -- the 1x1 convolution of the pooled block input, ALike.py:76-79 -- is
+//   one more 16-byte piece of conv2's K (free: K = 152 <= 160).
+// As three kernels (r02: 0.77 + 1.80 + 1.00 ms per 512 images) the 16-channel intermediate t2 made a round trip through HBM and
 // x2 was read back for the aggregation: 14.3 MB of avoidable traffic per image; fused, the block reads p1 once and writes
 // x2, a2, S2 once.  agg2 needs x2 with the pixel on the lane (A operand) where the accumulator has the channel on the lane:
 // each wave passes its 16 x 16 tile through 1 KB of LDS of its own (a wave's LDS operations execute in order: no barrier).
@@ -648,6 +572,11 @@ struct Block2Args {
     const uint4* wapk;   // pack_1x1_h16(agg2.w): 1 k-block
     const float* b1; const float* bsum; const float* wsg;
     int H, W;
+    // dynamic operand range (see conv_mfma.h, cm_scale_of): reciprocal weight scales of the three packs, and the constants of
+    // the two bounds |conv1 out| <= amax(p1) l1_c1 + bmax_c1, |x2| <= bound(conv1) l1_c2 + amax(p1) l1_ds + bmax_sum
+    float inv_ws1, inv_ws2, inv_wsa, l1_c1, bmax_c1, l1_c2, l1_ds, bmax_sum;
+    const unsigned* amax_x1;    // [B] float bits: largest value of the image's x1 (= of p1, its 2 x 2 max-pool)
+    unsigned* amax_a2;          // [B] float bits: largest a2 value of each image, for the head
 };
 
 
@@ -671,6 +600,14 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
 #pragma unroll
     for (int kb = 0; kb < 5; ++kb) { w2h[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2) * 64 + lane]); w2l[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2 + 1) * 64 + lane]); }
     const h8v wah = __builtin_bit_cast(h8v, a.wapk[lane]), wal = __builtin_bit_cast(h8v, a.wapk[64 + lane]);
+    // One activation scale for the block input AND conv1's output (conv2 accumulates pieces of both: the identity branch reads
+    // the input tile): that of the larger of amax(p1) and conv1's bound.  x2 gets its own (agg2 is a separate product).
+    const float am_p = __uint_as_float(a.amax_x1[b]);
+    const float bound1 = fmaf(am_p, a.l1_c1, a.bmax_c1);
+    const int e1 = cm_exp_of(fmaxf(am_p, bound1));
+    const int ex = cm_exp_of(fmaf(bound1, a.l1_c2, fmaf(am_p, a.l1_ds, a.bmax_sum)));
+    const float sc1 = cm_scale_of(e1), un_c1 = a.inv_ws1 * cm_unscale_of(e1), un_c2 = a.inv_ws2 * cm_unscale_of(e1);
+    const float scx = cm_scale_of(ex), un_a = a.inv_wsa * cm_unscale_of(ex);
     {   // stage the (TH+4) x (TW+4) tile of p1, split, zero outside the image
         const float* in = a.p1 + (size_t)b * P * 8;
         for (int i = tid; i < NP * 2; i += 256) {
@@ -679,6 +616,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.W + gx) * 8 + 4 * q);
+            v.x *= sc1; v.y *= sc1; v.z *= sc1; v.w *= sc1;
             uint2 hi, lo;
             split4(v, hi, lo);
             uint2* d = reinterpret_cast<uint2*>(&pin[pos]) + q;
@@ -717,7 +655,8 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             }
             const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
             const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;           // conv2 pads its INPUT with zeros
-            float4 v = make_float4(relu(acc[0] + bias1.x), relu(acc[1] + bias1.y), relu(acc[2] + bias1.z), relu(acc[3] + bias1.w));
+            float4 v = make_float4(relu(fmaf(acc[0], un_c1, bias1.x)) * sc1, relu(fmaf(acc[1], un_c1, bias1.y)) * sc1,
+                                   relu(fmaf(acc[2], un_c1, bias1.z)) * sc1, relu(fmaf(acc[3], un_c1, bias1.w)) * sc1);
             if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4(v, hi, lo);
@@ -738,6 +677,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     float* S2 = a.S2 + (size_t)b * P;
     uint2* xh = reinterpret_cast<uint2*>(&xs[wv][0][0][0]);
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);        // x2 >= 0 (ReLU): zero is the neutral element of the pool
+    float amx = 0.0f;                                    // this lane's largest a2 value
 #pragma unroll 2
     for (int k4 = 0; k4 < 4; ++k4) {
         const int row = 4 * (wv >> 1) + k4, col0 = (wv & 1) * 16;
@@ -759,12 +699,12 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         }
         const int gy = ty0 + row, gx = tx0 + col0 + px;
         const bool ok = gy < a.H && gx < a.W;
-        const float4 v = make_float4(relu(acc[0] + bsum.x), relu(acc[1] + bsum.y), relu(acc[2] + bsum.z), relu(acc[3] + bsum.w));
+        const float4 v = make_float4(relu(fmaf(acc[0], un_c2, bsum.x)), relu(fmaf(acc[1], un_c2, bsum.y)), relu(fmaf(acc[2], un_c2, bsum.z)), relu(fmaf(acc[3], un_c2, bsum.w)));
         if (ok && !a.p2) *reinterpret_cast<float4*>(x2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = v;
         pm = make_float4(fmaxf(pm.x, v.x), fmaxf(pm.y, v.y), fmaxf(pm.z, v.z), fmaxf(pm.w, v.w));
         {   // the x2 group, split, to this wave's LDS strip with the channel octets as slots: the B operand of agg2
             uint2 hi, lo;
-            split4(v, hi, lo);
+            split4(make_float4(v.x * scx, v.y * scx, v.z * scx, v.w * scx), hi, lo);
             const int h8 = (((g >> 1) * 16 + px) << 1) + (g & 1);
             xh[h8] = hi;
             xh[h8 + 64] = lo;                      // lo half: 2 x 16 slots = 64 8-byte units further
@@ -778,8 +718,11 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(wal, ihi, ag, 0, 0, 0);
             ag = __builtin_amdgcn_mfma_f32_16x16x32_f16(wah, ihi, ag, 0, 0, 0);
         }
-        const float4 av = make_float4(relu(ag[0]), relu(ag[1]), relu(ag[2]), relu(ag[3]));
-        if (ok) *reinterpret_cast<float4*>(a2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = av;
+        const float4 av = make_float4(relu(ag[0] * un_a), relu(ag[1] * un_a), relu(ag[2] * un_a), relu(ag[3] * un_a));
+        if (ok) {
+            *reinterpret_cast<float4*>(a2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = av;
+            amx = fmaxf(fmaxf(amx, fmaxf(av.x, av.y)), fmaxf(av.z, av.w));
+        }
         float sg = fmaf(av.w, wsg.w, fmaf(av.z, wsg.z, fmaf(av.y, wsg.y, av.x * wsg.x)));      // this group's share of the score logit
         sg += __shfl_xor(sg, 16, 64);
         sg += __shfl_xor(sg, 32, 64);
@@ -794,16 +737,17 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         if ((px & 3) == 0 && gy < a.H && gx < a.W)
             *reinterpret_cast<float4*>(a.p2 + (size_t)b * (P / 16) * 16 + ((size_t)(gy >> 2) * (a.W >> 2) + (gx >> 2)) * 16 + 4 * g) = pm;
     }
+    amax_commit(amx, a.amax_a2 + b, lane);
 }
 
 // agg [16][16] (cout, cin) -> one k-block of fragments: piece g < 2 = channel octet g
-std::vector<float> pack_1x1_h16(const float* w)
+std::vector<float> pack_1x1_h16(const float* w, float scale)
 {
     std::vector<uint16_t> hl((size_t)2 * 64 * 8, 0);
     for (int l = 0; l < 64; ++l)
         for (int j = 0; j < 8; ++j) {
             const int n = l & 15, g = l >> 4;
-            const float v = g < 2 ? w[n * 16 + 8 * g + j] : 0.0f;
+            const float v = g < 2 ? w[n * 16 + 8 * g + j] * scale : 0.0f;
             _Float16 hi = (_Float16)v;
             if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
             const _Float16 lo = (_Float16)(v - (float)hi);
@@ -815,8 +759,8 @@ std::vector<float> pack_1x1_h16(const float* w)
     return out;
 }
 
-// OIHW [16][CIN][3][3] (+ identity-branch [16][8]) -> conv3x3_h16 fragments [KB][hi / lo][64 lanes][8 halves], as floats (bit patterns)
-std::vector<float> pack_h16(const float* w, int CIN, const float* ds_w)
+// OIHW [16][CIN][3][3] (+ identity-branch [16][8]) -> alike_block2 fragments [KB][hi / lo][64 lanes][8 halves], as floats (bit patterns)
+std::vector<float> pack_h16(const float* w, int CIN, const float* ds_w, float scale)
 {
     const int OCT = CIN / 8, NK = 9 * OCT + (ds_w ? 1 : 0), KB = (NK + 3) / 4;
     std::vector<uint16_t> hl((size_t)KB * 2 * 64 * 8, 0);
@@ -827,6 +771,7 @@ std::vector<float> pack_h16(const float* w, int CIN, const float* ds_w)
                 float v = 0.0f;
                 if (kidx < 9 * OCT) { const int tap = kidx / OCT, o = kidx - tap * OCT; v = w[((size_t)n * CIN + 8 * o + j) * 9 + tap]; }
                 else if (ds_w && kidx == 9 * OCT) v = ds_w[n * 8 + j];
+                v *= scale;
                 _Float16 hi = (_Float16)v;
                 if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
                 const _Float16 lo = (_Float16)(v - (float)hi);
@@ -962,9 +907,10 @@ __device__ __forceinline__ void up8ch_load(const float* m, int Hs, int Ws, float
         u.t[4 * q + 2] = *reinterpret_cast<const float4*>(p10 + 4 * q); u.t[4 * q + 3] = *reinterpret_cast<const float4*>(p11 + 4 * q);
     }
 }
-__device__ __forceinline__ void up8ch_lerp(const Up8Taps& u, float* f)
+// `sc` (a power of two) scales the result exactly: it rides on the two y weights
+__device__ __forceinline__ void up8ch_lerp(const Up8Taps& u, float* f, float sc = 1.0f)
 {
-    const float ly = u.ly, lx = u.lx, hy = 1.0f - ly, hx = 1.0f - lx;
+    const float lx = u.lx, hx = 1.0f - lx, hy = (1.0f - u.ly) * sc, ly = u.ly * sc;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const float4 a = u.t[4 * q], b = u.t[4 * q + 1], c = u.t[4 * q + 2], d = u.t[4 * q + 3];
@@ -997,15 +943,20 @@ struct HybArgs {
     const float* wsc;  // [64]
     float* score; float* desc;
     int H, W;
-    int pf;            // line prefetch of the f16 head: 0 none, 1 streaming loads, 2 plain loads
+    // split-f16 form only: dynamic operand range (conv_mfma.h, cm_scale_of).  The fine features are bounded per image by
+    // max(amax(x1) l1_agg1, amax(a2)) -- relu(agg1 x1) and a convex combination of a2 values
+    const unsigned* amax_x1; const unsigned* amax_a2;     // [B] float bits, written by blocks 1 and 2
+    float l1_agg1;     // max over agg1's output channels of sum |w|
+    float ws_h, inv_ws_h;      // power-of-two scale the head's weight fragments were packed with, and its reciprocal
 };
 
 constexpr int SEG_TILES = 4;            // a wave owns one 128-pixel row segment
 constexpr int NT3 = 18, NT4 = 7;        // strip rows a segment can touch: floor(127/8)+... see the bounds below
 
 // rows [tb, tb + NT) of map E (clamped to the last column), interpolated in y, into a wave's LDS strip
+// `c` (a power of two; exact) scales the 64 descriptor rows of the strip, NOT the score share in channel 64
 template <int NT>
-__device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, int Ws, float sy, int y, int tb, int lane)
+__device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, int Ws, float sy, int y, int tb, int lane, float c = 1.0f)
 {
     const float fy = sy * (float)y;
     const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
@@ -1015,8 +966,9 @@ __device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, in
         const int xt = min(tb + t, Ws - 1);
         const float4 u = *reinterpret_cast<const float4*>(E + ((size_t)y0 * Ws + xt) * ESTRIDE + 4 * q);
         const float4 d = *reinterpret_cast<const float4*>(E + ((size_t)y1 * Ws + xt) * ESTRIDE + 4 * q);
+        const float cq = q < 16 ? c : 1.0f;
         float4 o;
-        o.x = hy * u.x + ly * d.x; o.y = hy * u.y + ly * d.y; o.z = hy * u.z + ly * d.z; o.w = hy * u.w + ly * d.w;
+        o.x = (hy * u.x + ly * d.x) * cq; o.y = (hy * u.y + ly * d.y) * cq; o.z = (hy * u.z + ly * d.z) * cq; o.w = (hy * u.w + ly * d.w) * cq;
         *reinterpret_cast<float4*>(V + t * ESTRIDE + 4 * q) = o;
     }
 }
@@ -1026,16 +978,12 @@ __device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, in
 // from the registers that built the features, and step s of the K loop consumes channel 16*(s/8) + 8h + (s%8) from A
 // and B alike (the MFMA does not care which k a lane calls its own, as long as A and B agree).  In the tap steps the
 // lane supplies the weight of pixel p for source column 2s + h.
-// MAP: which image rows the four waves of a workgroup own.
-//   0  four consecutive 128-pixel segments in raster order (r01): vertically adjacent rows sit in different workgroups,
-//      hence on different XCDs, and every a2 row is fetched once per output row that taps it (2.6x read amplification);
-//   1  the SAME 128-pixel column band of four consecutive rows: the <= 3 a2 rows and the 2 E3 / E4 rows those four
-//      output rows tap are fetched once per workgroup (they meet in the CU's L1 / the XCD's L2);
-//   2  as 1, and the workgroups of one XCD (blockIdx.x % 8) walk DOWN a column band, so the a2 row two vertically
-//      adjacent workgroups share is an L2 hit as well.  Needs gridDim.x % 8 == 0 (the host falls back to 1 otherwise).
+// A workgroup's four waves own the SAME 128-pixel column band of four consecutive rows: the <= 3 a2 rows and the 2 E3 / E4
+// rows those rows tap are fetched once per workgroup (they meet in the CU's L1 / the XCD's L2).  (r01's raster-order
+// segments fetched every a2 row once per output row that taps it, 2.6x read amplification; an XCD-contiguous walk down a
+// column band cut the fetches further without moving the time: the kernel is not fetch-bound.)
 // (Measured and rejected, r02: swapping the MFMA operands so that a lane holds four consecutive channels of its pixel and
 // stores 16-byte pieces -- 8 store instructions per tile instead of 32, but each touching 32 lines partially: 32.7 ms.)
-template <int MAP>
 __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
 {
     __shared__ __attribute__((aligned(16))) float Bl[16 * 2 * 64];   // [s][h][out]: head weight of chan(s,h), s < 16
@@ -1063,15 +1011,8 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
     const int tiles_per_row = a.W / 32, segs_per_row = (tiles_per_row + SEG_TILES - 1) / SEG_TILES;
     int y, xs;
     bool live;
-    if (MAP == 0) {
-        const int seg = blockIdx.x * 4 + wv;
-        live = seg < a.H * segs_per_row;
-        y = live ? seg / segs_per_row : 0; xs = live ? (seg - y * segs_per_row) * (32 * SEG_TILES) : 0;
-    } else {
-        const int groups = (a.H + 3) / 4;                       // row groups of four
-        int w = blockIdx.x;
-        if (MAP == 2) { const int per = gridDim.x / 8; w = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
-        const int band = MAP == 2 ? w / groups : w % segs_per_row, grp = MAP == 2 ? w - band * groups : w / segs_per_row;
+    {
+        const int w = blockIdx.x, band = w % segs_per_row, grp = w / segs_per_row;
         y = 4 * grp + wv; xs = band * (32 * SEG_TILES);
         live = y < a.H;
         if (!live) { y = 0; xs = 0; }
@@ -1187,21 +1128,31 @@ __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
     }
 }
 
-template <int MAP, bool PIPE, int WPS = 3>
-__global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
+// Pipelined stores: the 16 row stores of one half-tile are issued BETWEEN the matrix instructions of the other half (and the
+// second half's between the NEXT tile's loads and feature arithmetic), two per MFMA, instead of 32 in one burst at the end: a
+// wave that meets a full store queue then stalls for one queue slot while its MFMAs run, not for the drain of a whole 8 KB
+// burst with the SIMD's other waves doing the same.  (r02 measured the alternatives this replaced -- stores in one burst, four
+// waves per SIMD, no early line touch, plain instead of streaming line touch: all slower; they are gone from the source.)
+// Operand range (r03): the fine features are scaled by the power of two that fits the image's bound (HybArgs), for free --
+// the scale rides on the agg1 weights staged in LDS and on the two y weights of the a2 interpolation; the projected coarse
+// rows are brought to the same units when the strips are built, and the accumulator is scaled back before the store.
+__global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
 {
     __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];         // [hi/lo][(kb, nh, h, n)]: one 16-byte fragment per lane and MFMA
-    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j
-    __shared__ __attribute__((aligned(16))) float Ws[2 * 16];         // [h][s]:       score weight of chan(s,h)
+    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j, times the feature scale
+    __shared__ __attribute__((aligned(16))) float Ws[2 * 16];         // [h][s]:       score weight of chan(s,h), divided by the feature scale
     __shared__ __attribute__((aligned(16))) float V3[4][NT3 * ESTRIDE];
     __shared__ __attribute__((aligned(16))) float V4[4][NT4 * ESTRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
+    const int ef = cm_exp_of(fmaxf(__uint_as_float(a.amax_x1[b]) * a.l1_agg1, __uint_as_float(a.amax_a2[b])));
+    const float scf = cm_scale_of(ef), unf = cm_unscale_of(ef);
+    const float cacc = scf * a.ws_h, unacc = unf * a.inv_ws_h;       // units of the accumulator, and back
     Bh[0][tid] = wh16[tid];
     Bh[1][tid] = wh16[256 + tid];
-    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j]; }
-    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)]; }
+    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j] * scf; }
+    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)] * unf; }
 
     const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
     const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
@@ -1213,11 +1164,8 @@ __global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint
     const int tiles_per_row = a.W / 32, segs_per_row = (tiles_per_row + SEG_TILES - 1) / SEG_TILES;
     int y, xs;
     bool live;
-    {   // workgroup -> four consecutive rows of one 128-pixel column band (see alike_head_hyb, MAP 1 / 2)
-        const int groups = (a.H + 3) / 4;
-        int w = blockIdx.x;
-        if (MAP == 2) { const int per = gridDim.x / 8; w = (blockIdx.x & 7) * per + (blockIdx.x >> 3); }
-        const int band = MAP == 2 ? w / groups : w % segs_per_row, grp = MAP == 2 ? w - band * groups : w / segs_per_row;
+    {   // workgroup -> four consecutive rows of one 128-pixel column band (see alike_head_hyb)
+        const int w = blockIdx.x, band = w % segs_per_row, grp = w / segs_per_row;
         y = 4 * grp + wv; xs = band * (32 * SEG_TILES);
         live = y < a.H;
         if (!live) { y = 0; xs = 0; }
@@ -1235,21 +1183,18 @@ __global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint
         const int ncol = min(W2 - c0, npx / 2 + 2);
         const int lines_a2 = (ncol * 16 + 31) / 32;
         float dummy = 0.f;
-        if (a.pf == 1 && lane < npx / 4) dummy += __builtin_nontemporal_load(x1row + lane * 32);
-        if (a.pf == 2 && lane < npx / 4) dummy += x1row[lane * 32];
+        if (lane < npx / 4) dummy += __builtin_nontemporal_load(x1row + lane * 32);
         const int r = lane >= 34 ? 1 : 0, li = lane - 34 * r;
         const int yy = min(fy0 + r, H2 - 1);
-        if (a.pf && lane < 68 && li < lines_a2) dummy += a2[((size_t)yy * W2 + c0) * 16 + li * 32];
-        if (a.pf && lane + 64 < 68 && lane + 64 - 34 < lines_a2) dummy += a2[((size_t)min(fy0 + 1, H2 - 1) * W2 + c0) * 16 + (lane + 64 - 34) * 32];
+        if (lane < 68 && li < lines_a2) dummy += a2[((size_t)yy * W2 + c0) * 16 + li * 32];
+        if (lane + 64 < 68 && lane + 64 - 34 < lines_a2) dummy += a2[((size_t)min(fy0 + 1, H2 - 1) * W2 + c0) * 16 + (lane + 64 - 34) * 32];
         asm volatile("" :: "v"(dummy));
-    }
-    if (live) {
-        build_strip<NT3>(V3[wv], E3, H8, W8, sy8, y, tb3, lane);
-        build_strip<NT4>(V4[wv], E4, H32, W32, sy32, y, tb4, lane);
+        build_strip<NT3>(V3[wv], E3, H8, W8, sy8, y, tb3, lane, cacc);
+        build_strip<NT4>(V4[wv], E4, H32, W32, sy32, y, tb4, lane, cacc);
     }
     __syncthreads();
 
-    f32x16 pend = {0};                  // PIPE: channels 32..63 of the previous tile, stored under the next tile's feature arithmetic
+    f32x16 pend = {0};                  // channels 32..63 of the previous tile, stored under the next tile's feature arithmetic
     float* pend_d = nullptr;
     bool have = false;
     for (int t = 0; t < ntile; ++t) {
@@ -1260,14 +1205,14 @@ __global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint
         const float4 x1lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8), x1hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
         Up8Taps taps;
         up8ch_load(a2, H2, W2, sy2, sx2, y, x, 8 * h, taps);
-        if (PIPE && have) {
+        if (have) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
         }
         int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
         asm volatile("" : "+v"(z));
         const uint4* Bhz = &Bh[0][0] + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
-        float f[16];
+        float f[16];                            // the fine features, times scf
         {   // group 0: relu(agg1 . x1), outputs 8h..8h+7 (ALike.py:147)
             const float v[8] = {x1lo.x, x1lo.y, x1lo.z, x1lo.w, x1hi.x, x1hi.y, x1hi.z, x1hi.w};
 #pragma unroll
@@ -1281,7 +1226,7 @@ __global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
         }
-        up8ch_lerp(taps, f + 8);      // ALike.py:151
+        up8ch_lerp(taps, f + 8, scf);      // ALike.py:151
 
         const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
         const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;     // tile's first strip row
@@ -1303,103 +1248,61 @@ __global__ __launch_bounds__(256, WPS) void alike_head_f16(HybArgs a, const uint
 
         float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
         f32x16 acc0 = {0}, acc1 = {0};
-        if (!PIPE) {
+        h8v ahi[2], alo[2];
+        split8(f, ahi[0], alo[0]);
+        split8(f + 8, ahi[1], alo[1]);
+        float w3[3], w4[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {        // 16-deep block kb = fine group kb; lane (p, h) supplies channels 8h..8h+7 of it
-                h8v ahi, alo;
-                split8(f + 8 * kb, ahi, alo);
-                const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b1h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]);
-                const h8v b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]), b1l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b0h, acc0, 0, 0, 0);     // small terms first
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, b1h, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b0l, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b1l, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b0h, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, b1h, acc1, 0, 0, 0);
-            }
+        for (int s = 0; s < 3; ++s) { const int k = 2 * s + h; w3[s] = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f); }
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int k = 2 * s + h;
-                const float w = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f);
-                const float b0 = v3[k * ESTRIDE + p], b1 = v3[k * ESTRIDE + 32 + p];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
-            }
+        for (int s = 0; s < 2; ++s) { const int k = 2 * s + h; w4[s] = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f); }
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int k = 2 * s + h;
-                const float w = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f);
-                const float b0 = v4[k * ESTRIDE + p], b1 = v4[k * ESTRIDE + 32 + p];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b1, acc1, 0, 0, 0);
-            }
-            // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  Streaming stores: 40 GB
-            // per launch that nothing re-reads before they have left every cache
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rowp = (r & 3) + 8 * (r >> 2) + 4 * h;
-                __builtin_nontemporal_store(acc0[r], d + (size_t)rowp * 64 + p);
-                __builtin_nontemporal_store(acc1[r], d + (size_t)rowp * 64 + 32 + p);
-            }
-        } else {
-            // Pipelined form: the 16 row stores of one half-tile are issued BETWEEN the matrix instructions of the other half
-            // (and the second half's between the NEXT tile's feature arithmetic), two per MFMA, instead of 32 in one burst
-            // at the end: a wave that meets a full store queue then stalls for one queue slot while its MFMAs run, not for
-            // the drain of a whole 8 KB burst with the SIMD's other waves doing the same.
-            h8v ahi[2], alo[2];
-            split8(f, ahi[0], alo[0]);
-            split8(f + 8, ahi[1], alo[1]);
-            float w3[3], w4[2];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) { const int k = 2 * s + h; w3[s] = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f); }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) { const int k = 2 * s + h; w4[s] = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f); }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[kb], b0h, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0l, acc0, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0h, acc0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], v3[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], v4[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
-            // operands of the second half first, so that nothing but MFMAs and stores remains to be interleaved
-            h8v b1h[2], b1l[2];
-            float t3b[3], t4b[2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { b1h[kb] = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]); b1l[kb] = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]); }
-#pragma unroll
-            for (int s = 0; s < 3; ++s) t3b[s] = v3[(2 * s + h) * ESTRIDE + 32 + p];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) t4b[s] = v4[(2 * s + h) * ESTRIDE + 32 + p];
-            int r = 0;
-#define ST0_2() { const int ra = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r], d + (size_t)ra * 64 + p); ++r; \
-                  const int rb = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r], d + (size_t)rb * 64 + p); ++r; }
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], b1h[1], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1l[1], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1h[1], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[0], t3b[0], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[1], t3b[1], acc1, 0, 0, 0); ST0_2()
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[2], t3b[2], acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], t4b[0], acc1, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], t4b[1], acc1, 0, 0, 0);
-#undef ST0_2
-            // pin the interleaving (the scheduler otherwise gathers the stores into one burst behind the last MFMA)
-            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            pend = acc1; pend_d = d + 32 + p; have = true;
+        for (int kb = 0; kb < 2; ++kb) {        // 16-deep block kb = fine group kb; lane (p, h) supplies channels 8h..8h+7 of it
+            const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[kb], b0h, acc0, 0, 0, 0);     // small terms first
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0l, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0h, acc0, 0, 0, 0);
         }
-    }
-    if (PIPE && have) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
+        for (int s = 0; s < 3; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], v3[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], v4[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
+        // operands of the second half first, so that nothing but MFMAs and stores remains to be interleaved
+        h8v b1h[2], b1l[2];
+        float t3b[3], t4b[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { b1h[kb] = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]); b1l[kb] = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]); }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) t3b[s] = v3[(2 * s + h) * ESTRIDE + 32 + p];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) t4b[s] = v4[(2 * s + h) * ESTRIDE + 32 + p];
+        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  Streaming stores: 40 GB
+        // per launch that nothing re-reads before they have left every cache
+        int r = 0;
+#define ST0_2() { const int ra = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r] * unacc, d + (size_t)ra * 64 + p); ++r; \
+                  const int rb = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r] * unacc, d + (size_t)rb * 64 + p); ++r; }
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], b1h[1], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1l[1], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1h[1], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[0], t3b[0], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[1], t3b[1], acc1, 0, 0, 0); ST0_2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[2], t3b[2], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], t4b[0], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], t4b[1], acc1, 0, 0, 0);
+#undef ST0_2
+        // pin the interleaving (the scheduler otherwise gathers the stores into one burst behind the last MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        pend = acc1; pend_d = d + 32 + p; have = true;
+    }
+    if (have) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
     }
 }
 
@@ -1524,6 +1427,9 @@ namespace {
 struct AlikeNet : kpb_net {
     float *p1 = nullptr, *x1 = nullptr, *t2 = nullptr, *x2 = nullptr, *a2 = nullptr, *t3 = nullptr, *x3 = nullptr, *a3 = nullptr,
           *t4 = nullptr, *x4 = nullptr, *a4 = nullptr, *S2 = nullptr, *S3 = nullptr, *S4 = nullptr, *E3 = nullptr, *E4 = nullptr;
+    // split-f16 form: reciprocal power-of-two weight scales of the custom packs, and the L1 norms / bias maxima behind the
+    // bounds the fused kernels scale their intermediate maps by (conv_mfma.h, cm_scale_of)
+    std::map<std::string, float> k;
     HeadArgs head_args(float* score, float* desc)
     {
         HeadArgs h;
@@ -1551,6 +1457,23 @@ void transpose(const float* w, int co, int ci, std::vector<float>& out)
     for (int o = 0; o < co; ++o)
         for (int c = 0; c < ci; ++c) out[(size_t)c * co + o] = w[(size_t)o * ci + c];
 }
+// max over the `co` output channels of the sum of |w| over the channel's `per` weights, and max |b|
+float l1_rows(const float* w, int co, int per)
+{
+    float m = 0.0f;
+    for (int o = 0; o < co; ++o) {
+        double s = 0.0;
+        for (int i = 0; i < per; ++i) s += std::fabs((double)w[(size_t)o * per + i]);
+        m = std::max(m, (float)(s * (1.0 + 1e-6)));
+    }
+    return m;
+}
+float max_abs(const float* b, int n)
+{
+    float m = 0.0f;
+    for (int i = 0; i < n; ++i) m = std::max(m, std::fabs(b[i]));
+    return m;
+}
 
 template <int CIN, int COUT, int POOL, bool RES, int CDS, int RPOOL, bool DSOUT = false, int TW = 32>
 void launch_conv(kpb_ctx* ctx, const char* name, hipStream_t st, const ConvArgs& a, int B)
@@ -1565,12 +1488,14 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: ALIKE needs H and W multiples of 32 (got %dx%d)", H_, W_);
     const int H = H_, W = W_;
     const size_t P = (size_t)H * W, B = batch;
+    const bool h16 = conv_mfma_use_h16();       // the split-f16 matrix form (default) or the strict fp32 kernels (KPB_FP32_MATRIX=1)
     const size_t n_x1 = B * P * 8, n_2 = B * (P / 4) * 16, n_3 = B * (P / 64) * 32, n_a3 = B * (P / 64) * 16,
                  n_4 = B * (P / 1024) * 64, n_a4 = B * (P / 1024) * 16;
     const size_t n_s = B * (P / 4 + P / 64 + P / 1024) + 64;
     const size_t n_e = desc_out_dev ? B * (P / 64 + P / 1024) * ESTRIDE : 0;
     const size_t n_p1 = B * (P / 4) * 8;
-    const size_t total = n_x1 + n_p1 + 3 * n_2 + 6 * n_3 + n_a3 + 5 * n_4 + n_a4 + n_s + n_e;
+    const size_t n_rng = (2 * B + 63) / 64 * 64;
+    const size_t total = n_x1 + n_p1 + 3 * n_2 + 6 * n_3 + n_a3 + 5 * n_4 + n_a4 + n_s + n_e + n_rng;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
@@ -1586,76 +1511,59 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     S2 = p; p += B * (P / 4); S3 = p; p += B * (P / 64); S4 = p; p += B * (P / 1024) + 64;
     E3 = E4 = nullptr;
     if (desc_out_dev) { E3 = p; p += B * (P / 64) * ESTRIDE; E4 = p; p += B * (P / 1024) * ESTRIDE; }
+    unsigned* amax_x1 = reinterpret_cast<unsigned*>(p);      // [B], [B]: per-image largest x1 / a2 value (float bits), zeroed per forward
+    unsigned* amax_a2 = amax_x1 + B;
+    p += n_rng;
     this->B = batch; this->H = H; this->W = W;
     hipStream_t st = ctx->stream;
 
     Block1Args b1{img_dev, x1, p1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
-    static const int b1h = kpb_env_int("KPB_BLOCK1_H16", 1);
-    if (b1h) {
-        Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c1.pairs")), reinterpret_cast<const uint4*>(wp("b1c2.pairs"))};
-        KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1H_TH), batch), dim3(256), 0, st, hb);
-    } else
-    KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
-
     ConvArgs c;
-    bool p2_valid = false;
-    // block2 @ H/2 (ALike.py:139-140): pool2 fused into the reads
-    c = ConvArgs{p1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};      // pooled by block1
-    static const int h16 = kpb_env_int("KPB_CONV_H16", 1), fuse2 = kpb_env_int("KPB_BLOCK2_FUSED", 1);
-    if (h16 && fuse2) {
-        static const int b34 = kpb_env_int("KPB_BLOCK34_H16", 1);
-        const bool pooled = b34 && conv_mfma_use_h16();     // block 3 then reads the pooled map this kernel leaves
-        p2_valid = pooled;
-        Block2Args b2{p1, x2, a2, S2, pooled ? p2 : nullptr, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
-                      reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2};
+    if (h16) {
+        KPB_HIP(ctx, hipMemsetAsync(amax_x1, 0, 2 * B * sizeof(unsigned), st));
+        Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c1.pairs")), reinterpret_cast<const uint4*>(wp("b1c2.pairs")),
+                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), amax_x1};
+        KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1H_TH), batch), dim3(256), 0, st, hb);
+        // block2 @ H/2 (ALike.py:139-140) + agg2, fused; it hands block 3 the 4 x 4 max-pool of its output (141)
+        Block2Args b2{p1, x2, a2, S2, p2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
+                      reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2,
+                      k.at("b2c1.inv_ws"), k.at("b2c2.inv_ws"), k.at("agg2.inv_ws"), k.at("b2c1.l1"), k.at("b2c1.bmax"), k.at("b2c2.l1"), k.at("b2ds.l1"),
+                      k.at("b2c2.bsummax"), amax_x1, amax_a2};
         KPB_LAUNCH(ctx, "alike_block2", alike_block2, dim3(cdiv(W / 2, 32), cdiv(H / 2, 8), batch), dim3(256), 0, st, b2);
-    } else if (h16) {
-        const dim3 grid(cdiv(W / 2, 32), cdiv(H / 2, 8), batch);
-        H16Args h1{p1, nullptr, t2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), wp("b2c1.b"), H / 2, W / 2};
-        KPB_LAUNCH(ctx, "conv3x3_b2c1", (conv3x3_h16<8, false>), grid, dim3(256), 0, st, h1);
-        H16Args h2{t2, p1, x2, reinterpret_cast<const uint4*>(wp("b2c2.h16")), wp("b2c2.bsum"), H / 2, W / 2};
-        KPB_LAUNCH(ctx, "conv3x3_b2c2", (conv3x3_h16<16, true>), grid, dim3(256), 0, st, h2);
+        // blocks 3 and 4 @ H/8, H/32 (141-144) on conv_mfma_h: conv1 carries the identity branch ds(pooled input) as 32 / 64 more
+        // output channels whose weights sit on the centre tap only (no ReLU on those tiles); conv2 then reads conv1's half of that
+        // buffer and adds the other half.  Block 4's conv1 max-pools x3 4 x 4 while it stages it.
+        auto block_h = [&](const char* n1, const char* n2, const float* in, float* tr, float* xo, int cin, int cout, int Hi, int Wi, bool prepooled) {
+            const std::string k1 = std::string(n1) + ".h", k2 = std::string(n2) + ".wp";
+            ConvM m;
+            m.in = in; m.out = tr; m.wp = wp(k1.c_str()); m.bias = wp((std::string(n1) + ".hb").c_str()); m.xf = nullptr; m.active = nullptr; m.res = nullptr;
+            m.Hi = prepooled ? Hi / 4 : Hi; m.Wi = prepooled ? Wi / 4 : Wi; m.H = Hi / 4; m.W = Wi / 4;
+            m.CIN = cin; m.COUT = 2 * cout; m.NCH = 1; m.relu = 2; m.relu_nt = cout / 32;
+            m.nblk = cout / 32; m.istride = cin; m.ostride = 2 * cout; m.ooff = 0;
+            m.unscale = 1.0f / wscale.at(k1);
+            const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
+            // small layers are bound by per-workgroup latency: 8-row tiles (r02: b3c1 0.36 -> 0.32 ms, b3c2 0.58 -> 0.49 ms)
+            if (prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+            else KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 2, 2, false, 4>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk), dim3(256), 0, st, m);
+            ConvM c2;
+            c2.in = tr; c2.out = xo; c2.wp = wp(k2.c_str()); c2.bias = wp((std::string(n2) + ".bp").c_str()); c2.xf = nullptr; c2.active = nullptr;
+            c2.res = tr + cout; c2.rstride = 2 * cout;
+            c2.Hi = Hi / 4; c2.Wi = Wi / 4; c2.H = Hi / 4; c2.W = Wi / 4; c2.CIN = cout; c2.COUT = cout; c2.NCH = cout / 32; c2.relu = 0; c2.nblk = 1;
+            c2.istride = 2 * cout; c2.ostride = cout; c2.ooff = 0;
+            c2.unscale = 1.0f / wscale.at(k2);
+            if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch), dim3(256), 0, st, c2);
+            else KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 16), batch), dim3(256), 0, st, c2);
+        };
+        block_h("b3c1", "b3c2", p2, t3r3, x3, 16, 32, H / 2, W / 2, true);
+        block_h("b4c1", "b4c2", x3, t4r4, x4, 32, 64, H / 8, W / 8, false);
     } else {
+        // strict fp32: block 1 and the 3x3 convolutions on the fp32 vector ALUs, conv2 of blocks 3 / 4 on the fp32 MFMA
+        KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
+        c = ConvArgs{p1, t2, wp("b2c1.w"), wp("b2c1.b"), nullptr, nullptr, nullptr, nullptr, H / 2, W / 2};      // pooled by block1
         launch_conv<8, 16, 1, false, 4, 1>(ctx, "conv3x3_b2c1", st, c, batch);
         c = ConvArgs{t2, x2, wp("b2c2.w"), wp("b2c2.b"), p1, wp("b2ds.w"), wp("b2ds.b"), nullptr, H / 2, W / 2};
         launch_conv<16, 16, 1, true, 8, 1>(ctx, "conv3x3_b2c2", st, c, batch);
-    }
-    // blocks 3 and 4 @ H/8, H/32 (141-144).  conv_mfma_h form: conv1 reads the previous block's output max-pooled 4 x 4 while it
-    // stages it, and carries the identity branch ds(pooled input) as 32 / 64 more output channels whose weights sit on the
-    // centre tap only (no ReLU on those tiles); conv2 then reads conv1's half of that buffer and adds the other half.
-    static const int b34h = kpb_env_int("KPB_BLOCK34_H16", 1);
-    auto block_h = [&](const char* n1, const char* n2, const float* in, float* tr, float* xo, int cin, int cout, int Hi, int Wi, bool prepooled) {
-        const std::string k1 = std::string(n1) + ".h", k2 = std::string(n2) + ".wp";
-        ConvM m;
-        m.in = in; m.out = tr; m.wp = wp(k1.c_str()); m.bias = wp((std::string(n1) + ".hb").c_str()); m.xf = nullptr; m.active = nullptr; m.res = nullptr;
-        m.Hi = prepooled ? Hi / 4 : Hi; m.Wi = prepooled ? Wi / 4 : Wi; m.H = Hi / 4; m.W = Wi / 4;
-        m.CIN = cin; m.COUT = 2 * cout; m.NCH = 1; m.relu = 2; m.relu_nt = cout / 32;
-        m.nblk = cout / 32; m.istride = cin; m.ostride = 2 * cout; m.ooff = 0;
-        m.unscale = 1.0f / (ACT_SCALE * wscale.at(k1));
-        const dim3 grid(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk);
-        const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
-        static const int c1mt1 = kpb_env_int("KPB_B3C1_MT1", 1);      // a small layer: 8-row tiles (0.36 -> 0.32 ms)
-        if (cin == 16 && prepooled && c1mt1) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
-        else if (cin == 16 && prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 2>), grid, dim3(256), 0, st, m);
-        else if (cin == 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, true, false, false, 2, 2, false, 4>), grid, dim3(256), 0, st, m);
-        else KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 2, 2, false, 4>), grid, dim3(256), 0, st, m);
-        ConvM c2;
-        c2.in = tr; c2.out = xo; c2.wp = wp(k2.c_str()); c2.bias = wp((std::string(n2) + ".bp").c_str()); c2.xf = nullptr; c2.active = nullptr;
-        c2.res = tr + cout; c2.rstride = 2 * cout;
-        c2.Hi = Hi / 4; c2.Wi = Wi / 4; c2.H = Hi / 4; c2.W = Wi / 4; c2.CIN = cout; c2.COUT = cout; c2.NCH = cout / 32; c2.relu = 0; c2.nblk = 1;
-        c2.istride = 2 * cout; c2.ostride = cout; c2.ooff = 0;
-        c2.unscale = 1.0f / (ACT_SCALE * wscale.at(k2));
-        const dim3 g2(cdiv(c2.W, 16), cdiv(c2.H, 16), batch);
-        static const int mt1 = kpb_env_int("KPB_B3C2_MT1", 1);      // a one-tile layer: 8-row tiles, five workgroups per CU (0.58 -> 0.49 ms)
-        if (cout == 32 && mt1) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch), dim3(256), 0, st, c2);
-        else if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), g2, dim3(256), 0, st, c2);
-        else KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, dim3(256), 0, st, c2);
-    };
-    if (b34h && conv_mfma_use_h16()) {
-        block_h("b3c1", "b3c2", p2_valid ? p2 : x2, t3r3, x3, 16, 32, H / 2, W / 2, p2_valid);
-        block_h("b4c1", "b4c2", x3, t4r4, x4, 32, 64, H / 8, W / 8, false);
-    } else {
-    // block3 @ H/8 (141-142): pool4
+        // block3 @ H/8 (141-142): pool4
         c = ConvArgs{x2, t3, wp("b3c1.w"), wp("b3c1.b"), nullptr, wp("b3ds.w"), wp("b3ds.b"), r3, H / 8, W / 8};
         launch_conv<16, 32, 4, false, 4, 1, true, 16>(ctx, "conv3x3_b3c1", st, c, batch);        // 80 columns at 480x640: 16-wide tiles divide them
         {   // conv2 of block3 on the MFMA kernel, identity branch precomputed (ALike.py:72-80)
@@ -1663,11 +1571,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             m.in = t3; m.out = x3; m.wp = wp("b3c2.wp"); m.bias = wp("b3c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r3;
             m.Hi = H / 8; m.Wi = W / 8; m.H = H / 8; m.W = W / 8; m.CIN = 32; m.COUT = 32; m.NCH = 1; m.relu = 0; m.nblk = 1;
             m.istride = 32; m.ostride = 32; m.ooff = 0;
-            if (conv_mfma_use_h16()) {
-                m.unscale = 1.0f / (ACT_SCALE * wscale.at("b3c2.wp"));
-                KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
-            } else
-                KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+            KPB_LAUNCH(ctx, "conv3x3_b3c2", (conv_mfma<3, 1, 32, false, false, false, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
         }
         // block4 @ H/32 (143-144): pool4
         c = ConvArgs{x3, t4, wp("b4c1.w"), wp("b4c1.b"), nullptr, wp("b4ds.w"), wp("b4ds.b"), r4, H / 32, W / 32};
@@ -1677,40 +1581,23 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             m.in = t4; m.out = x4; m.wp = wp("b4c2.wp"); m.bias = wp("b4c2.bp"); m.xf = nullptr; m.active = nullptr; m.res = r4;
             m.Hi = H / 32; m.Wi = W / 32; m.H = H / 32; m.W = W / 32; m.CIN = 64; m.COUT = 64; m.NCH = 2; m.relu = 0; m.nblk = 1;
             m.istride = 64; m.ostride = 64; m.ooff = 0;
-            if (conv_mfma_use_h16()) {
-                m.unscale = 1.0f / (ACT_SCALE * wscale.at("b4c2.wp"));
-                KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch), dim3(256), 0, st, m);
-            } else
-                KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
+            KPB_LAUNCH(ctx, "conv3x3_b4c2", (conv_mfma<3, 1, 32, false, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch), dim3(256), 0, st, m);
         }
-    }
-    // aggregation 1x1 + ReLU (147-150), each with its share of the score logit; agg1 is fused into the head
-    if (!(h16 && fuse2))
+        // aggregation 1x1 + ReLU of block 2 (147-148); agg1 is fused into the head
         KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4, nullptr, nullptr);
+    }
+    // aggregation 1x1 + ReLU (149-150), each with its share of the score logit and -- dense mode -- of every head row
     KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64, wp("head.wT") + 32 * 64, E3);
     KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
     // upsample + concat + head (151-162)
     if (desc_out_dev) {
-        static const int pf_env = kpb_env_int("KPB_HEAD_PF", 1);
-        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W, pf_env};
-        const int segs_per_row = cdiv(W / 32, SEG_TILES);
-        const int segs = H * segs_per_row, work4 = cdiv(H, 4) * segs_per_row;
-        // measured choices (r02, 512 images of 480x640): row-group mapping 1, split-f16 fine groups, interleaved stores
-        static const int map_env = kpb_env_int("KPB_HEAD_MAP", 1), f16 = kpb_env_int("KPB_HEAD_F16", 1), pipe = kpb_env_int("KPB_HEAD_PIPE", 1);
-        int map = map_env;
-        if (map == 2 && work4 % 8 != 0) map = 1;
-        if (f16 && map != 0) {
-            const uint4* wh16 = reinterpret_cast<const uint4*>(wp("head.wh16"));
-            static const int wps = kpb_env_int("KPB_HEAD_WPS", 3);
-            if (wps == 4 && map == 1 && !pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, false, 4>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
-            else if (wps == 4 && map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, true, 4>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
-            else if (map == 1 && !pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
-            else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<1, true>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
-            else if (!pipe) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<2, false>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
-            else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_f16<2, true>), dim3(work4, batch), dim3(256), 0, st, hy, wh16);
-        } else if (map == 0) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<0>), dim3(cdiv(segs, 4), batch), dim3(256), 0, st, hy);
-        else if (map == 1) KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<1>), dim3(work4, batch), dim3(256), 0, st, hy);
-        else KPB_LAUNCH(ctx, "alike_head_dense", (alike_head_hyb<2>), dim3(work4, batch), dim3(256), 0, st, hy);
+        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W, amax_x1, amax_a2, 0.f, 1.f, 1.f};
+        const int work4 = cdiv(H, 4) * cdiv(W / 32, SEG_TILES);     // four consecutive rows of one 128-pixel column band per workgroup
+        if (h16) {
+            hy.l1_agg1 = k.at("agg1.l1"); hy.inv_ws_h = k.at("head.inv_ws"); hy.ws_h = 1.0f / hy.inv_ws_h;
+            KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16, dim3(work4, batch), dim3(256), 0, st, hy, reinterpret_cast<const uint4*>(wp("head.wh16")));
+        } else
+            KPB_LAUNCH(ctx, "alike_head_dense", alike_head_hyb, dim3(work4, batch), dim3(256), 0, st, hy);
     } else {
         LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W};
         KPB_LAUNCH(ctx, "alike_head_score", alike_score_lin, dim3(cdiv(H * W, 256), batch), dim3(256), 0, st, la);
@@ -1756,8 +1643,15 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         ws.put("b1c1.w", tmp);
         ws.put_raw("b1c1.b", bl.get("b1c1.b", {c1}), 8);
         repack3x3(bl.get("b1c2.w", {c1, c1, 3, 3}), 8, 8, tmp); ws.put("b1c2.w", tmp);
-        ws.put("b1c2.pairs", pack_b1c2_pairs(bl.get("b1c2.w", {c1, c1, 3, 3})));
-        ws.put("b1c1.pairs", pack_b1c1_pairs(bl.get("b1c1.w", {c1, 3, 3, 3})));
+        {   // split-f16 fragments, each pack scaled to max |w| in [2^12, 2^13), and the constants of conv1's output bound
+            const float* w1 = bl.get("b1c1.w", {c1, 3, 3, 3});
+            const float* w2 = bl.get("b1c2.w", {c1, c1, 3, 3});
+            const float s1 = weight_scale_h(w1, 8 * 27), s2 = weight_scale_h(w2, 8 * 72);
+            ws.put("b1c1.pairs", pack_b1c1_pairs(w1, s1));
+            ws.put("b1c2.pairs", pack_b1c2_pairs(w2, s2));
+            net->k["b1c1.inv_ws"] = 1.0f / s1; net->k["b1c2.inv_ws"] = 1.0f / s2;
+            net->k["b1c1.l1"] = l1_rows(w1, 8, 27); net->k["b1c1.bmax"] = max_abs(bl.get("b1c1.b", {c1}), 8);
+        }
         ws.put_raw("b1c2.b", bl.get("b1c2.b", {c1}), 8);
     }
     const uint32_t ch[5] = {0, c1, c2, c3, c4};
@@ -1772,14 +1666,25 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         snprintf(nm, 16, "b%dds.b", i); ws.put_raw(nm, bl.get(nm, {co}), co);
     }
     {   // block 2 on the split-f16 MFMA kernel: fragments + combined biases
-        ws.put("b2c1.h16", pack_h16(bl.get("b2c1.w", {c2, c1, 3, 3}), 8, nullptr));
-        ws.put("b2c2.h16", pack_h16(bl.get("b2c2.w", {c2, c2, 3, 3}), 16, bl.get("b2ds.w", {c2, c1})));
+        const float* w1 = bl.get("b2c1.w", {c2, c1, 3, 3});
+        const float* w2 = bl.get("b2c2.w", {c2, c2, 3, 3});
+        const float* wd = bl.get("b2ds.w", {c2, c1});
+        const float* wa = bl.get("agg2.w", {dim / 4, c2});
+        const float s1 = weight_scale_h(w1, 16 * 72);
+        const float s2 = std::min(weight_scale_h(w2, 16 * 144), weight_scale_h(wd, 16 * 8));     // conv2 and the identity branch share one accumulation
+        const float sa = weight_scale_h(wa, 16 * 16);
+        ws.put("b2c1.h16", pack_h16(w1, 8, nullptr, s1));
+        ws.put("b2c2.h16", pack_h16(w2, 16, wd, s2));
         const float* b2 = bl.get("b2c2.b", {c2});
         const float* bd = bl.get("b2ds.b", {c2});
         tmp.assign(16, 0.f);
         for (int i = 0; i < 16; ++i) tmp[i] = b2[i] + bd[i];
         ws.put("b2c2.bsum", tmp);
-        ws.put("agg2.h16", pack_1x1_h16(bl.get("agg2.w", {dim / 4, c2})));
+        ws.put("agg2.h16", pack_1x1_h16(wa, sa));
+        net->k["b2c1.inv_ws"] = 1.0f / s1; net->k["b2c2.inv_ws"] = 1.0f / s2; net->k["agg2.inv_ws"] = 1.0f / sa;
+        net->k["b2c1.l1"] = l1_rows(w1, 16, 72); net->k["b2c1.bmax"] = max_abs(bl.get("b2c1.b", {c2}), 16);
+        net->k["b2c2.l1"] = l1_rows(w2, 16, 144); net->k["b2ds.l1"] = l1_rows(wd, 16, 8); net->k["b2c2.bsummax"] = max_abs(tmp.data(), 16);
+        net->k["agg1.l1"] = l1_rows(bl.get("agg1.w", {dim / 4, c1}), 16, 8);
     }
     auto put_mfma = [&](const char* name, const float* w, int cout, int cin, int ntb) {
         if (conv_mfma_use_h16()) {
@@ -1823,9 +1728,14 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         ws.put_raw("head.ws", hw + 64 * 64, 64);
         // split-f16 fragments of the fine-group rows (alike_head_f16): [hi/lo][kb][nh][h][n][j] halves,
         // value = head.w[o = 32 nh + n][c = 16 kb + 8 h + j]; hi = f16(w) toward zero, lo = f16(w - hi)
+        // (rows 0..63 x channels 0..31: the part this pack carries sets its power-of-two scale)
+        float hmax = 0.0f;
+        for (int o = 0; o < 64; ++o) for (int cc = 0; cc < 32; ++cc) hmax = std::max(hmax, std::fabs(hw[o * 64 + cc]));
+        const float sh = weight_scale_h(&hmax, 1);
+        net->k["head.inv_ws"] = 1.0f / sh;
         std::vector<uint16_t> hl(2 * 2 * 2 * 2 * 32 * 8);
         for (int kb = 0; kb < 2; ++kb) for (int nh = 0; nh < 2; ++nh) for (int hh = 0; hh < 2; ++hh) for (int n = 0; n < 32; ++n) for (int j = 0; j < 8; ++j) {
-            const float w = hw[(32 * nh + n) * 64 + 16 * kb + 8 * hh + j];
+            const float w = hw[(32 * nh + n) * 64 + 16 * kb + 8 * hh + j] * sh;
             _Float16 hi = (_Float16)w;
             if (fabsf((float)hi) > fabsf(w)) {          // the cast rounds to nearest: step back toward zero
                 uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2);

@@ -23,10 +23,10 @@ struct ConvM {
     const float* res;   // optional [B][H][W][COUT] added before the ReLU (ALIKE ResBlock identity branch, ALike.py:76-79)
     int Hi, Wi, H, W, CIN, COUT, NCH, relu, nblk;
     int istride, ostride, ooff;   // floats between consecutive input / output pixels, channel offset of the output
-    float unscale = 1.0f;         // conv_mfma_h: 1 / (ACT_SCALE x the layer's weight scale)
+    float unscale = 1.0f;         // conv_mfma_h / gemm_h: 1 / (the layer's power-of-two weight scale)
     int relu_nt = 0;              // conv_mfma_h with relu == 2: only the first relu_nt 32-wide output tiles get the ReLU
     int rstride = 0;              // floats between consecutive pixels of `res` (0: COUT)
-    const float* xw = nullptr;    // conv_mfma_h<XC>: [tap][CIN] fp32 weights / ACT_SCALE of ONE extra output channel (index xco) taken on the VALU
+    const float* xw = nullptr;    // conv_mfma_h<XC>: [tap][CIN] fp32 weights of ONE extra output channel (index xco) taken on the VALU
     float xb = 0.0f;              // its bias
     int xco = 0;
 };
@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 // (x - hi is exact in fp32), and each product taken as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_f16
 // with fp32 accumulation: three f16 MFMAs cover K = 16 in 96 cycles where the fp32 instruction needs 512, and the
 // dropped a_lo*b_lo term is <= 2^-22 of the product.  Both operands are scaled by powers of two first so that the lo
-// halves stay out of the f16 subnormals: the weights per layer to max|w| in [2^12, 2^13) at pack time, the activations
-// by ACT_SCALE when they are staged (exact), and the accumulator is scaled back in the epilogue (ConvM::unscale).
-// Activations beyond 65504 / ACT_SCALE = 4094 would saturate; image-normalised feature maps are orders below that.
+// halves stay out of the f16 subnormals and the hi halves below saturation: the weights per layer to max|w| in [2^12, 2^13)
+// at pack time, the activations per workgroup and slab by the power of two that fits the largest magnitude of the slab being
+// staged (cm_scale_of; the accumulator is rescaled -- exactly -- when a later slab needs a smaller scale), and the
+// accumulator is scaled back in the epilogue (ConvM::unscale = 1 / weight scale, times the activation unscale).
 //
 // LDS: one image [IH][IW] of pixels, each [hi: CC halves | lo: CC halves | 16 bytes pad] = 4*CC + 16 bytes = an odd number
 // of 16-byte slots, rows padded to a multiple of 256 bytes.  A ds_read_b128 is served in 16-lane groups (lanes {0-3, 12-15,
@@ -179,7 +180,6 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 // L2-resident) MT times.
 typedef _Float16 cm_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
-constexpr float ACT_SCALE = 16.0f;
 
 __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
 {
@@ -188,6 +188,32 @@ __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
     const cm_h2 d = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.z - (float)b[0], v.w - (float)b[1]));
     hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
     lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
+
+// ---- dynamic operand range (r03).  A split operand is exact to ~2^-22 only while its hi half does not saturate (|x| < 65504)
+// and its lo half stays a normal f16 (|x| >= 2^-3): a FIXED activation scale therefore fails silently on tensors far from
+// the range it was chosen for.  Every split site now measures (or rigorously bounds) the largest magnitude `amax` of what it
+// is about to split and scales by the power of two that puts amax in [2^14, 2^15); the scale is divided out of the fp32
+// accumulator again, exactly.  Values down to 2^-17 amax keep full precision, smaller ones an absolute error <= 2^-38 amax.
+// Non-finite data stays non-finite (the scale is clamped, never inf or zero).
+__device__ __forceinline__ int cm_exp_of(float amax)           // clamped exponent field: amax < 2^(e - 126)
+{
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    return min(max(e, 24), 230);
+}
+__device__ __forceinline__ float cm_scale_of(int e) { return __uint_as_float((unsigned)(268 - e) << 23); }     // 2^(141 - e): amax * scale < 2^15
+__device__ __forceinline__ float cm_unscale_of(int e) { return __uint_as_float((unsigned)(e - 14) << 23); }    // its reciprocal
+__device__ __forceinline__ float cm_pow2(int d) { return __uint_as_float((unsigned)(127 + d) << 23); }         // 2^d, |d| <= 126
+
+__device__ __forceinline__ float cm_amax4(float m, const float4 v)
+{
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+__device__ __forceinline__ float cm_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
 }
 
 // XC: one more output channel than the tiles hold (DISK's 129 = 4 x 32 + 1) is accumulated on the VALU from the same LDS
@@ -223,7 +249,9 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
     const size_t ntile_stride = (size_t)T * a.NCH * NKB * 4 * 32;
 
     static_assert(!XC || (MT == 2 && S == 1 && !POOL_OUT), "conv_mfma_h: the extra channel maps one pixel of a 16x16 tile to each thread");
+    __shared__ __attribute__((aligned(16))) float s_amax[4];       // the four waves' largest staged magnitude of the slab in flight
     float xacc = 0.0f;
+    int e_cur = 24;              // exponent the accumulators' activation scale belongs to (workgroup-uniform)
     f32x16 acc[MT][NTB];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -232,42 +260,62 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
     for (int ch = 0; ch < a.NCH; ++ch) {
+        float4 buf[NLD];
+        float amax = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int idx = tid + k * 256;
+            const int pix = idx / Q, q = idx - pix * Q;
+            const int y = pix / IW, x = pix - y * IW;
+            const int gy = iy0 + y, gx = ix0 + x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < IH * IW * Q && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
+                if (POOL_IN) {
+                    const float* s = in + ((size_t)(PF * gy) * a.Wi + PF * gx) * a.istride + ch * CC + 4 * q;
+                    v = *reinterpret_cast<const float4*>(s);
+#pragma unroll
+                    for (int py = 0; py < PF; ++py)
+#pragma unroll
+                        for (int px = 0; px < PF; ++px) {
+                            if (py == 0 && px == 0) continue;
+                            const float4 w4 = *reinterpret_cast<const float4*>(s + ((size_t)py * a.Wi + px) * a.istride);
+                            v.x = fmaxf(v.x, w4.x); v.y = fmaxf(v.y, w4.y); v.z = fmaxf(v.z, w4.z); v.w = fmaxf(v.w, w4.w);
+                        }
+                } else {
+                    v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.istride + ch * CC + 4 * q);
+                }
+                if (XF) {
+                    const float4* t4 = reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + ch * CC + 4 * q) * 4);
+                    const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+                    v.x = fmaf(v.x, t0.x, t0.y); v.x = v.x >= 0.0f ? v.x : v.x * t0.z;
+                    v.y = fmaf(v.y, t1.x, t1.y); v.y = v.y >= 0.0f ? v.y : v.y * t1.z;
+                    v.z = fmaf(v.z, t2.x, t2.y); v.z = v.z >= 0.0f ? v.z : v.z * t2.z;
+                    v.w = fmaf(v.w, t3.x, t3.y); v.w = v.w >= 0.0f ? v.w : v.w * t3.z;
+                }
+            }
+            buf[k] = v;
+            amax = cm_amax4(amax, v);
+        }
+        amax = cm_wave_max(amax);
+        if (lane == 0) s_amax[wv] = amax;
+        // ONE barrier serves two purposes: the previous slab's taps are done with the tile, and the four wave maxima are
+        // visible.  (The global loads above were issued before it: they touch registers only.)
         __syncthreads();
         {
-            float4 buf[NLD];
+            const float4 am = *reinterpret_cast<const float4*>(s_amax);
+            const int e_new = cm_exp_of(fmaxf(fmaxf(am.x, am.y), fmaxf(am.z, am.w)));
+            if (ch == 0) e_cur = e_new;
+            else if (e_new > e_cur) {           // this slab needs a smaller scale: bring what has been accumulated down to it (exact)
+                const float f = cm_pow2(e_cur - e_new);
 #pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int idx = tid + k * 256;
-                const int pix = idx / Q, q = idx - pix * Q;
-                const int y = pix / IW, x = pix - y * IW;
-                const int gy = iy0 + y, gx = ix0 + x;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (idx < IH * IW * Q && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
-                    if (POOL_IN) {
-                        const float* s = in + ((size_t)(PF * gy) * a.Wi + PF * gx) * a.istride + ch * CC + 4 * q;
-                        v = *reinterpret_cast<const float4*>(s);
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int py = 0; py < PF; ++py)
+                    for (int n = 0; n < NTB; ++n)
 #pragma unroll
-                            for (int px = 0; px < PF; ++px) {
-                                if (py == 0 && px == 0) continue;
-                                const float4 w4 = *reinterpret_cast<const float4*>(s + ((size_t)py * a.Wi + px) * a.istride);
-                                v.x = fmaxf(v.x, w4.x); v.y = fmaxf(v.y, w4.y); v.z = fmaxf(v.z, w4.z); v.w = fmaxf(v.w, w4.w);
-                            }
-                    } else {
-                        v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.istride + ch * CC + 4 * q);
-                    }
-                    if (XF) {
-                        const float4* t4 = reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + ch * CC + 4 * q) * 4);
-                        const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
-                        v.x = fmaf(v.x, t0.x, t0.y); v.x = v.x >= 0.0f ? v.x : v.x * t0.z;
-                        v.y = fmaf(v.y, t1.x, t1.y); v.y = v.y >= 0.0f ? v.y : v.y * t1.z;
-                        v.z = fmaf(v.z, t2.x, t2.y); v.z = v.z >= 0.0f ? v.z : v.z * t2.z;
-                        v.w = fmaf(v.w, t3.x, t3.y); v.w = v.w >= 0.0f ? v.w : v.w * t3.z;
-                    }
-                }
-                buf[k] = v;
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] *= f;
+                e_cur = e_new;
             }
+            const float sc = cm_scale_of(e_cur);
 #pragma unroll
             for (int k = 0; k < NLD; ++k) {
                 const int idx = tid + k * 256;
@@ -275,13 +323,14 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                 if (idx < IH * IW * Q) {
                     const int y = pix / IW, x = pix - y * IW;
                     uint2 hi, lo;
-                    cm_split4(make_float4(buf[k].x * ACT_SCALE, buf[k].y * ACT_SCALE, buf[k].z * ACT_SCALE, buf[k].w * ACT_SCALE), hi, lo);
+                    cm_split4(make_float4(buf[k].x * sc, buf[k].y * sc, buf[k].z * sc, buf[k].w * sc), hi, lo);
                     *reinterpret_cast<uint2*>(&tile[y * ROWP + x * PITCH + 8 * q]) = hi;
                     *reinterpret_cast<uint2*>(&tile[y * ROWP + x * PITCH + LO + 8 * q]) = lo;
                 }
             }
         }
         __syncthreads();
+        float xpart = 0.0f;      // XC: this slab's share of the extra channel, in the slab's activation scale
 #pragma unroll 1
         for (int tap = 0; tap < T; ++tap) {
             const int ky = tap / KS, kx = tap - ky * KS;
@@ -322,10 +371,11 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
                     const cm_h8 vh = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + 16 * q));
                     const cm_h8 vl = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + LO + 16 * q));
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xacc = fmaf((float)vh[e] + (float)vl[e], xw[8 * q + e], xacc);
+                    for (int e = 0; e < 8; ++e) xpart = fmaf((float)vh[e] + (float)vl[e], xw[8 * q + e], xpart);
                 }
             }
         }
+        if (XC && nb == 0) xacc = fmaf(xpart, cm_unscale_of(e_cur), xacc);
     }
     if (XC && nb == 0) {
         const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
@@ -335,8 +385,9 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
             a.out[(size_t)b * a.H * a.W * a.ostride + a.ooff + ((size_t)gy * a.W + gx) * a.ostride + a.xco] = o;
         }
     }
+    const float unscale = a.unscale * cm_unscale_of(e_cur);      // weight scale and activation scale, both powers of two
 
-    // epilogue: as conv_mfma, per M tile; the accumulator carries ACT_SCALE x the layer's weight scale
+    // epilogue: as conv_mfma, per M tile; the accumulator carries the layer's weight scale x the activation scale of e_cur
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int trow = 2 * (wv * MT + m);          // first of the tile's two output rows inside the workgroup tile
@@ -347,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                v[r] = fmaf(acc[m][n][r], a.unscale, bias);
+                v[r] = fmaf(acc[m][n][r], unscale, bias);
                 if (a.relu == 1 || (a.relu == 2 && nt0 + n < a.relu_nt)) v[r] = relu(v[r]);
             }
             if (co >= a.COUT) continue;
@@ -395,15 +446,20 @@ __global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
 template <int NTB, int MT = 2>
 __global__ __launch_bounds__(256) void gemm_h(ConvM a)
 {
-    constexpr int CC = 32, KC = 16, NKB = 2, Q = CC / 4, PITCH = 4 * CC + 16, LO = 2 * CC, ROWS = 128 * MT, BUF = ROWS * PITCH, NLD = ROWS * Q / 256;
-    __shared__ __attribute__((aligned(256))) unsigned char tile[2 * BUF];
+    // r03: a wave stages exactly the 32 MT rows it multiplies, so its slice of the LDS buffers is private to it (a wave's LDS
+    // operations execute in order: no barrier anywhere in the kernel) and the activation scale is chosen PER WAVE from the
+    // largest magnitude of the slab it is staging (see cm_scale_of).
+    constexpr int CC = 32, KC = 16, NKB = 2, Q = CC / 4, PITCH = 4 * CC + 16, LO = 2 * CC, WROWS = 32 * MT, ROWS = 4 * WROWS, WBUF = WROWS * PITCH,
+                  NLD = WROWS * Q / 64;
+    __shared__ __attribute__((aligned(256))) unsigned char tile[2 * 4 * WBUF];     // [buffer][wave][row][hi | lo | pad]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
     if (a.active && !a.active[b]) return;
-    const int nrows = a.H * a.W, r0 = blockIdx.x * ROWS;
+    const int nrows = a.H * a.W, r0 = blockIdx.x * ROWS + WROWS * wv;          // this wave's first row
     const float* in = a.in + (size_t)b * nrows * a.istride;
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)a.NCH * NKB * 4 * 32;
+    unsigned char* wt = tile + wv * WBUF;
 
     f32x16 acc[MT][NTB];
 #pragma unroll
@@ -414,28 +470,44 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
     float4 buf[NLD];
+    int e_cur = 24;
     auto fetch = [&](int ch) {
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256, row = idx / Q, q = idx - row * Q;
+            const int idx = lane + k * 64, row = idx / Q, q = idx - row * Q;
             buf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r0 + row < nrows) buf[k] = *reinterpret_cast<const float4*>(in + (size_t)(r0 + row) * a.istride + ch * CC + 4 * q);
         }
     };
-    auto stage = [&](int which) {
-        unsigned char* t = tile + which * BUF;
+    auto stage = [&](int which, bool first) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) amax = cm_amax4(amax, buf[k]);
+        const int e_new = cm_exp_of(cm_wave_max(amax));
+        if (first) e_cur = e_new;
+        else if (e_new > e_cur) {              // this slab needs a smaller scale: bring the accumulators down to it (exact)
+            const float f = cm_pow2(e_cur - e_new);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] *= f;
+            e_cur = e_new;
+        }
+        const float sc = cm_scale_of(e_cur);
+        unsigned char* t = wt + which * 4 * WBUF;
 #pragma unroll
         for (int k = 0; k < NLD; ++k) {
-            const int idx = tid + k * 256, row = idx / Q, q = idx - row * Q;
+            const int idx = lane + k * 64, row = idx / Q, q = idx - row * Q;
             uint2 hi, lo;
-            cm_split4(make_float4(buf[k].x * ACT_SCALE, buf[k].y * ACT_SCALE, buf[k].z * ACT_SCALE, buf[k].w * ACT_SCALE), hi, lo);
+            cm_split4(make_float4(buf[k].x * sc, buf[k].y * sc, buf[k].z * sc, buf[k].w * sc), hi, lo);
             *reinterpret_cast<uint2*>(&t[row * PITCH + 8 * q]) = hi;
             *reinterpret_cast<uint2*>(&t[row * PITCH + LO + 8 * q]) = lo;
         }
     };
     fetch(0);
-    stage(0);
-    __syncthreads();
+    stage(0, true);
     // (Also requesting the next slab's weight fragments a slab ahead costs 94 more VGPRs and the second wave per SIMD: 1.7x slower.)
     for (int ch = 0; ch < a.NCH; ++ch) {
         const bool more = ch + 1 < a.NCH;
@@ -449,10 +521,10 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
                 Bh[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 0) * 32]);
                 Bl[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 2) * 32]);
             }
-        const unsigned char* t = tile + (ch & 1) * BUF;
+        const unsigned char* t = wt + (ch & 1) * 4 * WBUF;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            const unsigned char* ap = t + (32 * MT * wv + 32 * m + p) * PITCH + h * KC * 2;
+            const unsigned char* ap = t + (32 * m + p) * PITCH + h * KC * 2;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
@@ -469,10 +541,10 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bl[n][kb], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
                 }
-        if (more) stage((ch + 1) & 1);      // the other buffer: its last readers passed the barrier of slab ch - 1
-        __syncthreads();
+        if (more) stage((ch + 1) & 1, false);      // the wave's other buffer
     }
 
+    const float unscale = a.unscale * cm_unscale_of(e_cur);
     float* out = a.out + (size_t)b * nrows * a.ostride + a.ooff;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -483,8 +555,8 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
             if (co >= a.COUT) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = r0 + 32 * MT * wv + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = fmaf(acc[m][n][r], a.unscale, bias);
+                const int row = r0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = fmaf(acc[m][n][r], unscale, bias);
                 if (a.relu) v = relu(v);
                 if (row < nrows) out[(size_t)row * a.ostride + co] = v;
             }
@@ -550,11 +622,13 @@ std::vector<float> pack_mfma_h(const float* w, int COUT, int CIN, int KS, int CC
     return f;
 }
 
-// measured default (r02): the split-f16 form; KPB_CONVM_H16=0 brings back the fp32 MFMA kernels for comparison
+// The split-f16 matrix form is the product; KPB_FP32_MATRIX=1 selects the strict-fp32 kernels everywhere (fp32 MFMA / fp32 vector
+// ALUs: the forms of r01) -- the companion figure of bench.py and a cross-check the tests run in a child process.  Read once
+// per process.
 inline bool conv_mfma_use_h16()
 {
-    static const int v = kpb_env_int("KPB_CONVM_H16", 1);
-    return v != 0;
+    static const int v = kpb_env_int("KPB_FP32_MATRIX", 0);
+    return v == 0;
 }
 
 // OIHW [COUT][CIN][KS][KS] -> conv_mfma fragment order [ntile][tap][chunk][h][32][KC]

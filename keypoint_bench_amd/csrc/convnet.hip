@@ -332,18 +332,13 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     const bool x = xf != nullptr;
     const dim3 block(256);
     if (conv_mfma_use_h16()) {     // split-f16 form: stride-1 layers take two M tiles per wave (16-row workgroup tiles)
-        a.unscale = 1.0f / (ACT_SCALE * net->wscale.at(L.name + ".w"));
+        a.unscale = 1.0f / (net->wscale.at(L.name + ".w"));
         const dim3 g2(cdiv(a.W, 16), cdiv(a.H, 16), B * a.nblk), g1(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk);
         // one-tile layers (cout <= 32) are bound by per-workgroup latency: 8-row tiles (one M tile per wave, 28 KB of LDS, five
         // workgroups per CU) measured 8-16 % faster; layers with two output tiles lose the fragment reuse that way (+8 % time)
-        static const int mt1 = kpb_env_int("KPB_CONVM_MT1", 1);       // 0: 16-row tiles everywhere, 2: 8-row tiles for all 3x3 layers
-        if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1 && mt1 >= 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), g1, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 2>), g2, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && mt1 >= 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 1>), g1, block, 0, st, a);
+        if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), g1, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && mt1 >= 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 1>), g1, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x && mt1 >= 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 1>), g1, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2, 1>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
@@ -403,7 +398,7 @@ void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b
             ws.wscale[L.name + ".w"] = sc;
             std::vector<float> xw((size_t)T * L.cin);
             for (int c = 0; c < L.cin; ++c)
-                for (int t = 0; t < T; ++t) xw[(size_t)t * L.cin + c] = w[((size_t)co * L.cin + c) * T + t] / ACT_SCALE;
+                for (int t = 0; t < T; ++t) xw[(size_t)t * L.cin + c] = w[((size_t)co * L.cin + c) * T + t];
             ws.put(L.name + ".xw", xw);
             ws.wscale[L.name + ".xb"] = b ? b[co] : 0.0f;     // a host-side scalar, carried with the scales
         } else if (conv_mfma_use_h16()) {

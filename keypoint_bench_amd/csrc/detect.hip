@@ -897,7 +897,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         // then; measured: 3 rounds 2.26 + 1.49 ms, 5 rounds 2.75 + 1.39 ms, 2 rounds 1.87 + 2.52 ms per 512 images)
         // with top-K pruning the tail is cheap and two rounds are the optimum (r02: 2 rounds 2.19 + <0.2 ms, 3 rounds 2.57 + <0.2 ms;
         // one round confirms too few maxima for the bound and the tail overflows)
-        a.max_local = env_int("KPB_NMS_MAXLOCAL", (p.ulist && s == 0) ? (p.clist ? 2 : 3) : 64);
+        a.max_local = (p.ulist && s == 0) ? (p.clist ? 2 : 3) : 64;
         const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
         switch (r) {
         case 1: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<1>, grid, block, 0, ctx->stream, a); break;
@@ -984,7 +984,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_fast_nms(kpb_ctx* ctx,
     }
     NmsPlan p;
     if (int rc = nms_plan(ctx, batch, H, W, nms_dist, p)) return rc;
-    const int chunk = env_int("KPB_NMS_SWEEPS", 6);
+    const int chunk = 6;
     int run = 0, pending = 1, neg = 0;
     while (pending) {
         if (run == 0) {
@@ -1073,7 +1073,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     if (prm->nms_dist > 0) {
         if (int rc = kpb_reserve(ctx, ctx->ws_nms_map, (size_t)batch * P * sizeof(float))) return rc;
         d.cur = static_cast<float*>(ctx->ws_nms_map.p);
-        const int chunk = env_int("KPB_NMS_SWEEPS", 6);
+        const int chunk = 6;
         if (int rc = nms_open(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, chunk, d.sweeps_run)) return rc;
     }
     if (int rc = det_select(ctx, d)) return rc;
@@ -1094,7 +1094,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
         ctx->det_pending = 0;
         return KPB_OK;
     }
-    const int chunk = env_int("KPB_NMS_SWEEPS", 6);
+    const int chunk = 6;
     int rerun = 0;
     for (;;) {
         int pending = 0, neg = 0;

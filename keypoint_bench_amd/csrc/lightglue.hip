@@ -241,14 +241,19 @@ __device__ __forceinline__ void cm_split8(const float* f, cm_h8& hi, cm_h8& lo)
     lo = __builtin_bit_cast(cm_h8, make_uint4(l0.x, l0.y, l1.x, l1.y));
 }
 
+// Operand range (r03, conv_mfma.h cm_scale_of): every 32-key block of K and of V is split at the power-of-two scale that fits the
+// block's own largest magnitude; the two exponents go to `kvexp` and lg_flash_h takes the scales out again (K: in the factor
+// the scores are multiplied by anyway; V: see there).  Q is scaled per query tile inside lg_flash_h.
 struct FragArgs {
     const float* k; const float* v; uint4* kf; uint4* vf;
+    int* kvexp;         // [S][NH][MP/32][2]: cm_exp_of(amax) of the K block and of the V block
     const int* cnt; const int* active;
     int MP, cross;
 };
 
 __global__ __launch_bounds__(256) void lg_kv_frags(FragArgs a)
 {
+    __shared__ float s_am[2][4];
     const int s = blockIdx.z, head = blockIdx.y, blk = blockIdx.x;
     // the fragments of sequence s are read by the queries of sequence s (self) or s ^ 1 (cross)
     if (!a.active[a.cross ? (s ^ 1) : s]) return;
@@ -256,34 +261,40 @@ __global__ __launch_bounds__(256) void lg_kv_frags(FragArgs a)
     if (blk * 32 >= n) return;
     const int t = threadIdx.x, lane = t & 63, p = lane & 31, h = lane >> 5, NB = a.MP / 32;
     const size_t fb = (((size_t)s * NH + head) * NB + blk) * 8 * 64;
+    float fk[8], fv[8], mk = 0.0f, mv = 0.0f;
+    const int kbk = t >> 6, nh = (t >> 6) & 1, kbv = t >> 7;
     {
-        const int kb = t >> 6, key = 32 * blk + p;
-        float f[8];
-        const float* src = a.k + ((size_t)s * a.MP + key) * D + head * HD + 16 * kb + 8 * h;
+        const int key = 32 * blk + p;
+        const float* src = a.k + ((size_t)s * a.MP + key) * D + head * HD + 16 * kbk + 8 * h;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = key < n ? src[j] : 0.0f;
-        cm_h8 hi, lo;
-        cm_split8(f, hi, lo);
-        a.kf[fb + (kb * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
-        a.kf[fb + (kb * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
-    }
-    {
-        const int nh = (t >> 6) & 1, kb = t >> 7;
-        float f[8];
+        for (int j = 0; j < 8; ++j) { fk[j] = key < n ? src[j] : 0.0f; mk = fmaxf(mk, fabsf(fk[j])); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int key = 32 * blk + 16 * kb + 8 * (j >> 2) + 4 * h + (j & 3);
-            f[j] = key < n ? a.v[((size_t)s * a.MP + key) * D + head * HD + 32 * nh + p] : 0.0f;
+            const int kv = 32 * blk + 16 * kbv + 8 * (j >> 2) + 4 * h + (j & 3);
+            fv[j] = kv < n ? a.v[((size_t)s * a.MP + kv) * D + head * HD + 32 * nh + p] : 0.0f;
+            mv = fmaxf(mv, fabsf(fv[j]));
         }
-        cm_h8 hi, lo;
-        cm_split8(f, hi, lo);
-        a.vf[fb + ((nh * 2 + kb) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
-        a.vf[fb + ((nh * 2 + kb) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
     }
+    mk = cm_wave_max(mk); mv = cm_wave_max(mv);
+    if (lane == 0) { s_am[0][t >> 6] = mk; s_am[1][t >> 6] = mv; }
+    __syncthreads();
+    const int ek = cm_exp_of(fmaxf(fmaxf(s_am[0][0], s_am[0][1]), fmaxf(s_am[0][2], s_am[0][3])));
+    const int ev = cm_exp_of(fmaxf(fmaxf(s_am[1][0], s_am[1][1]), fmaxf(s_am[1][2], s_am[1][3])));
+    if (t == 0) { int* e = a.kvexp + (((size_t)s * NH + head) * NB + blk) * 2; e[0] = ek; e[1] = ev; }
+    const float sk = cm_scale_of(ek), sv = cm_scale_of(ev);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fk[j] *= sk; fv[j] *= sv; }
+    cm_h8 hi, lo;
+    cm_split8(fk, hi, lo);
+    a.kf[fb + (kbk * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    a.kf[fb + (kbk * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
+    cm_split8(fv, hi, lo);
+    a.vf[fb + ((nh * 2 + kbv) * 2 + 0) * 64 + lane] = __builtin_bit_cast(uint4, hi);
+    a.vf[fb + ((nh * 2 + kbv) * 2 + 1) * 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
 struct FlashHArgs {
-    const float* q; const uint4* kf; const uint4* vf; float* out;
+    const float* q; const uint4* kf; const uint4* vf; const int* kvexp; float* out;
     const int* cnt; const int* active;
     int MP, cross; float scale;
 };
@@ -299,12 +310,22 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
     const int kv = a.cross ? (s ^ 1) : s;
     const int nk = a.cnt[kv], NB = a.MP / 32;
     cm_h8 Qh[4], Ql[4];
+    float qscale;           // a.scale / (the tile's Q scale): with the key block's K scale, what turns the accumulator into scores
     {
         const float* qp = a.q + ((size_t)s * a.MP + q0 + p) * D + head * HD + 8 * h;       // rows past nq stay inside the padded buffer
+        float4 t0[4], t1[4];
+        float am = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * kb), t1 = *reinterpret_cast<const float4*>(qp + 16 * kb + 4);
-            const float f[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            t0[kb] = *reinterpret_cast<const float4*>(qp + 16 * kb); t1[kb] = *reinterpret_cast<const float4*>(qp + 16 * kb + 4);
+            am = cm_amax4(cm_amax4(am, t0[kb]), t1[kb]);
+        }
+        const int eq = cm_exp_of(cm_wave_max(am));
+        const float sq = cm_scale_of(eq);
+        qscale = a.scale * cm_unscale_of(eq);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const float f[8] = {t0[kb].x * sq, t0[kb].y * sq, t0[kb].z * sq, t0[kb].w * sq, t1[kb].x * sq, t1[kb].y * sq, t1[kb].z * sq, t1[kb].w * sq};
             cm_split8(f, Qh[kb], Ql[kb]);
         }
     }
@@ -312,9 +333,13 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
     float m_run = -INFINITY, l_run = 0.0f;
     const uint4* kfb = a.kf + ((size_t)kv * NH + head) * NB * 8 * 64 + lane;
     const uint4* vfb = a.vf + ((size_t)kv * NH + head) * NB * 8 * 64 + lane;
+    const int* kve = a.kvexp + ((size_t)kv * NH + head) * NB * 2;
+    int ev_run = 0;         // exponent whose V scale the output accumulators carry (wave-uniform); 0: nothing accumulated yet
     for (int k0 = 0; k0 < nk; k0 += 32) {
         const uint4* kf = kfb + (size_t)(k0 >> 5) * 8 * 64;
         const uint4* vf = vfb + (size_t)(k0 >> 5) * 8 * 64;
+        const int ek = __builtin_amdgcn_readfirstlane(kve[2 * (k0 >> 5)]), ev = __builtin_amdgcn_readfirstlane(kve[2 * (k0 >> 5) + 1]);
+        const float kscale = qscale * cm_unscale_of(ek);
         cm_h8 Kh[4], Kl[4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
@@ -341,7 +366,7 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            sc[r] = key < nk ? st[r] * a.scale : -INFINITY;
+            sc[r] = key < nk ? st[r] * kscale : -INFINITY;
             mx = fmaxf(mx, sc[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -360,6 +385,20 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
                 O0[r] *= ar; O1[r] *= ar;
             }
         }
+        // V blocks come at their own scales: the accumulators keep the scale of the LARGEST block so far (a larger one brings
+        // them down to it, exactly), a smaller block's probabilities are brought down instead (its products are that much
+        // smaller than what is already there).  The probabilities themselves are scaled by 2^13 for the split (P <= 1).
+        if (ev > ev_run) {
+            if (ev_run) {
+                const float dn = cm_pow2(max(ev_run - ev, -126));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { O0[r] *= dn; O1[r] *= dn; }
+            }
+            ev_run = ev;
+        }
+        const float pfac = cm_pow2(max(ev - ev_run, -100) + 13);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pr[r] *= pfac;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {       // registers 8 kb .. 8 kb + 7 are this lane half's keys of k-block kb
             cm_h8 Ph, Pl;
@@ -372,7 +411,7 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
             O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vh[1][kb], O1, 0, 0, 0);
         }
     }
-    const float inv = l_run > 0.0f ? 1.0f / l_run : 0.0f;
+    const float inv = l_run > 0.0f ? (1.0f / l_run) * cm_unscale_of(max(ev_run, 24)) * cm_pow2(-13) : 0.0f;
     float* op = a.out + (size_t)s * a.MP * D + head * HD + p;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -711,12 +750,9 @@ int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name
     a.CIN = cin; a.COUT = cout; a.NCH = cin / 32; a.relu = 0; a.nblk = (cout + 63) / 64;
     a.istride = istride; a.ostride = ostride; a.ooff = ooff;
     if (conv_mfma_use_h16()) {
-        a.unscale = 1.0f / (ACT_SCALE * lg->wscale.at(name + ".w"));
-        static const int pipe = kpb_env_int("KPB_GEMM_PIPE", 1);
-        static const int gmt = kpb_env_int("KPB_GEMM_MT", 1);      // 128-row tiles: 37 KB of LDS, four workgroups per CU (8-15 % faster than 256-row tiles)
-        if (pipe && gmt == 1) KPB_LAUNCH(ctx, tag, (gemm_h<2, 1>), dim3(cdiv(MP, 128), 1, S * a.nblk), dim3(256), 0, ctx->stream, a);
-        else if (pipe) KPB_LAUNCH(ctx, tag, (gemm_h<2>), dim3(cdiv(MP, 256), 1, S * a.nblk), dim3(256), 0, ctx->stream, a);
-        else KPB_LAUNCH(ctx, tag, (conv_mfma_h<1, 1, 32, false, false, false, 2, 2>), dim3(1, cdiv(MP, 256), S * a.nblk), dim3(256), 0, ctx->stream, a);
+        a.unscale = 1.0f / (lg->wscale.at(name + ".w"));
+        // 128-row tiles: four workgroups per CU (8-15 % faster than 256-row tiles, r02)
+        KPB_LAUNCH(ctx, tag, (gemm_h<2, 1>), dim3(cdiv(MP, 128), 1, S * a.nblk), dim3(256), 0, ctx->stream, a);
     } else
         KPB_LAUNCH(ctx, tag, (conv_mfma<1, 1, 32, false, false, false, 2>), dim3(1, MP / 128, S * a.nblk), dim3(256), 0, ctx->stream, a);
     return KPB_OK;
@@ -826,7 +862,8 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
                  o_v = take(T * D), o_ctx = take(T * D), o_h1 = take(T * 512), o_y = take(T * D), o_conf = take(T), o_msc = take(T), o_z = take(T),
                  o_md = take(T * D), o_sim = take((size_t)B * MP * MP), o_mx = take(T), o_lg = take(T), o_bv = take(T),
                  o_ind0 = take(T), o_ind1 = take(T), o_dst = take(T), o_bi = take(T), o_ints = take((size_t)8 * S + 64),
-                 o_kf = take(T * D), o_vf = take(T * D);      // K / V in MFMA operand order, (hi, lo) halves: 4 bytes per element
+                 o_kf = take(T * D), o_vf = take(T * D),      // K / V in MFMA operand order, (hi, lo) halves: 4 bytes per element
+                 o_kve = take((size_t)S * NH * (MP / 32) * 2);  // per 32-key block: exponents of the K and V scales
     const bool fresh = need * sizeof(float) > lg->ws.cap;
     if (int rc = kpb_reserve(ctx, lg->ws, need * sizeof(float))) return rc;
     float* base = static_cast<float*>(lg->ws.p);
@@ -839,6 +876,7 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
     int *ind[2] = {reinterpret_cast<int*>(base + o_ind0), reinterpret_cast<int*>(base + o_ind1)}, *dst = reinterpret_cast<int*>(base + o_dst),
         *besti = reinterpret_cast<int*>(base + o_bi), *ints = reinterpret_cast<int*>(base + o_ints);
     uint4 *kfrag = reinterpret_cast<uint4*>(base + o_kf), *vfrag = reinterpret_cast<uint4*>(base + o_vf);
+    int* kvexp = reinterpret_cast<int*>(base + o_kve);
     int *cnt = ints, *cnt_orig = ints + S, *newcnt = ints + 2 * S, *active_seq = ints + 3 * S, *fin_seq = ints + 4 * S, *active_pair = ints + 5 * S,
         *fin_pair = ints + 5 * S + B, *stop = ints + 6 * S;
 
@@ -872,9 +910,9 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
         if ((rc = lg_linear(ctx, lg, "lg_Wqkv", L + ".Wqkv", 256, 768, c, 512, qkv, 768, 0, S, MP, active_seq))) return rc;
         KPB_LAUNCH(ctx, "lg_rotary", lg_rotary, dim3(cdiv(max_k * 128, 256), S), dim3(256), 0, st, qkv, cs, sn, q, k, v, cnt, active_seq, MP);
         if (conv_mfma_use_h16()) {
-            FragArgs fr{k, v, kfrag, vfrag, cnt, active_seq, MP, 0};
+            FragArgs fr{k, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 0};
             KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
-            FlashHArgs fa{q, kfrag, vfrag, cx, cnt, active_seq, MP, 0, 0.125f};
+            FlashHArgs fa{q, kfrag, vfrag, kvexp, cx, cnt, active_seq, MP, 0, 0.125f};
             KPB_LAUNCH(ctx, "lg_flash_self", lg_flash_h, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
         } else {
             FlashArgs fa{q, k, v, cx, cnt, active_seq, MP, 0, 0.125f};
@@ -886,9 +924,9 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
         if ((rc = lg_linear(ctx, lg, "lg_to_qk", L + ".toqk", 256, 256, c, 512, q, 256, 0, S, MP, active_seq))) return rc;
         if ((rc = lg_linear(ctx, lg, "lg_to_v", L + ".tov", 256, 256, c, 512, v, 256, 0, S, MP, active_seq))) return rc;
         if (conv_mfma_use_h16()) {
-            FragArgs fr{q, v, kfrag, vfrag, cnt, active_seq, MP, 1};
+            FragArgs fr{q, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 1};
             KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
-            FlashHArgs fc{q, kfrag, vfrag, cx, cnt, active_seq, MP, 1, 0.125f};
+            FlashHArgs fc{q, kfrag, vfrag, kvexp, cx, cnt, active_seq, MP, 1, 0.125f};
             KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash_h, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
         } else {
             FlashArgs fc{q, q, v, cx, cnt, active_seq, MP, 1, 0.125f};

@@ -280,8 +280,8 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
 //      spare, for every exact tie as well; mc_j likewise with the largest row norm;
 //   4. match_exact: scipy's float64 sum for the listed pairs only (same order, no FMA), filed under their row and column
 //      in the slots match_finalize reads (the per-tile partial arrays of match_tile, one slot per column / row tile).
-// A pair whose descriptors are not finite, or that needs more slots than there are tiles (massive exact ties), raises a
-// flag: match_tile then runs for that pair alone (it returns at once for the others) and overwrites the slots.  Results
+// A pair whose descriptors are not finite or reach 2^15 in magnitude (the split would saturate), or that needs more slots than
+// there are tiles (massive exact ties), raises a flag: match_tile then runs for that pair alone (it returns at once for the others) and overwrites the slots.  Results
 // are bit-identical to match_tile's by construction; tests/test_gpu_match.py checks them on the goldens and the tie / NaN cases.
 typedef _Float16 mh8 __attribute__((ext_vector_type(8)));
 typedef float mf4 __attribute__((ext_vector_type(4)));
@@ -319,11 +319,13 @@ __global__ __launch_bounds__(256) void match_prep(PreArgs a)
     const float* src = (second ? a.d1 : a.d0) + ((size_t)b * cap + row) * a.C;
     uint4* dst = (second ? a.h1 : a.h0) + ((size_t)b * cap + row) * P8;
     const size_t lo_off = (size_t)gridDim.y * cap * P8;
-    float nn = 0.0f;
+    float nn = 0.0f, big = 0.0f;
     if (row < cnt) {
         for (int p8 = q; p8 < P8; p8 += 8) {
             const float4 u = *reinterpret_cast<const float4*>(src + 8 * p8), v = *reinterpret_cast<const float4*>(src + 8 * p8 + 4);
             const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+            big = fmaxf(fmaxf(fmaxf(big, fmaxf(fabsf(u.x), fabsf(u.y))), fmaxf(fabsf(u.z), fabsf(u.w))),
+                        fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
             unsigned hw[4], lw[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -338,6 +340,10 @@ __global__ __launch_bounds__(256) void match_prep(PreArgs a)
         }
     }
     nn += __shfl_xor(nn, 1, 64); nn += __shfl_xor(nn, 2, 64); nn += __shfl_xor(nn, 4, 64);       // the same tree for every row: deterministic
+    // The filter's error bound (match_margin) holds while every component is carried to 2^-20 relative or 2^-25 absolute, i.e.
+    // while its hi half does not saturate: a component of magnitude >= 2^15 (un-normalised descriptors can be anything) hands
+    // the whole pair to the exact kernel, like a non-finite one.
+    if (row < cnt && big >= 32768.0f) a.flag[b] = 1;
     if (row < cnt && q == 0) {
         if (!(nn < 3.0e38f)) a.flag[b] = 1;             // NaN / inf / overflow: the exact kernel takes this pair
         else atomicMax(&s_max[second ? 1 : 0], __float_as_uint(nn));

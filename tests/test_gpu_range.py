@@ -1,0 +1,197 @@
+"""Operand range of the split-f16 matrix arithmetic: every split site scales by the power of two
+that fits what it is about to split (csrc/conv_mfma.h, cm_scale_of), so the SAME function with its intermediate tensors shifted
+by 2^+-12 -- one layer's weights (and bias) times s, its consumers' weights divided by s; ReLU and max-pool are positively
+homogeneous -- must come out within the unchanged tolerances.  The fp32 oracle is indifferent to such shifts (powers of two
+commute with fp32 rounding), so the expected values are those of the unshifted weights.  Also: descriptors far outside the f16
+range through kpb_match (bit-exact: the pair falls to the exact kernel), a generic convolution fed activations beyond 65 504,
+and LightGlue with its attention operands shifted."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import alike_ref
+from keypoint_bench_amd import synthetic, weights
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ATOL_DESC, ATOL_SCORE = 1e-4, 1e-5      # the tolerances of tests/test_gpu_alike.py, unchanged
+
+# (name, tensors multiplied by s, tensors divided by s) -- which intermediate the shift moves
+SHIFTS = [
+    ("block1 intermediate", ["b1c1.w", "b1c1.b"], ["b1c2.w"]),
+    ("x1", ["b1c2.w", "b1c2.b"], ["b2c1.w", "b2ds.w", "agg1.w"]),
+    ("block2 intermediate", ["b2c1.w", "b2c1.b"], ["b2c2.w"]),
+    ("x2", ["b2c2.w", "b2c2.b", "b2ds.w", "b2ds.b"], ["agg2.w", "b3c1.w", "b3ds.w"]),
+    ("a2", ["agg2.w"], ["head.w[16:32]"]),
+    ("block3 intermediate", ["b3c1.w", "b3c1.b"], ["b3c2.w"]),
+    ("x3", ["b3c2.w", "b3c2.b", "b3ds.w", "b3ds.b"], ["agg3.w", "b4c1.w", "b4ds.w"]),
+    ("block4 intermediate", ["b4c1.w", "b4c1.b"], ["b4c2.w"]),
+    ("x4", ["b4c2.w", "b4c2.b", "b4ds.w", "b4ds.b"], ["agg4.w"]),
+]
+
+
+def _shift(t, up, down, s):
+    t = {k: v.copy() for k, v in t.items()}
+    for names, f in ((up, s), (down, 1.0 / s)):
+        for n in names:
+            if n.startswith("head.w["):
+                lo, hi = (int(x) for x in n[7:-1].split(":"))
+                t["head.w"][:, lo:hi] *= np.float32(f)
+            else:
+                t[n] = (t[n] * np.float32(f)).astype(np.float32)
+    return t
+
+
+def _net(tensors, dense=True):
+    from keypoint_bench_amd.models.ALike import ALNet
+    net = ALNet(dict(c1=8, c2=16, c3=32, c4=64, dim=64), dense_descriptors=dense)
+    net.load_packed(weights.pack(tensors, weights.ARCH_ALIKE))
+    return net.eval()
+
+
+@pytest.fixture(scope="module")
+def expected():
+    img = synthetic.image_pair(3, 96, 160)[0]
+    t = {k: torch.from_numpy(v) for k, v in weights.load_alike_t().items()}
+    with torch.no_grad():
+        so, do = alike_ref.alnet_forward(torch.from_numpy(img)[None], t)
+    return img, so[0, 0].numpy(), do[0].numpy()
+
+
+@pytest.mark.parametrize("log2s", [12, -12])
+@pytest.mark.parametrize("case", SHIFTS, ids=[c[0] for c in SHIFTS])
+def test_alike_with_an_intermediate_tensor_shifted_by_2_pm_12(expected, case, log2s):
+    img, so, do = expected
+    _, up, down = case
+    t = _shift(weights.load_alike_t(), up, down, 2.0 ** log2s)
+    with torch.no_grad():       # the oracle does not care about the shift: a check on the construction of the case itself
+        s2, d2 = alike_ref.alnet_forward(torch.from_numpy(img)[None], {k: torch.from_numpy(v) for k, v in t.items()})
+    np.testing.assert_allclose(s2[0, 0].numpy(), so, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(d2[0].numpy(), do, rtol=0, atol=2e-6)
+    score, desc = _net(t)(torch.from_numpy(img)[None].to(DEV))
+    np.testing.assert_allclose(score[0, 0].cpu().numpy(), so, rtol=0, atol=ATOL_SCORE)
+    np.testing.assert_allclose(desc[0].cpu().numpy(), do, rtol=0, atol=ATOL_DESC)
+
+
+@pytest.mark.parametrize("log2s", [8, -8, 16])
+def test_alike_image_range(expected, log2s):
+    """An image handed over in another range (0..255 instead of 0..1, or a dim one) with conv1's weights compensating: the
+    image tile is split at the scale of its own largest pixel."""
+    img, so, do = expected
+    s = np.float32(2.0 ** log2s)
+    t = weights.load_alike_t()
+    t["b1c1.w"] = (t["b1c1.w"] / s).astype(np.float32)
+    score, desc = _net(t)(torch.from_numpy(img * s)[None].to(DEV))
+    np.testing.assert_allclose(score[0, 0].cpu().numpy(), so, rtol=0, atol=ATOL_SCORE)
+    np.testing.assert_allclose(desc[0].cpu().numpy(), do, rtol=0, atol=ATOL_DESC)
+
+
+def test_alike_keypoint_only_mode_shifted(expected):
+    """dense_descriptors=False (score in its linear form, descriptors at keypoints) shares blocks 1-4 with the dense mode."""
+    from keypoint_bench_amd.utils.matcher import sample_descriptors
+    img, so, do = expected
+    t = _shift(weights.load_alike_t(), ["b1c2.w", "b1c2.b"], ["b2c1.w", "b2ds.w", "agg1.w"], 2.0 ** 12)
+    score, desc = _net(t, dense=False)(torch.from_numpy(img)[None].to(DEV))
+    np.testing.assert_allclose(score[0, 0].cpu().numpy(), so, rtol=0, atol=ATOL_SCORE)
+    pts = torch.tensor([[0.3, 0.4, 1.0], [0.71, 0.13, 1.0], [0.05, 0.93, 1.0]], device=DEV)
+    got = sample_descriptors(pts, desc).cpu().numpy()
+    want = oracle.sample(do, pts.cpu().numpy())
+    np.testing.assert_allclose(got, want, rtol=0, atol=ATOL_DESC)
+
+
+# ------------------------------------------------------------------------------------------------ matcher
+@pytest.mark.parametrize("scale", [1e5, 7e4, 3.3e4, 1e-5, 1.0])
+@pytest.mark.parametrize("C", [64, 256])
+def test_match_descriptors_far_outside_the_f16_range_stay_bit_exact(scale, C):
+    """matcher.py:227-230 on un-normalised descriptors of any magnitude (ALIKE's are un-normalised by design): components of
+    2^15 and more would saturate the prefilter's half-precision split, so the pair goes to the exact kernel; tiny ones ride on
+    the absolute term of the prefilter's margin.  Pairs and float64 distances equal the oracle's bit for bit either way."""
+    from keypoint_bench_amd.utils.matcher import match_descriptors
+    rng = np.random.default_rng(int(C + 1000 + np.log2(scale) * 7))
+    n, m = 300, 280
+    base = rng.standard_normal((n, C)).astype(np.float32)
+    d0 = (base * np.float32(scale)).astype(np.float32)
+    d1 = ((base[rng.permutation(n)[:m]] + 0.05 * rng.standard_normal((m, C)).astype(np.float32)) * np.float32(scale)).astype(np.float32)
+    for md in (np.inf, 5.0 * scale):
+        pairs, dist = match_descriptors(torch.from_numpy(d0).to(DEV), torch.from_numpy(d1).to(DEV), max_distance=md, cross_check=True, return_distance=True)
+        op, od = oracle.match(d0, d1, md, True)
+        assert len(op) > 100
+        assert np.array_equal(pairs.cpu().numpy(), op) and np.array_equal(dist.cpu().numpy(), od), (scale, C, md)
+
+
+def test_match_one_huge_component_among_ordinary_descriptors():
+    """A single out-of-range component (1e9) in one row: the whole pair takes the exact kernel, nothing else changes."""
+    from keypoint_bench_amd.utils.matcher import match_descriptors
+    rng = np.random.default_rng(5)
+    d0 = rng.standard_normal((257, 64)).astype(np.float32)
+    d1 = (d0[rng.permutation(257)] + 0.01 * rng.standard_normal((257, 64))).astype(np.float32)
+    d0[100, 7] = 1e9
+    pairs, dist = match_descriptors(torch.from_numpy(d0).to(DEV), torch.from_numpy(d1).to(DEV), max_distance=np.inf, cross_check=True, return_distance=True)
+    op, od = oracle.match(d0, d1, np.inf, True)
+    assert np.array_equal(pairs.cpu().numpy(), op) and np.array_equal(dist.cpu().numpy(), od)
+
+
+# ------------------------------------------------------------------------------------------------ generic convolution / other nets
+@pytest.mark.parametrize("log2s", [14, -14])
+def test_superpoint_with_an_activation_far_outside_the_old_fixed_window(log2s):
+    """conv_mfma_h used to stage activations times a fixed 16: anything beyond 4 094 saturated silently.  conv1a's
+    output shifted to ~1e5 (and to ~1e-5), conv1b compensating: every later tensor is unchanged, the heat map and the
+    descriptors must be those of the unshifted net."""
+    from keypoint_bench_amd.models.SuperPoint import SuperPointNet
+    sd = weights.random_superpoint(11)
+    img = torch.from_numpy(synthetic.image_pair(5, 64, 96)[0])[None].to(DEV)
+    base = SuperPointNet()
+    base.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    h0, d0 = base.eval()(img)
+    s = np.float32(2.0 ** log2s)
+    sd2 = {k: v.copy() for k, v in sd.items()}
+    sd2["conv1a.weight"] = sd2["conv1a.weight"] * s
+    sd2["conv1a.bias"] = sd2["conv1a.bias"] * s
+    sd2["conv1b.weight"] = sd2["conv1b.weight"] / s
+    net = SuperPointNet()
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd2.items()})
+    h1, d1 = net.eval()(img)
+    np.testing.assert_allclose(h1.cpu().numpy(), h0.cpu().numpy(), rtol=2e-3, atol=1e-7)       # tests/test_gpu_superpoint.py's bounds
+    np.testing.assert_allclose(d1.cpu().numpy(), d0.cpu().numpy(), rtol=0, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ LightGlue
+@pytest.mark.parametrize("log2s", [11, -11])
+def test_lightglue_attention_operands_shifted(log2s):
+    """lightglue.py:173-185, 216-243: the same matcher with the attention operands moved by 2^+-11 -- self attention: q rows of
+    Wqkv times s, k rows divided by s (scores unchanged), v rows times s with out_proj divided by s; cross attention: to_v times
+    s with to_out divided by s.  The reference's fixtures (tests/golden/lightglue.npz) hold for the shifted weights too."""
+    import sys
+    from conftest import load_golden, GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden_lightglue as mk
+    from keypoint_bench_amd.models.lightglue import LightGlue
+    name = "disk_plain"
+    g = load_golden("lightglue.npz")
+    dim, scale, seed, n0, n1 = (int(v) for v in g[name + ".cfg"])
+    dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale, n0=n0, n1=n1)
+    sd = weights.random_lightglue_state_dict(seed, dim, str(g[name + ".variant"]))
+    s = np.float32(2.0 ** log2s)
+    for i in range(weights.LG_LAYERS):
+        p = "transformers.%d.self_attn" % i
+        w, b = sd[p + ".Wqkv.weight"], sd[p + ".Wqkv.bias"]          # output index = head * 192 + dim * 3 + (q, k, v)
+        f = np.where(np.arange(768) % 3 == 1, 1.0 / s, s).astype(np.float32)
+        sd[p + ".Wqkv.weight"], sd[p + ".Wqkv.bias"] = w * f[:, None], b * f
+        sd[p + ".out_proj.weight"] = sd[p + ".out_proj.weight"] / s
+        p = "transformers.%d.cross_attn" % i
+        sd[p + ".to_v.weight"], sd[p + ".to_v.bias"] = sd[p + ".to_v.weight"] * s, sd[p + ".to_v.bias"] * s
+        sd[p + ".to_out.weight"] = sd[p + ".to_out.weight"] / s
+    m = LightGlue(features=None, desc_scale=scale)
+    m.load_state_dict(sd)
+    T = lambda a: torch.from_numpy(a).to(DEV)
+    pairs, scores, stop = m.match_indices(T(p0), T(p1), T(dm0), T(dm1), {"w": 320, "h": 240})
+    assert stop == int(g[name + ".stop"])
+    ws = {tuple(r): v for r, v in zip(g[name + ".matches"].tolist(), g[name + ".scores"].tolist())}
+    gs = {tuple(r): v for r, v in zip(pairs.cpu().numpy().tolist(), scores.cpu().numpy().tolist())}
+    for r in set(ws) ^ set(gs):
+        v = ws.get(r, gs.get(r))
+        assert abs(v - 0.1) < 1e-3, "match %s (score %.4f) differs and is not at the threshold" % (r, v)
+    common = sorted(set(ws) & set(gs))
+    assert len(common) >= 0.98 * len(ws) and len(common) > 20
+    np.testing.assert_allclose([gs[r] for r in common], [ws[r] for r in common], rtol=2e-3, atol=1e-5)

@@ -42,7 +42,7 @@ def test_batched_rows_equal_single_pair_rows(task, dense):
     batched = runner.PairRunner(params(task), device=DEV, batch=4, dense_descriptors=dense)
     agg, rowsb = batched.run(ds)
     assert batched.batched_pairs == 11
-    assert np.array_equal(rows1.view(np.uint32), rowsb.view(np.uint32)), (rows1, rowsb)
+    assert np.array_equal(rows1.view(np.uint64), rowsb.view(np.uint64)), (rows1, rowsb)
     assert rowsb[:, 0].min() > 50                                         # the rows carry real keypoint counts
     assert np.isfinite(agg["mean_matches" if task == "match_stats" else "repeatability"])
 
@@ -83,7 +83,7 @@ def test_sequence_rows_batched_equal_single_and_chunks_reproduce_them(dense):
     batched = runner.PairRunner(prm, device=DEV, batch=4, dense_descriptors=dense)
     _, rowsb = batched.run(ds)
     assert batched.batched_pairs == 9
-    assert np.array_equal(rows1.view(np.uint32), rowsb.view(np.uint32)), (rows1, rowsb)
+    assert np.array_equal(rows1.view(np.uint64), rowsb.view(np.uint64)), (rows1, rowsb)
     # contiguous chunks with one-frame overlap: what ranks 0..2 of a 3-rank run would each compute
     for world in (2, 3):
         got = np.zeros_like(rows1[:, :3])
@@ -91,9 +91,9 @@ def test_sequence_rows_batched_equal_single_and_chunks_reproduce_them(dense):
             idx = runner.shard_chunk(len(ds), rank, world)
             for mode_batch in (1, 4):
                 r = runner.PairRunner(prm, device=DEV, batch=mode_batch, dense_descriptors=dense)
-                rows = np.asarray(r._run_sequence(ds, idx), np.float32)
+                rows = np.asarray(r._run_sequence(ds, idx), np.float64)           # rows are float64 end to end (runner.pack_rows)
                 got[idx] = rows
-                assert np.array_equal(rows.view(np.uint32), rows1[idx, :3].view(np.uint32)), (world, rank, mode_batch)
+                assert np.array_equal(rows.view(np.uint64), np.ascontiguousarray(rows1[idx, :3]).view(np.uint64)), (world, rank, mode_batch)
         assert np.array_equal(got, rows1[:, :3])
 
 
@@ -122,7 +122,7 @@ def test_visual_odometer_rows_batched_equal_single_and_chunks_reproduce_them():
     batched = runner.PairRunner(prm, device=DEV, batch=4)
     aggb, rowsb = batched.run(ds)
     assert batched.batched_pairs == 7
-    assert np.array_equal(rows1.view(np.uint32), rowsb.view(np.uint32)), (rows1, rowsb)
+    assert np.array_equal(rows1.view(np.uint64), rowsb.view(np.uint64)), (rows1, rowsb)
     assert np.array_equal(agg1["t_est"], aggb["t_est"]) and agg1["r_est"].shape == (8, 3, 3) and agg1["t_est"].shape == (8, 3, 1)
     # rotations are rotations; the camera slides sideways: the composed path has moved, mostly in the image plane
     for R in agg1["r_est"]:
@@ -136,8 +136,8 @@ def test_visual_odometer_rows_batched_equal_single_and_chunks_reproduce_them():
             idx = runner.shard_chunk(len(ds), rank, world)
             for mode_batch in (1, 4):
                 r = runner.PairRunner(prm, device=DEV, batch=mode_batch)
-                rows = np.asarray(r._run_sequence(ds, idx, "visual_odometer"), np.float32)
-                assert np.array_equal(rows.view(np.uint32), rows1[idx, :13].view(np.uint32)), (world, rank, mode_batch)
+                rows = np.asarray(r._run_sequence(ds, idx, "visual_odometer"), np.float64)
+                assert np.array_equal(rows.view(np.uint64), np.ascontiguousarray(rows1[idx, :13]).view(np.uint64)), (world, rank, mode_batch)
     # frame pair (2, 3) against the same steps taken with the oracle's pieces
     net = runner.build_model(prm)
     t = lambda a: torch.from_numpy(a)[None].to(DEV)
@@ -175,11 +175,11 @@ def test_host_items_are_staged_through_pinned_buffers_and_decoded_uint8_images_e
         _, rows[name] = r.run(d)
         assert r.batched_pairs == 10
         assert (r.staged_batches == 0) == (name == "dev"), (name, r.staged_batches)
-    assert np.array_equal(rows["f32"].view(np.uint32), rows["dev"].view(np.uint32))
-    assert np.array_equal(rows["u8"].view(np.uint32), rows["f32"].view(np.uint32))
+    assert np.array_equal(rows["f32"].view(np.uint64), rows["dev"].view(np.uint64))
+    assert np.array_equal(rows["u8"].view(np.uint64), rows["f32"].view(np.uint64))
     single = runner.PairRunner(params("repeatability"), device=DEV, batch=1)
     _, rows1 = single.run(u8)                     # the single-pair path takes decoded images too
-    assert np.array_equal(rows1.view(np.uint32), rows["u8"].view(np.uint32))
+    assert np.array_equal(rows1.view(np.uint64), rows["u8"].view(np.uint64))
 
 
 def test_a_failing_dataset_item_surfaces_from_the_staging_thread():
