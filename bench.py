@@ -37,19 +37,18 @@ PEAK_F16_TFLOPS = 16 * 157.3   # MI355X_MICROARCH.md, matrix cores: the F16/BF16
 PEAK_SPLIT_TFLOPS = PEAK_F16_TFLOPS / 3.0
 
 
+def strict_fp32():
+    """KPB_FP32_MATRIX=1: the strict-fp32 kernels (fp32 MFMA / fp32 vector ALUs) instead of the split-f16 matrix forms."""
+    return os.environ.get("KPB_FP32_MATRIX", "0") not in ("", "0")
+
+
 def mfma_peak(kernel):
     """Matrix roof (TFLOP/s of algorithmic fp32 FLOPs) of `kernel` in this build."""
-    env = os.environ.get
-    if kernel == "alike_head_dense":
-        return PEAK_SPLIT_TFLOPS if env("KPB_HEAD_F16", "1") != "0" else PEAK_F32_TFLOPS
-    if kernel == "alike_block1":
-        return PEAK_SPLIT_TFLOPS if env("KPB_BLOCK1_H16", "1") != "0" else PEAK_F32_TFLOPS
-    if kernel == "alike_block2":
-        return PEAK_SPLIT_TFLOPS
     if kernel.startswith("match_approx"):
         return PEAK_SPLIT_TFLOPS
-    if kernel in ("conv3x3_b3c1", "conv3x3_b3c2", "conv3x3_b4c1", "conv3x3_b4c2") or kernel.startswith(("sp_conv", "xf_", "disk_", "lg_")):
-        return PEAK_SPLIT_TFLOPS if env("KPB_CONVM_H16", "1") != "0" else PEAK_F32_TFLOPS
+    split = ("alike_head_dense", "alike_block1", "alike_block2", "conv3x3_b3c1", "conv3x3_b3c2", "conv3x3_b4c1", "conv3x3_b4c2")
+    if kernel in split or kernel.startswith(("sp_conv", "xf_", "disk_", "lg_")):
+        return PEAK_F32_TFLOPS if strict_fp32() else PEAK_SPLIT_TFLOPS
     return PEAK_F32_TFLOPS
 
 
@@ -95,6 +94,51 @@ def cpu_baseline(pairs_per_worker=6):
                        "%d single-thread workers, %.1f s wall, %.2f s/pair/core" % (n, cores, wall, busy / n))
 
 
+def fp32_companion(args):
+    """The same command with the strict-fp32 kernels (KPB_FP32_MATRIX=1: fp32 MFMA / fp32 vector ALUs, no half-precision
+    operand anywhere), run in a CHILD process before this one touches the GPU: what the split-f16 matrix arithmetic buys."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(3, args.steps // 2)), "--warmup", str(args.warmup), "--no-cpu-baseline",
+           "--no-variants", "--model", args.model, "--matcher", args.matcher]
+    if args.pairs_per_step:
+        cmd += ["--pairs-per-step", str(args.pairs_per_step)]
+    if args.sparse:
+        cmd.append("--sparse")
+    if args.distinct:
+        cmd += ["--distinct", str(args.distinct)]
+    try:
+        p = subprocess.run(cmd, env=dict(os.environ, KPB_FP32_MATRIX="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        return {"arithmetic": "strict fp32: fp32 MFMA (v_mfma_f32_32x32x2_f32) and fp32 vector ALUs, no half-precision operands",
+                "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+                "dominant_kernel": (j.get("roofline") or {}).get("kernel"), "dominant_kernel_ms": (j.get("roofline") or {}).get("avg_ms")}
+    except Exception as e:      # the companion is a reported extra: its failure must not cost the main figure
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+# whole-path algorithmic work per pair (SURVEY.md 8d): conv / GEMM FLOPs (2 x MAC) and compulsory HBM bytes
+NET_GFLOP_PER_IMAGE = {"alike": 3.8885, "alike_sparse": 1.3720 + 0.0082, "superpoint": 52.10, "xfeat": 2.54, "disk": 197.8}
+DESC_CHANNELS = {"alike": 64, "superpoint": 256, "xfeat": 64, "disk": 128}
+
+
+def step_roofline(model, matcher, sparse, pairs_per_s_per_gpu):
+    """Whole-step roofline: the path's algorithmic FLOPs and compulsory bytes per pair times the measured rate of
+    ONE GPU, against the matrix and HBM peaks.  The dense ALIKE mode adds the 2 x 2 x 78.6 MB of descriptor maps the
+    reference's layering asks for (written, then sampled), as 8d says to."""
+    C = DESC_CHANNELS[model]
+    key = "alike_sparse" if (model == "alike" and sparse) else model
+    flops = 2 * NET_GFLOP_PER_IMAGE[key] * 1e9 + (2 * 1000 * 1000 * C if matcher == "brute_force" else 0)
+    nbytes = 2 * (3.686e6 + 1.229e6 + 1.229e6 + 0.012e6) + 2 * 1000 * 4 * C * 4 + 2 * 1000 * C * 4 + 0.016e6
+    dense_extra = 2 * 2 * 78.6e6 if (model == "alike" and not sparse) else 0.0
+    peak = PEAK_F32_TFLOPS if strict_fp32() else PEAK_SPLIT_TFLOPS
+    tf, gbs = pairs_per_s_per_gpu * flops / 1e12, pairs_per_s_per_gpu * (nbytes + dense_extra) / 1e9
+    return {"flops_per_pair": flops, "compulsory_bytes_per_pair": nbytes, "dense_map_bytes_per_pair": dense_extra,
+            "achieved_tflops": round(tf, 2), "mfma_peak_tflops": round(peak, 1), "frac_mfma": round(tf / peak, 4),
+            "achieved_gbs": round(gbs, 1), "hbm_peak_gbs": PEAK_HBM_GBS, "frac_hbm": round(gbs / PEAK_HBM_GBS, 4),
+            "note": "LightGlue's FLOPs are not in SURVEY 8d and are not counted" if matcher == "lightglue" else None}
+
+
 # ---------------------------------------------------------------------------------------- roofline table
 def kernel_costs(B2, B, K, C, dense, sweeps):
     """Algorithmic (compulsory) FLOPs and HBM bytes PER LAUNCH of each kernel."""
@@ -108,8 +152,9 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     c["conv3x3_b4c1"] = (2 * (P // 1024) * 9 * 32 * 64 * B2, ((P // 64) * 128 + (P // 1024) * 256) * B2)
     c["conv3x3_b4c2"] = (2 * (P // 1024) * (9 * 64 * 64 + 32 * 64) * B2, ((P // 1024) * 256 * 2 + (P // 64) * 128) * B2)
     c["conv1x1_agg2"] = (2 * (P // 4) * 16 * 16 * B2, (P // 4) * 128 * B2)
-    # block 2 fused (b2c1 + b2c2 + identity branch + agg2): reads the pooled block-1 map, writes x2, a2 and the score share
-    c["alike_block2"] = (c["conv3x3_b2c1"][0] + c["conv3x3_b2c2"][0] + c["conv1x1_agg2"][0], (P // 4) * (32 + 64 + 64 + 4) * B2)
+    # block 2 fused (b2c1 + b2c2 + identity branch + agg2): reads the pooled block-1 map (32 B per pixel of H/2 x W/2), writes a2
+    # (64 B), the score share (4 B) and the 4 x 4 max-pool of x2 block 3 reads (64 B per pixel of H/8 x W/8); x2 stays in LDS
+    c["alike_block2"] = (c["conv3x3_b2c1"][0] + c["conv3x3_b2c2"][0] + c["conv1x1_agg2"][0], ((P // 4) * (32 + 64 + 4) + (P // 64) * 64) * B2)
     c["conv1x1_agg3"] = (2 * (P // 64) * 32 * 16 * B2, (P // 64) * 192 * B2)
     c["conv1x1_agg4"] = (2 * (P // 1024) * 64 * 16 * B2, (P // 1024) * 320 * B2)
     feat = 2 * 8 * 16 + 3 * 16 * 8 + 2 * 64            # agg1 + three 4-tap lerps + score dot (score-only kernel)
@@ -182,7 +227,7 @@ def workload_label(model, matcher):
            ("xfeat", "brute_force"): "BASELINE configs[3] extract+match stage", ("disk", "lightglue"): "BASELINE configs[4] extract+match stage"}
     tag = cfg.get((model, matcher), "not a BASELINE config")
     m = ("brute-force mutual match (euclidean fp64, max_distance=5, cross_check)" if matcher == "brute_force"
-         else "LightGlue attention matcher (fp32 MFMA, 9 layers, early stop + pruning)")
+         else "LightGlue attention matcher (split-f16 MFMA with fp32 accumulation, 9 layers, early stop + pruning)")
     return "%s extract + NMS(nms_dist=6, border=8, top_k=1000) + %s, 640x480 pairs [%s]" % (net, m, tag)
 
 
@@ -194,6 +239,8 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=None, help="pairs per GPU per step (default: 256 ALIKE and XFeat [SURVEY 8d], 16 SuperPoint and DISK)")
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the keypoint-only and strict-fp32 companion figures")
+    ap.add_argument("--spawn", action="store_true", help="take the multi-GPU launch path (a child torchrun, one rank per GPU over RCCL) even at --gpus 1")
     ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic pairs generated (default: one per pair of the batch; fewer are cycled)")
     ap.add_argument("--matcher", default="brute_force", choices=["brute_force", "lightglue"],
                     help="lightglue = BASELINE configs[4] (with --model disk or superpoint), seeded stand-in weights")
@@ -201,8 +248,8 @@ def main():
                     help="alike = BASELINE configs[1] (the headline); superpoint = configs[2] with seeded random weights")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "RANK" not in os.environ:
-        # a bare `python bench.py --gpus N`: start the N ranks as a CHILD torchrun (nothing in this process has touched the
+    if (args.gpus > 1 or args.spawn) and "RANK" not in os.environ:
+        # a bare `python bench.py --gpus N` (or --spawn at N = 1): start the N ranks as a CHILD torchrun (nothing in this process has touched the
         # GPU yet -- a process that has must never be replaced by another program on this pool) and relay its JSON line
         import socket
         import subprocess
@@ -211,7 +258,7 @@ def main():
         port = s_.getsockname()[1]
         s_.close()
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--spawn"]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
         lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
@@ -227,6 +274,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()          # before anything touches the GPU (spawned workers, CPU only)
+    fp32 = None
+    if rank == 0 and world == 1 and "RANK" not in os.environ and not args.no_variants and not strict_fp32():
+        fp32 = fp32_companion(args)   # a child process with KPB_FP32_MATRIX=1 (the library reads the knob once per process)
 
     import numpy as np
     import torch
@@ -317,7 +367,7 @@ def main():
     # the same pairs with keypoint-only descriptors (ALNet(dense_descriptors=False): same keypoints and matches, the
     # 78.6 MB/image descriptor map is never written; SURVEY 8d asks to say which was run): timed like the main loop
     variant = None
-    if args.model == "alike" and not args.sparse and args.matcher == "brute_force":
+    if args.model == "alike" and not args.sparse and args.matcher == "brute_force" and not args.no_variants:
         pipe2 = PairPipeline(alike_t(dense_descriptors=False).eval(), EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
         for _ in range(args.warmup):
             pipe2.run(images)
@@ -373,7 +423,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "image-pairs/sec (extract+NMS+BF-match, 640x480, top_k=1000)",
+            "metric": "image-pairs/sec (extract+NMS+%s, 640x480, top_k=1000)" % ("BF-match" if args.matcher == "brute_force" else "LightGlue-match"),
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -381,10 +431,13 @@ def main():
                        "matcher": args.matcher, "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns,
-                       "arithmetic": "fp32 results; matrix products as split-f16 MFMA triples with fp32 accumulation (2^-22 per product), fp64 match"},
+                       "arithmetic": ("strict fp32 (KPB_FP32_MATRIX=1): fp32 MFMA / fp32 vector ALUs, fp64 match" if strict_fp32() else
+                                      "fp32 results; matrix products as split-f16 MFMA triples with fp32 accumulation (2^-22 per product), operands "
+                                      "scaled per tile to the f16 window (no fixed range), fp64 match")},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
                         "pairs_gathered": int(allrows.shape[0])},
-            "roofline": roof, "cpu_baseline": cpu, "variant": variant,
+            "roofline": roof, "roofline_step": step_roofline(args.model, args.matcher, args.sparse, value / world),
+            "cpu_baseline": cpu, "variant": variant, "variant_fp32": fp32,
         }
         print(json.dumps(out))
     if use_dist:

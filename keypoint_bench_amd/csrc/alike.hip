@@ -37,13 +37,26 @@ __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
 }
 
 
-// Largest value of a NON-NEGATIVE tensor, per image: a wave offers its maximum to the image's slot (float bits order like
-// unsigned integers for non-negative floats).  The slot is read first and the atomic skipped when it would not raise it -- after
-// the first few workgroups of an image almost every wave skips (a stale read only costs an unnecessary atomic).
-__device__ __forceinline__ void amax_commit(float lane_max, unsigned* slot, int lane)
+// Largest value of a NON-NEGATIVE tensor, per image, without atomics: every wave of the producing kernel leaves its maximum in a
+// slot of its own ([image][workgroup][wave]), and amax_reduce -- one small workgroup per image, launched between producer and
+// consumer -- folds an image's slots into one float.  (r03 first tried one atomicMax per wave on a per-image word: the waves of
+// an image run together, all see the initial zero, and 1.2 M same-line atomics per launch cost block 1 1.8 ms.)
+__device__ __forceinline__ void amax_commit(float lane_max, float* slots, int slot, int lane)
 {
-    const unsigned bits = __float_as_uint(cm_wave_max(lane_max));
-    if (lane == 0 && bits > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, bits);
+    const float m = cm_wave_max(lane_max);
+    if (lane == 0) slots[slot] = m;
+}
+
+__global__ __launch_bounds__(256) void amax_reduce(const float* slots, int n, unsigned* out)
+{
+    __shared__ float s[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float m = 0.0f;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, slots[(size_t)b * n + i]);
+    m = cm_wave_max(m);
+    if ((tid & 63) == 0) s[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) out[b] = __float_as_uint(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])));
 }
 
 // ------------------------------------------------------------------------------------------------ block1
@@ -221,7 +234,7 @@ struct Block1HArgs {
     const uint4* w2pk;   // [3 kb][hi / lo][64 lanes] fragments of conv2 (pack_b1c2_pairs), scaled by 1 / inv_ws2
     float inv_ws1, inv_ws2;     // reciprocals of the two power-of-two weight scales
     float l1_c1, bmax_c1;       // max over output channels of sum |w| of conv1, max |bias|: |conv1 output| <= amax(input) l1 + bmax
-    unsigned* amax_x1;          // [B] float bits: largest x1 value of each image (x1 >= 0), read by block 2 and the head
+    float* wmax_x1;             // [B][workgroups][4 waves]: every wave's largest x1 value (x1 >= 0); amax_reduce folds them per image
 };
 
 constexpr int B1H_TH = 16;
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             if (sN == 0 && py < H2 && pxl < W2) *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + py) * W2 + pxl) * 8 + c0) = m;
         }
     }
-    amax_commit(xmax, ha.amax_x1 + b, lane);
+    amax_commit(xmax, ha.wmax_x1, ((b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wv, lane);
 }
 
 // conv1 of block 1, OIHW [8][3][3][3] -> alike_block1_h fragments [2 kb][hi / lo][64 lanes][8 halves]: lane (n = (s, cout), g),
@@ -576,7 +589,7 @@ struct Block2Args {
     // the two bounds |conv1 out| <= amax(p1) l1_c1 + bmax_c1, |x2| <= bound(conv1) l1_c2 + amax(p1) l1_ds + bmax_sum
     float inv_ws1, inv_ws2, inv_wsa, l1_c1, bmax_c1, l1_c2, l1_ds, bmax_sum;
     const unsigned* amax_x1;    // [B] float bits: largest value of the image's x1 (= of p1, its 2 x 2 max-pool)
-    unsigned* amax_a2;          // [B] float bits: largest a2 value of each image, for the head
+    float* wmax_a2;             // [B][workgroups][4 waves]: every wave's largest a2 value, folded per image by amax_reduce for the head
 };
 
 
@@ -737,7 +750,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         if ((px & 3) == 0 && gy < a.H && gx < a.W)
             *reinterpret_cast<float4*>(a.p2 + (size_t)b * (P / 16) * 16 + ((size_t)(gy >> 2) * (a.W >> 2) + (gx >> 2)) * 16 + 4 * g) = pm;
     }
-    amax_commit(amx, a.amax_a2 + b, lane);
+    amax_commit(amx, a.wmax_a2, ((b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wv, lane);
 }
 
 // agg [16][16] (cout, cin) -> one k-block of fragments: piece g < 2 = channel octet g
@@ -1494,7 +1507,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     const size_t n_s = B * (P / 4 + P / 64 + P / 1024) + 64;
     const size_t n_e = desc_out_dev ? B * (P / 64 + P / 1024) * ESTRIDE : 0;
     const size_t n_p1 = B * (P / 4) * 8;
-    const size_t n_rng = (2 * B + 63) / 64 * 64;
+    const int nw1 = cdiv(W, B1_TW) * cdiv(H, B1H_TH) * 4, nw2 = cdiv(W / 2, 32) * cdiv(H / 2, 8) * 4;      // per-wave maxima of blocks 1 / 2
+    const size_t n_rng = (2 * B + B * (nw1 + nw2) + 63) / 64 * 64;
     const size_t total = n_x1 + n_p1 + 3 * n_2 + 6 * n_3 + n_a3 + 5 * n_4 + n_a4 + n_s + n_e + n_rng;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
@@ -1511,8 +1525,10 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     S2 = p; p += B * (P / 4); S3 = p; p += B * (P / 64); S4 = p; p += B * (P / 1024) + 64;
     E3 = E4 = nullptr;
     if (desc_out_dev) { E3 = p; p += B * (P / 64) * ESTRIDE; E4 = p; p += B * (P / 1024) * ESTRIDE; }
-    unsigned* amax_x1 = reinterpret_cast<unsigned*>(p);      // [B], [B]: per-image largest x1 / a2 value (float bits), zeroed per forward
+    unsigned* amax_x1 = reinterpret_cast<unsigned*>(p);      // [B], [B]: per-image largest x1 / a2 value (float bits)
     unsigned* amax_a2 = amax_x1 + B;
+    float* wmax_x1 = p + 2 * B;                                // [B][nw1], [B][nw2]: the per-wave maxima they are folded from
+    float* wmax_a2 = wmax_x1 + B * nw1;
     p += n_rng;
     this->B = batch; this->H = H; this->W = W;
     hipStream_t st = ctx->stream;
@@ -1520,16 +1536,17 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     Block1Args b1{img_dev, x1, p1, wp("b1c1.w"), wp("b1c1.b"), wp("b1c2.w"), wp("b1c2.b"), H, W};
     ConvArgs c;
     if (h16) {
-        KPB_HIP(ctx, hipMemsetAsync(amax_x1, 0, 2 * B * sizeof(unsigned), st));
         Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c1.pairs")), reinterpret_cast<const uint4*>(wp("b1c2.pairs")),
-                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), amax_x1};
+                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), wmax_x1};
         KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1H_TH), batch), dim3(256), 0, st, hb);
+        KPB_LAUNCH(ctx, "amax_reduce", amax_reduce, dim3(batch), dim3(256), 0, st, wmax_x1, nw1, amax_x1);
         // block2 @ H/2 (ALike.py:139-140) + agg2, fused; it hands block 3 the 4 x 4 max-pool of its output (141)
         Block2Args b2{p1, x2, a2, S2, p2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
                       reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2,
                       k.at("b2c1.inv_ws"), k.at("b2c2.inv_ws"), k.at("agg2.inv_ws"), k.at("b2c1.l1"), k.at("b2c1.bmax"), k.at("b2c2.l1"), k.at("b2ds.l1"),
-                      k.at("b2c2.bsummax"), amax_x1, amax_a2};
+                      k.at("b2c2.bsummax"), amax_x1, wmax_a2};
         KPB_LAUNCH(ctx, "alike_block2", alike_block2, dim3(cdiv(W / 2, 32), cdiv(H / 2, 8), batch), dim3(256), 0, st, b2);
+        KPB_LAUNCH(ctx, "amax_reduce", amax_reduce, dim3(batch), dim3(256), 0, st, wmax_a2, nw2, amax_a2);
         // blocks 3 and 4 @ H/8, H/32 (141-144) on conv_mfma_h: conv1 carries the identity branch ds(pooled input) as 32 / 64 more
         // output channels whose weights sit on the centre tap only (no ReLU on those tiles); conv2 then reads conv1's half of that
         // buffer and adds the other half.  Block 4's conv1 max-pools x3 4 x 4 while it stages it.
