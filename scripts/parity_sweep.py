@@ -4,7 +4,8 @@ fp32 CPU chain (oracle/: torch-fp32 ALIKE-t restatement + C detection / sampling
 The stages are bit-exact on equal inputs; the net's score map differs from the CPU's by ~1e-6, which can flip an NMS decision
 between near-equal neighbours.  Prints, over `pairs` synthetic 640x480 pairs: max score / descriptor differences, the
 number of images whose keypoint index sets are identical, and the number of pairs whose match sets are identical.
-    python scripts/parity_sweep.py [pairs]        (GPU box; the oracle is the checker, never the product)"""
+    python scripts/parity_sweep.py [pairs] [out.json]     (GPU box; the oracle is the checker, never the product)
+tests/test_gpu_parity_sweep.py runs `sweep(8)` as a test."""
 import os
 import sys
 import time
@@ -34,15 +35,15 @@ def cpu_pair(i):
     return out, pairs
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+def sweep(n, first=0, workers=None):
+    """Compares pairs first .. first + n - 1; returns the figures as a dict."""
     import multiprocessing as mp
     import oracle
     oracle.build()
     t0 = time.time()
-    with mp.get_context("spawn").Pool(min(16, len(os.sched_getaffinity(0)))) as pool:
-        ref = pool.map(cpu_pair, range(n))
-    print("cpu chain: %.0f s" % (time.time() - t0))
+    with mp.get_context("spawn").Pool(workers or min(16, len(os.sched_getaffinity(0)))) as pool:
+        ref = pool.map(cpu_pair, range(first, first + n))
+    cpu_s = time.time() - t0
     from keypoint_bench_amd import synthetic
     from keypoint_bench_amd.models.ALike import alike_t
     from keypoint_bench_amd.utils.extracter import detection
@@ -53,7 +54,7 @@ def main():
     ds = dd = 0.0
     nk = nm = diffk = 0
     for i in range(n):
-        views = synthetic.image_pair(i, 480, 640)
+        views = synthetic.image_pair(first + i, 480, 640)
         feats, gidx, widx = [], [], []
         for j, v in enumerate(views):
             s, d = net(torch.from_numpy(v)[None].cuda())
@@ -66,8 +67,9 @@ def main():
             diffk += len(a ^ b)
             nk += len(b)
             f = sample_descriptors(k, d)
-            if a == b and np.array_equal(got_idx, np.asarray(want_idx)):
-                dd = max(dd, float(np.abs(f.cpu().numpy() - want_f).max()))
+            if a == b:      # descriptors compared keypoint by keypoint (rows of near-equal score may be permuted)
+                order_g, order_w = np.argsort(got_idx, kind="stable"), np.argsort(np.asarray(want_idx), kind="stable")
+                dd = max(dd, float(np.abs(f.cpu().numpy()[order_g] - want_f[order_w]).max()))
             feats.append(f)
             gidx.append(got_idx)
             widx.append(np.asarray(want_idx))
@@ -79,9 +81,22 @@ def main():
         same_matches += got_m == want_m
         diffm += len(got_m ^ want_m)
         nm += len(ref[i][1])
-    print("pairs %d: max |score diff| %.2e, max |descriptor diff| (identical keypoint lists) %.2e" % (n, ds, dd))
-    print("images with identical keypoint sets: %d / %d (%d of %d keypoints differ), in identical row order: %d; pairs with identical match sets "
-          "(as pixel pairs): %d / %d (%d of %d matches differ)" % (same_kps, 2 * n, diffk // 2, nk, same_order, same_matches, n, diffm // 2, nm))
+    return {"pairs": n, "first_pair_seed": first, "images": 2 * n, "size": "640x480", "extractor": EP, "matcher": BF,
+            "max_abs_score_diff": ds, "max_abs_descriptor_diff": dd,
+            "images_with_identical_keypoint_sets": int(same_kps), "images_in_identical_row_order": int(same_order),
+            "keypoints": int(nk), "keypoints_differing": int(diffk // 2),
+            "pairs_with_identical_match_sets": int(same_matches), "matches": int(nm), "matches_differing": int(diffm // 2),
+            "cpu_chain_seconds": round(cpu_s, 1)}
+
+
+def main():
+    import json
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    r = sweep(n)
+    print(json.dumps(r))
+    if len(sys.argv) > 2:
+        with open(sys.argv[2], "w") as f:
+            json.dump(r, f, indent=1)
 
 
 if __name__ == "__main__":

@@ -39,16 +39,28 @@ def main():
     lg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(lg)
     torch.set_num_threads(8)
-    out = {}
+    path = os.path.join(HERE, "lightglue.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}      # cases already in the file are kept as they are
     cases = []
-    # the last two are the CONFIGURED size of BASELINE configs[4] / the bench (top_k = 1000 keypoints: not a multiple of the
-    # kernel's 32-query tile; 977 != 1000 exercises unequal sides)
-    for name, dim, scale, variant, seed, n0, n1 in (("sp_plain", 256, 8, "plain", 21, 300, 280), ("sp_stop", 256, 8, "stop", 22, 300, 280),
-                                                    ("sp_prune", 256, 8, "prune", 23, 300, 280), ("disk_plain", 128, 1, "plain", 24, 300, 280),
-                                                    ("disk_prune", 128, 1, "prune", 25, 300, 280), ("disk_n1000", 128, 1, "plain", 26, 1000, 977),
-                                                    ("sp_n1000", 256, 8, "prune", 27, 1000, 1000)):
+    # disk_n1000 / sp_n1000 are the CONFIGURED size of BASELINE configs[4] / the bench (top_k = 1000 keypoints: not a multiple of
+    # the kernel's 32-query tile; 977 != 1000 exercises unequal sides).  The last two run above the keypoint counts at which the
+    # reference's CUDA paths start to prune (pruning_keypoint_thresholds: 1024 without / 1536 with FlashAttention,
+    # lightglue.py:352-357, 574-589): the reference instance is CONFIGURED with the threshold its `pruning_min_kpts` would return
+    # on such a device (the dict it reads is instance data; on the CPU it holds -1 = always prune).
+    for name, dim, scale, variant, seed, n0, n1, th in (("sp_plain", 256, 8, "plain", 21, 300, 280, -1), ("sp_stop", 256, 8, "stop", 22, 300, 280, -1),
+                                                        ("sp_prune", 256, 8, "prune", 23, 300, 280, -1), ("disk_plain", 128, 1, "plain", 24, 300, 280, -1),
+                                                        ("disk_prune", 128, 1, "prune", 25, 300, 280, -1), ("disk_n1000", 128, 1, "plain", 26, 1000, 977, -1),
+                                                        ("sp_n1000", 256, 8, "prune", 27, 1000, 1000, -1),
+                                                        ("disk_n1536_th1024", 128, 1, "prune", 28, 1536, 1500, 1024),
+                                                        ("disk_n2048_th1536", 128, 1, "prune", 29, 2048, 2000, 1536)):
+        cases.append(name)
+        if name + ".cfg" in out:
+            continue
         net = lg.LightGlue(features=None, input_dim=dim)
         net.desc_scale = scale
+        if th >= 0:
+            net.pruning_keypoint_thresholds = dict(lg.LightGlue.pruning_keypoint_thresholds, cpu=th)
+        out[name + ".prune_th"] = np.array(th)
         sd = weights.random_lightglue_state_dict(seed, dim, variant)
         r = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         assert not r.unexpected_keys and all(k == "confidence_thresholds" for k in r.missing_keys), (r.unexpected_keys, r.missing_keys)
@@ -70,10 +82,9 @@ def main():
         out[name + ".m0"], out[name + ".m1"] = m0.numpy(), m1.numpy()
         if n0 <= 300:
             out[name + ".sdesc0"] = d0.numpy()
-        cases.append(name)
         print("  lightglue", name, "matches", res["matches"][0].shape[0], "stop", res["stop"], "kept0", int((res["prune0"][0] == res["prune0"][0].max()).sum()))
     out["cases"] = np.array(cases)
-    np.savez_compressed(os.path.join(HERE, "lightglue.npz"), **out)
+    np.savez_compressed(path, **out)
     return 0
 
 

@@ -23,12 +23,17 @@ def _matcher(seed, dim, scale, variant, **kw):
     return m
 
 
-@pytest.mark.parametrize("name", ["sp_plain", "sp_stop", "sp_prune", "disk_plain", "disk_prune", "disk_n1000", "sp_n1000"])
+@pytest.mark.parametrize("name", ["sp_plain", "sp_stop", "sp_prune", "disk_plain", "disk_prune", "disk_n1000", "sp_n1000",
+                                  "disk_n1536_th1024", "disk_n2048_th1536"])
 def test_lightglue_against_reference_golden(name):
+    """The last two cases run ABOVE the keypoint counts at which the reference's CUDA paths start to prune
+    (pruning_keypoint_thresholds 1024 / 1536, lightglue.py:352-357, 574-589): 1536 and 2048 keypoints, the matcher built with
+    the same `prune_min_kpts` the reference instance was configured with, pruning until a side drops below it."""
     g = load_golden("lightglue.npz")
     dim, scale, seed, n0, n1 = (int(v) for v in g[name + ".cfg"])
     dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale, n0=n0, n1=n1)
-    m = _matcher(seed, dim, scale, str(g[name + ".variant"]))
+    th = int(g[name + ".prune_th"]) if name + ".prune_th" in g else -1
+    m = _matcher(seed, dim, scale, str(g[name + ".variant"]), prune_min_kpts=th)
     T = lambda a: torch.from_numpy(a).to(DEV)
     pairs, scores, stop = m.match_indices(T(p0), T(p1), T(dm0), T(dm1), {"w": 320, "h": 240})
     assert stop == int(g[name + ".stop"])
