@@ -901,25 +901,8 @@ __device__ __forceinline__ void up8ch(const float* m, int Hs, int Ws, float sy, 
     }
 }
 
-// the same in two phases: issue the eight 16-byte tap loads, interpolate later (lets the caller put other memory
-// operations behind the loads in program order)
+// the same for taps already in registers (the head reads them from the a2 band it keeps in LDS)
 struct Up8Taps { float4 t[8]; float ly, lx; };
-__device__ __forceinline__ void up8ch_load(const float* m, int Hs, int Ws, float sy, float sx, int y, int x, int c0, Up8Taps& u)
-{
-    const float fy = sy * (float)y, fx = sx * (float)x;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    u.ly = fy - (float)y0; u.lx = fx - (float)x0;
-    const float* p00 = m + ((size_t)y0 * Ws + x0) * 16 + c0;
-    const float* p01 = m + ((size_t)y0 * Ws + x1) * 16 + c0;
-    const float* p10 = m + ((size_t)y1 * Ws + x0) * 16 + c0;
-    const float* p11 = m + ((size_t)y1 * Ws + x1) * 16 + c0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        u.t[4 * q + 0] = *reinterpret_cast<const float4*>(p00 + 4 * q); u.t[4 * q + 1] = *reinterpret_cast<const float4*>(p01 + 4 * q);
-        u.t[4 * q + 2] = *reinterpret_cast<const float4*>(p10 + 4 * q); u.t[4 * q + 3] = *reinterpret_cast<const float4*>(p11 + 4 * q);
-    }
-}
 // `sc` (a power of two) scales the result exactly: it rides on the two y weights
 __device__ __forceinline__ void up8ch_lerp(const Up8Taps& u, float* f, float sc = 1.0f)
 {
@@ -967,23 +950,53 @@ constexpr int SEG_TILES = 4;            // a wave owns one 128-pixel row segment
 constexpr int NT3 = 18, NT4 = 7;        // strip rows a segment can touch: floor(127/8)+... see the bounds below
 
 // rows [tb, tb + NT) of map E (clamped to the last column), interpolated in y, into a wave's LDS strip
-// `c` (a power of two; exact) scales the 64 descriptor rows of the strip, NOT the score share in channel 64
+// `c` (a power of two; exact) scales the 64 descriptor rows of the strip, NOT the score share in channel 64.
+// Two phases, so that a caller can put every load of its prologue in flight before the first of them is waited for: as one
+// loop (load, interpolate, store, next) the strip cost seven dependent L2 round trips per workgroup -- with the a2 band 5.8 us
+// of a workgroup's ~20 us, and a store stream running at 0.7 of the fill rate because of it (r03, stores-only build).
 template <int NT>
-__device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, int Ws, float sy, int y, int tb, int lane, float c = 1.0f)
+struct StripRegs { float4 u[(NT * (ESTRIDE / 4) + 63) / 64], d[(NT * (ESTRIDE / 4) + 63) / 64]; };
+
+template <int NT>
+__device__ __forceinline__ void strip_load(StripRegs<NT>& r, const float* E, int Hs, int Ws, float sy, int y, int tb, int lane)
 {
     const float fy = sy * (float)y;
     const int y0 = (int)fy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
-    const float ly = fy - (float)y0, hy = 1.0f - ly;
-    for (int i = lane; i < NT * (ESTRIDE / 4); i += 64) {
+#pragma unroll
+    for (int k = 0; k < (NT * (ESTRIDE / 4) + 63) / 64; ++k) {
+        const int i = min(lane + 64 * k, NT * (ESTRIDE / 4) - 1);
         const int t = i / (ESTRIDE / 4), q = i - t * (ESTRIDE / 4);
         const int xt = min(tb + t, Ws - 1);
-        const float4 u = *reinterpret_cast<const float4*>(E + ((size_t)y0 * Ws + xt) * ESTRIDE + 4 * q);
-        const float4 d = *reinterpret_cast<const float4*>(E + ((size_t)y1 * Ws + xt) * ESTRIDE + 4 * q);
+        r.u[k] = *reinterpret_cast<const float4*>(E + ((size_t)y0 * Ws + xt) * ESTRIDE + 4 * q);
+        r.d[k] = *reinterpret_cast<const float4*>(E + ((size_t)y1 * Ws + xt) * ESTRIDE + 4 * q);
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void strip_store(const StripRegs<NT>& r, float* V, int Hs, float sy, int y, int lane, float c)
+{
+    const float fy = sy * (float)y;
+    const int y0 = (int)fy;
+    const float ly = fy - (float)y0, hy = 1.0f - ly;
+#pragma unroll
+    for (int k = 0; k < (NT * (ESTRIDE / 4) + 63) / 64; ++k) {
+        const int i = lane + 64 * k;
+        const int t = i / (ESTRIDE / 4), q = i - t * (ESTRIDE / 4);
         const float cq = q < 16 ? c : 1.0f;
+        const float4 u = r.u[k], d = r.d[k];
         float4 o;
         o.x = (hy * u.x + ly * d.x) * cq; o.y = (hy * u.y + ly * d.y) * cq; o.z = (hy * u.z + ly * d.z) * cq; o.w = (hy * u.w + ly * d.w) * cq;
-        *reinterpret_cast<float4*>(V + t * ESTRIDE + 4 * q) = o;
+        if (i < NT * (ESTRIDE / 4)) *reinterpret_cast<float4*>(V + t * ESTRIDE + 4 * q) = o;
     }
+}
+
+// rows [tb, tb + NT) of map E (clamped to the last column), interpolated in y, into a wave's LDS strip
+template <int NT>
+__device__ __forceinline__ void build_strip(float* V, const float* E, int Hs, int Ws, float sy, int y, int tb, int lane, float c = 1.0f)
+{
+    StripRegs<NT> r;
+    strip_load<NT>(r, E, Hs, Ws, sy, y, tb, lane);
+    strip_store<NT>(r, V, Hs, sy, y, lane, c);
 }
 
 // Lane (p, h) of a wave owns pixel p of the tile and, of each of the two fine 16-channel groups, channels 8h..8h+7:
@@ -1156,9 +1169,18 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
     __shared__ __attribute__((aligned(16))) float Ws[2 * 16];         // [h][s]:       score weight of chan(s,h), divided by the feature scale
     __shared__ __attribute__((aligned(16))) float V3[4][NT3 * ESTRIDE];
     __shared__ __attribute__((aligned(16))) float V4[4][NT4 * ESTRIDE];
+    // the a2 pixels the workgroup's four rows x 128 pixels tap: <= 4 source rows x 66 columns x 16 channels, fetched ONCE (each
+    // output row used to fetch its two a2 rows itself).  A pixel's four 16-byte slots are XOR-swizzled by (column / 4) % 4 so
+    // that the 8 columns a ds_read_b128 lane group touches (columns 4 apart would share banks) fall on distinct banks.
+    constexpr int A2R = 4, A2C = 66;
+    __shared__ __attribute__((aligned(16))) float4 A2[A2R * A2C * 4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
+    // (r03 measured an XCD-contiguous workgroup map -- blockIdx.x % 8 shares an L2, so give each XCD a contiguous run of row
+    // groups: FETCH_SIZE fell from 1.73x to 1.05x of the algorithmic reads and the kernel took 2.5 % LONGER, as in r02: it is
+    // not bound by what it fetches.  Not kept.)
+    const int wmap = blockIdx.x;
     const int ef = cm_exp_of(fmaxf(__uint_as_float(a.amax_x1[b]) * a.l1_agg1, __uint_as_float(a.amax_a2[b])));
     const float scf = cm_scale_of(ef), unf = cm_unscale_of(ef);
     const float cacc = scf * a.ws_h, unacc = unf * a.inv_ws_h;       // units of the accumulator, and back
@@ -1178,49 +1200,72 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
     int y, xs;
     bool live;
     {   // workgroup -> four consecutive rows of one 128-pixel column band (see alike_head_hyb)
-        const int w = blockIdx.x, band = w % segs_per_row, grp = w / segs_per_row;
+        const int w = wmap, band = w % segs_per_row, grp = w / segs_per_row;
         y = 4 * grp + wv; xs = band * (32 * SEG_TILES);
         live = y < a.H;
         if (!live) { y = 0; xs = 0; }
     }
     const int ntile = live ? min(SEG_TILES, tiles_per_row - xs / 32) : 0;
     const int tb3 = (int)(sx8 * (float)xs), tb4 = (int)(sx32 * (float)xs);
-    if (live) {
-        // Touch every 128-byte line the segment's four tiles will read (x1: 32 lines; a2: two rows of <= 34) with one
-        // dword per lane, before anything else: the lines are in flight while the strips are built and tile 0 computes,
-        // and the per-tile loads of tiles 1..3 find them in L2 instead of paying an HBM round trip each (the waves of a
-        // SIMD were all parked on s_waitcnt two thirds of the time).  The values are discarded.
-        const int npx = 32 * ntile;
-        const float* x1row = a.x1 + ((size_t)b * a.H * a.W + (size_t)y * a.W + xs) * 8;
-        const int fy0 = (int)(sy2 * (float)y), c0 = (int)(sx2 * (float)xs);
-        const int ncol = min(W2 - c0, npx / 2 + 2);
-        const int lines_a2 = (ncol * 16 + 31) / 32;
-        float dummy = 0.f;
-        if (lane < npx / 4) dummy += __builtin_nontemporal_load(x1row + lane * 32);
-        const int r = lane >= 34 ? 1 : 0, li = lane - 34 * r;
-        const int yy = min(fy0 + r, H2 - 1);
-        if (lane < 68 && li < lines_a2) dummy += a2[((size_t)yy * W2 + c0) * 16 + li * 32];
-        if (lane + 64 < 68 && lane + 64 - 34 < lines_a2) dummy += a2[((size_t)min(fy0 + 1, H2 - 1) * W2 + c0) * 16 + (lane + 64 - 34) * 32];
-        asm volatile("" :: "v"(dummy));
-        build_strip<NT3>(V3[wv], E3, H8, W8, sy8, y, tb3, lane, cacc);
-        build_strip<NT4>(V4[wv], E4, H32, W32, sy32, y, tb4, lane, cacc);
-    }
-    __syncthreads();
-
     f32x16 pend = {0};                  // channels 32..63 of the previous tile, stored under the next tile's feature arithmetic
     float* pend_d = nullptr;
     bool have = false;
-    for (int t = 0; t < ntile; ++t) {
+    // A wave's vector-memory operations complete IN ORDER (loads and stores share one counter): a load issued behind a store
+    // waits for that store's acknowledgement, which under 40 GB of streaming writes takes microseconds.  So every tile's ten
+    // 16-byte loads are issued a whole tile early -- before ANY store of the tile in front of it -- and are older than every
+    // store they could queue behind.
+    struct TileIn { float4 x1lo, x1hi; };
+    auto fetch = [&](int t, TileIn& in) {
+        const int x = xs + 32 * t + p;
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+        in.x1lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8); in.x1hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
+    };
+    TileIn tin[2];
+    if (ntile > 0) fetch(0, tin[0]);
+    const int r_lo = (int)(sy2 * (float)(4 * (wmap / segs_per_row))), c_lo = (int)(sx2 * (float)((wmap % segs_per_row) * (32 * SEG_TILES)));
+    StripRegs<NT3> sr3;
+    StripRegs<NT4> sr4;
+    {   // every load of the prologue goes out before the first LDS store waits for one of them
+        float4 v[(A2R * A2C * 4 + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (A2R * A2C * 4 + 255) / 256; ++k) {
+            const int i = tid + 256 * k, slot = i & 3, pc = i >> 2, col = pc % A2C, row = pc / A2C;
+            const int gr = min(r_lo + row, H2 - 1), gc = min(c_lo + col, W2 - 1);
+            v[k] = i < A2R * A2C * 4 ? *reinterpret_cast<const float4*>(a2 + ((size_t)gr * W2 + gc) * 16 + 4 * slot) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        strip_load<NT3>(sr3, E3, H8, W8, sy8, y, tb3, lane);
+        strip_load<NT4>(sr4, E4, H32, W32, sy32, y, tb4, lane);
+#pragma unroll
+        for (int k = 0; k < (A2R * A2C * 4 + 255) / 256; ++k) {
+            const int i = tid + 256 * k, slot = i & 3, pc = i >> 2, col = pc % A2C;
+            if (i < A2R * A2C * 4) A2[pc * 4 + (slot ^ ((col >> 2) & 3))] = v[k];
+        }
+    }
+    strip_store<NT3>(sr3, V3[wv], H8, sy8, y, lane, cacc);       // (a wave with no live row has y = 0: harmless)
+    strip_store<NT4>(sr4, V4[wv], H32, sy32, y, lane, cacc);
+    __syncthreads();
+    auto body = [&](const int t, const TileIn& cur, TileIn& nxt) {
         const int x0 = xs + 32 * t, x = x0 + p;
         const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
-        // this tile's ten 16-byte loads go out FIRST; the second half of the previous tile is stored behind them (the
-        // vector-memory path of a CU is a queue: loads issued behind a store burst wait for its drain)
-        const float4 x1lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8), x1hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
+        if (t + 1 < ntile) fetch(t + 1, nxt);
+        const float4 x1lo = cur.x1lo, x1hi = cur.x1hi;
         Up8Taps taps;
-        up8ch_load(a2, H2, W2, sy2, sx2, y, x, 8 * h, taps);
+        {   // up8ch_load's arithmetic, the four taps read from the band in LDS
+            const float fy = sy2 * (float)y, fx = sx2 * (float)x;
+            const int gy0 = (int)fy, gx0 = (int)fx;
+            const int ry0 = gy0 - r_lo, rx0 = gx0 - c_lo;
+            const int ry1 = ry0 + (gy0 < H2 - 1 ? 1 : 0), rx1 = rx0 + (gx0 < W2 - 1 ? 1 : 0);
+            taps.ly = fy - (float)gy0; taps.lx = fx - (float)gx0;
+            const int s0 = (rx0 >> 2) & 3, s1 = (rx1 >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                taps.t[4 * q + 0] = A2[(ry0 * A2C + rx0) * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 1] = A2[(ry0 * A2C + rx1) * 4 + ((2 * h + q) ^ s1)];
+                taps.t[4 * q + 2] = A2[(ry1 * A2C + rx0) * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 3] = A2[(ry1 * A2C + rx1) * 4 + ((2 * h + q) ^ s1)];
+            }
+        }
         if (have) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
         }
         int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
         asm volatile("" : "+v"(z));
@@ -1292,8 +1337,11 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
         // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  Streaming stores: 40 GB
         // per launch that nothing re-reads before they have left every cache
         int r = 0;
-#define ST0_2() { const int ra = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r] * unacc, d + (size_t)ra * 64 + p); ++r; \
-                  const int rb = (r & 3) + 8 * (r >> 2) + 4 * h; __builtin_nontemporal_store(acc0[r] * unacc, d + (size_t)rb * 64 + p); ++r; }
+        // (the lane-dependent part of a row's address, 4 h rows and channel p, sits in ONE base pointer: the 16 row offsets are
+        // compile-time constants that fold into the store instructions instead of costing a 64-bit add each)
+        float* dl = d + (4 * h) * 64 + p;
+#define ST0_2() { __builtin_nontemporal_store(acc0[r] * unacc, dl + ((r & 3) + 8 * (r >> 2)) * 64); ++r; \
+                  __builtin_nontemporal_store(acc0[r] * unacc, dl + ((r & 3) + 8 * (r >> 2)) * 64); ++r; }
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); ST0_2()
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); ST0_2()
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); ST0_2()
@@ -1311,11 +1359,15 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
 #pragma unroll
         for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        pend = acc1; pend_d = d + 32 + p; have = true;
+        pend = acc1; pend_d = dl + 32; have = true;
+    };
+    for (int t = 0; t < ntile; t += 2) {        // two tiles per trip: the two input sets swap roles, no register copies
+        body(t, tin[0], tin[1]);
+        if (t + 1 < ntile) body(t + 1, tin[1], tin[0]);
     }
     if (have) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + (size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * 64);
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
     }
 }
 
