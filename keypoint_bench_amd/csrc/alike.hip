@@ -27,15 +27,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float relu(float v);
 
 // fp32 x 4 -> (hi, lo) half-precision pairs: hi = f16(x) toward zero, lo = f16(x - hi) (x - hi is exact in fp32)
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo)
-{
-    const h2v a = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)), b = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
-    const h2v c = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.x - (float)a[0], v.y - (float)a[1]));
-    const h2v d = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(v.z - (float)b[0], v.w - (float)b[1]));
-    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-    lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
-}
-
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) { cm_split4(v, hi, lo); }
 
 // Largest value of a NON-NEGATIVE tensor, per image, without atomics: every wave of the producing kernel leaves its maximum in a
 // slot of its own ([image][workgroup][wave]), and amax_reduce -- one small workgroup per image, launched between producer and
@@ -619,7 +611,8 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     const float bound1 = fmaf(am_p, a.l1_c1, a.bmax_c1);
     const int e1 = cm_exp_of(fmaxf(am_p, bound1));
     const int ex = cm_exp_of(fmaf(bound1, a.l1_c2, fmaf(am_p, a.l1_ds, a.bmax_sum)));
-    const float sc1 = cm_scale_of(e1), un_c1 = a.inv_ws1 * cm_unscale_of(e1), un_c2 = a.inv_ws2 * cm_unscale_of(e1);
+    const float sc1 = cm_scale_of(e1), un_c1s = a.inv_ws1, un_c2 = a.inv_ws2 * cm_unscale_of(e1);      // conv1: unscale(e1) x sc1 = 1
+    const bool edge = ty0 == 0 || tx0 == 0 || ty0 + TH >= a.H || tx0 + TW >= a.W;
     const float scx = cm_scale_of(ex), un_a = a.inv_wsa * cm_unscale_of(ex);
     {   // stage the (TH+4) x (TW+4) tile of p1, split, zero outside the image
         const float* in = a.p1 + (size_t)b * P * 8;
@@ -643,7 +636,8 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     const uint4* zp = &zslot;
     {   // conv1 + ReLU -> mid (split).  Groups gi < 2 MH = (row gi / 2, columns 16 (gi & 1) .. + 15); the two rightmost columns of
         // all rows go to two extra groups: slot k of extra group e is position ((16 e + k) / 2, 32 + (k & 1))
-        const float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + 4 * g);
+        float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + 4 * g);
+        bias1.x *= sc1; bias1.y *= sc1; bias1.z *= sc1; bias1.w *= sc1;       // conv1's output is split at the scale of its input: the scale rides on the bias
         uint2* midh = reinterpret_cast<uint2*>(mid);
         // fixed trip count (the last round is empty for waves 2 and 3) so that two groups can be in flight per wave
 #pragma unroll 2
@@ -668,9 +662,8 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             }
             const int gy = ty0 - 1 + y, gx = tx0 - 1 + x;
             const bool inside = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;           // conv2 pads its INPUT with zeros
-            float4 v = make_float4(relu(fmaf(acc[0], un_c1, bias1.x)) * sc1, relu(fmaf(acc[1], un_c1, bias1.y)) * sc1,
-                                   relu(fmaf(acc[2], un_c1, bias1.z)) * sc1, relu(fmaf(acc[3], un_c1, bias1.w)) * sc1);
-            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v = make_float4(relu(fmaf(acc[0], un_c1s, bias1.x)), relu(fmaf(acc[1], un_c1s, bias1.y)), relu(fmaf(acc[2], un_c1s, bias1.z)), relu(fmaf(acc[3], un_c1s, bias1.w)));
+            if (edge && !inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 hi, lo;
             split4(v, hi, lo);
             if (y < MH) {
@@ -1145,13 +1138,10 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
 // Per 32-pixel tile: 12 f16 MFMAs (32 cycles) + 10 fp32 MFMAs (64 cycles) = 1024 matrix cycles instead of 2688.
 __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
 {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const h2v a = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(f[2 * i], f[2 * i + 1]));
-        const float r0 = f[2 * i] - (float)a[0], r1 = f[2 * i + 1] - (float)a[1];       // exact
-        const h2v b = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
-        hi[2 * i] = a[0]; hi[2 * i + 1] = a[1]; lo[2 * i] = b[0]; lo[2 * i + 1] = b[1];
-    }
+    uint4 a, b;
+    cm_split2(f[0], f[1], a.x, b.x); cm_split2(f[2], f[3], a.y, b.y);
+    cm_split2(f[4], f[5], a.z, b.z); cm_split2(f[6], f[7], a.w, b.w);
+    hi = __builtin_bit_cast(h8v, a); lo = __builtin_bit_cast(h8v, b);
 }
 
 // Pipelined stores: the 16 row stores of one half-tile are issued BETWEEN the matrix instructions of the other half (and the

@@ -181,13 +181,29 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 typedef _Float16 cm_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
 
+// x - (float)h for the low (HI = 0) or high (HI = 1) half of a packed f16 pair, in ONE instruction: v_fma_mix_f32 converts the
+// f16 source on the fly (exactly) and the fused multiply-add by 1.0 rounds once -- x - hi is exact anyway.  The plain form
+// (v_cvt_f32_f16 + v_sub_f32) costs two issue slots per element in kernels that are bound by vector issue.
+template <int HI>
+__device__ __forceinline__ float cm_residual(float x, unsigned packed)
+{
+    float r;
+    if (HI) asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(x));
+    else asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(x));
+    return r;
+}
+
+// fp32 x 2 -> (hi, lo) half-precision pairs: hi = f16(x) toward zero, lo = f16(x - hi)
+__device__ __forceinline__ void cm_split2(float x, float y, unsigned& hi, unsigned& lo)
+{
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y));
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(cm_residual<0>(x, hi), cm_residual<1>(y, hi)));
+}
+
 __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
 {
-    const cm_h2 a = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.x, v.y)), b = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.z, v.w));
-    const cm_h2 c = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.x - (float)a[0], v.y - (float)a[1]));
-    const cm_h2 d = __builtin_bit_cast(cm_h2, __builtin_amdgcn_cvt_pkrtz(v.z - (float)b[0], v.w - (float)b[1]));
-    hi = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
-    lo = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+    cm_split2(v.x, v.y, hi.x, lo.x);
+    cm_split2(v.z, v.w, hi.y, lo.y);
 }
 
 // ---- dynamic operand range (r03).  A split operand is exact to ~2^-22 only while its hi half does not saturate (|x| < 65504)
