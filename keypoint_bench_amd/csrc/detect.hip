@@ -167,28 +167,51 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep(NmsArgs a)
 // ------------------------------------------------------------------------------------------------
 // Specialised sweep for nms_dist 1..8 (compile-time radius): same rules as nms_sweep, with the two
 // window passes done on 8-pixel register strips -- a horizontal strip is five ds_read_b128 for
-// r = 6 instead of 104 ds_read_b32, the running maxima are built by doubling (width 2, 4, 8, 16) --
-// so one local round costs ~4 LDS accesses and ~15 VALU ops per pixel.
+// r = 6 instead of 104 ds_read_b32, the running maxima are built by tripling on v_max3_f32 (widths 3, 9) --
+// so one local round costs ~4 LDS accesses and ~10 VALU ops per pixel.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }       // one v_max3_f32
+
+// o[i] = max(a[i .. i+WIN-1]); NIN >= NOUT + WIN - 1.  Running maxima are built by TRIPLING on the three-input maximum (widths
+// 3, 9) and the window is covered by two or three of them, overlapping where they must: 38 instructions for eight outputs of a
+// 13-wide window (r = 6) where doubling on the two-input maximum (r02) took 61 -- the sweep is bound by vector issue.
 template <int WIN, int NOUT, int NIN>
 __device__ __forceinline__ void window_max(const float (&a)[NIN], float (&o)[NOUT])
 {
-    // o[i] = max(a[i .. i+WIN-1]); NIN >= NOUT + WIN - 1
     static_assert(NIN >= NOUT + WIN - 1, "window_max input too short");
+    static_assert(WIN >= 1 && WIN <= 18, "window_max: windows of up to 18");
     if constexpr (WIN == 1) {
 #pragma unroll
         for (int i = 0; i < NOUT; ++i) o[i] = a[i];
+    } else if constexpr (WIN == 2) {
+#pragma unroll
+        for (int i = 0; i < NOUT; ++i) o[i] = fmaxf(a[i], a[i + 1]);
     } else {
-        constexpr int P = WIN >= 16 ? 16 : (WIN >= 8 ? 8 : (WIN >= 4 ? 4 : 2));   // largest power of two <= WIN
-        float m[NIN];
+        constexpr int N3 = NOUT + WIN - 3;          // m3[i] = max a[i .. i+2], i < N3
+        float m3[N3];
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) m[i] = a[i];
+        for (int i = 0; i < N3; ++i) m3[i] = max3f(a[i], a[i + 1], a[i + 2]);
+        if constexpr (WIN == 3) {
 #pragma unroll
-        for (int w = 1; w < P; w <<= 1) {
+            for (int i = 0; i < NOUT; ++i) o[i] = m3[i];
+        } else if constexpr (WIN <= 6) {
 #pragma unroll
-            for (int i = 0; i + w < NIN; ++i) m[i] = fmaxf(m[i], m[i + w]);   // m[i] = max a[i .. i+2w-1] (in place, ascending i)
+            for (int i = 0; i < NOUT; ++i) o[i] = fmaxf(m3[i], m3[i + WIN - 3]);
+        } else if constexpr (WIN <= 8) {
+#pragma unroll
+            for (int i = 0; i < NOUT; ++i) o[i] = max3f(m3[i], m3[i + 3], m3[i + WIN - 3]);
+        } else {
+            constexpr int N9 = NOUT + WIN - 9;      // m9[i] = max a[i .. i+8], i < N9
+            float m9[N9];
+#pragma unroll
+            for (int i = 0; i < N9; ++i) m9[i] = max3f(m3[i], m3[i + 3], m3[i + 6]);
+            if constexpr (WIN == 9) {
+#pragma unroll
+                for (int i = 0; i < NOUT; ++i) o[i] = m9[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NOUT; ++i) o[i] = fmaxf(m9[i], m9[i + WIN - 9]);
+            }
         }
-#pragma unroll
-        for (int i = 0; i < NOUT; ++i) o[i] = fmaxf(m[i], m[i + WIN - P]);
     }
 }
 
