@@ -383,6 +383,7 @@ class PairRunner:
         self.batched_pairs = 0
         self.staged_batches = 0
         self._stager = None
+        self.decode_workers = None          # threads that run dataset[i] ahead of the staging thread (None: one per host core, at most 16)
 
     # ---- single pair (model_interface.py:189-212 + the task call)
     def test_step(self, batch, idx):
@@ -569,6 +570,9 @@ class PairRunner:
         def shape_of(a):
             return tuple(a.shape[:2]) if is_decoded_u8(a) else tuple(a.shape[-2:])
 
+        from .datasets import Prefetcher
+        fetched = Prefetcher(dataset, indices, workers=self.decode_workers)
+
         def produce():
             try:
                 group, key = [], None
@@ -584,8 +588,7 @@ class PairRunner:
                         q.put(("batch", group, pinned))
                     group = []
 
-                for i in indices:
-                    item = dataset[i]
+                for i, item in fetched:       # dataset[i], decoded / read a few items ahead on a thread pool (datasets.Prefetcher)
                     a, b = _host_array(item["image0"]), _host_array(item["image1"])
                     single = a is None or b is None or (task_type not in ("AUC", "FundamentalMatrixRansac") and not _homo_only(item))
                     if not single:
@@ -676,6 +679,7 @@ class PairRunner:
                 except queue.Empty:
                     pass
             th.join()
+            fetched.close()
         return [out[i] for i in indices]
 
     # ---- batched sequence (BASELINE configs[3]: brute-force branch)

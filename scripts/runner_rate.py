@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--host", action="store_true")
     ap.add_argument("--u8", action="store_true", help="with --host: items are decoded uint8 [H,W,3] images (a quarter of the PCIe bytes)")
+    ap.add_argument("--files", choices=["png", "jpeg"], default=None,
+                    help="items are image FILES, decoded by PIL on the runner's prefetch pool (keypoint_bench_amd/datasets.py: SURVEY 8(f)2's decode stage)")
+    ap.add_argument("--decode-workers", type=int, default=None)
     ap.add_argument("--dense", action="store_true")
     ap.add_argument("--tasks", nargs="+", default=["match_stats", "repeatability", "MHA", "AUC"])
     ap.add_argument("--sequence", action="store_true", help="a sequence dataset instead (frames sliding over one canvas): FundamentalMatrix and visual_odometer tasks")
@@ -49,6 +52,27 @@ def main():
         ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
                    "warp01_params": dict(mode="homo", homography_matrix=h01, width=W, height=H, intrinsics0=K, intrinsics1=K, pose01=T01),
                    "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(h01).astype(np.float32), width=W, height=H)})
+    decode_only = None
+    if args.files:      # the same views as encoded files on local disk (page cache after the first read, like a warmed dataset)
+        import tempfile
+        from PIL import Image
+        from keypoint_bench_amd import datasets
+        tmp = tempfile.mkdtemp(prefix="kpb_files_")
+        paths = []
+        for j in range(args.distinct):
+            pp = []
+            for k, v in enumerate(synthetic.image_pair(5000 + j, H, W)):
+                u8 = np.ascontiguousarray((v.transpose(1, 2, 0) * 255.0 + 0.5).astype(np.uint8))
+                f = os.path.join(tmp, "%d_%d.%s" % (j, k, args.files))
+                Image.fromarray(u8).save(f, format=args.files.upper(), quality=92)
+                pp.append(f)
+            paths.append(pp)
+        recs = [dict(it, image0=paths[i % args.distinct][0], image1=paths[i % args.distinct][1]) for i, it in enumerate(ds)]
+        ds = datasets.ImagePairFiles(recs)
+        t0 = time.perf_counter()        # what the decode pool alone delivers (no device work)
+        with datasets.Prefetcher(ds, range(args.pairs), workers=args.decode_workers) as pf:
+            n = sum(1 for _ in pf)
+        decode_only = round(n / (time.perf_counter() - t0), 1)
     if args.sequence:
         canvas, _ = synthetic.image_pair(4242, H + 64, W + 64)
         rng = np.random.default_rng(3)
@@ -62,7 +86,9 @@ def main():
                        "last_ground_truth": np.array([0.05 * max(i - 1, 0), 0, 0, 0, 0, 0, 1], np.float32)})
         if args.tasks == ["match_stats", "repeatability", "MHA", "AUC"]:
             args.tasks = ["FundamentalMatrix", "visual_odometer"]
-    out = {"pairs": args.pairs, "batch": args.batch, "items": ("host uint8 HWC" if args.u8 else "host numpy fp32 CHW") if args.host else "device tensors",
+    out = {"pairs": args.pairs, "batch": args.batch, "items": ("%s files decoded by PIL (%s threads)" % (args.files, args.decode_workers or "one per core, <= 16")) if args.files else
+           ("host uint8 HWC" if args.u8 else "host numpy fp32 CHW") if args.host else "device tensors",
+           "decode_pool_alone_pairs_per_s": decode_only,
            "descriptors": "dense-map" if args.dense else "keypoint-only"}
     for task in args.tasks:
         params = {"model_type": args.model, "task_type": task, "XFeat_params": {}, "FundamentalMatrix_params": {"th": 3.0}, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),
@@ -74,6 +100,7 @@ def main():
             from keypoint_bench_amd.models.XFeat import xfeat_random
             model = xfeat_random(9).eval()
         r = runner.PairRunner(params, model=model, device=dev, batch=args.batch, dense_descriptors=args.dense)
+        r.decode_workers = args.decode_workers
         try:
             agg, _ = r.run(ds)            # warm-up: allocations, first-shape workspaces
         except (ImportError, NotImplementedError) as e:

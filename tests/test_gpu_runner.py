@@ -224,3 +224,31 @@ def test_a_failing_batched_task_raises_instead_of_hanging(monkeypatch, fail_at):
     assert st.free.qsize() == st.slots and st.order.qsize() == 0            # every slot is back
     _, rows = r.run(good)
     assert rows.shape[0] == 6 and np.isfinite(rows[:, :3]).all()
+
+
+def test_encoded_image_files_go_through_the_decode_pool_and_give_the_rows_of_their_decoded_arrays(tmp_path):
+    """SURVEY 8(f)2, decode stage: PNG / JPEG files decoded by PIL on the prefetch pool (datasets.ImagePairFiles, as
+    megadepth.py:149-152), staged as uint8, transformed on the device -- the rows of handing the decoded arrays over directly."""
+    import io
+    from PIL import Image
+    from keypoint_bench_amd import datasets
+    ds = pair_dataset(7, shapes=((96, 128), (96, 128), (64, 96)))
+    recs, arrays = [], []
+    for j, it in enumerate(ds):
+        views = []
+        for v, name in ((it["image0"], "a"), (it["image1"], "b")):
+            u8 = np.ascontiguousarray((v.transpose(1, 2, 0) * 255.0 + 0.5).astype(np.uint8))
+            fmt = "PNG" if j % 2 == 0 else "JPEG"
+            path = tmp_path / ("%d%s.%s" % (j, name, fmt.lower()))
+            Image.fromarray(u8).save(path, format=fmt, quality=92)
+            views.append((str(path), datasets.decode_rgb(str(path))))
+        recs.append(dict(it, image0=views[0][0], image1=views[1][0] if j != 3 else open(views[1][0], "rb").read()))   # one item as bytes
+        arrays.append(dict(it, image0=views[0][1], image1=views[1][1]))
+    r_files = runner.PairRunner(params("repeatability"), device=DEV, batch=4)
+    r_files.decode_workers = 3
+    _, rows_files = r_files.run(datasets.ImagePairFiles(recs))
+    r_arr = runner.PairRunner(params("repeatability"), device=DEV, batch=4)
+    _, rows_arr = r_arr.run(arrays)
+    assert r_files.batched_pairs == 7 and r_files.staged_batches > 0
+    assert np.array_equal(rows_files.view(np.uint64), rows_arr.view(np.uint64))
+    assert rows_files[:, 0].min() > 20
