@@ -1,11 +1,19 @@
 #!/bin/bash
-# Bench lines of the other §8(a) rows (N2..N5), run on the GPU box:  bash scripts/collect_other_nets.sh r01
-R=${1:-r01}
+# Bench lines and per-kernel PMC summaries of the other 8(a) rows (N2..N5), run on the GPU box:  bash scripts/collect_other_nets.sh r03 [pmc]
+# With a second argument the PMC passes (scripts/prof_pmc.sh: SQ, matrix-pipe, FETCH_SIZE, WRITE_SIZE, GRBM) run for SuperPoint,
+# DISK + LightGlue and XFeat as well.
+R=${1:-r03}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$R
 for spec in "superpoint brute_force" "xfeat brute_force" "disk brute_force" "superpoint lightglue" "disk lightglue"; do
   set -- $spec
   timeout -k 10 300 python bench.py --model $1 --matcher $2 --no-cpu-baseline > gpurun_out/$R/bench_$1_$2.json 2> gpurun_out/$R/bench_$1_$2.err || echo "$spec failed"
 done
+if [ -n "$2" ] || [ -n "$PMC" ]; then
+  bash scripts/prof_pmc.sh ${R}_superpoint --model superpoint > gpurun_out/$R/pmc_superpoint.txt 2>&1
+  bash scripts/prof_pmc.sh ${R}_disk_lightglue --model disk --matcher lightglue > gpurun_out/$R/pmc_disk_lightglue.txt 2>&1
+  bash scripts/prof_pmc.sh ${R}_xfeat --model xfeat > gpurun_out/$R/pmc_xfeat.txt 2>&1
+fi
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("gpurun_out/$R/bench_*_*.json")):

@@ -47,8 +47,8 @@ def prof_name(k):
             return name
     return None
 for k in names:
-    if prof_name(k) and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         f = agg[k]["FETCH_SIZE"] / calls[k]["FETCH_SIZE"]; w = agg[k]["WRITE_SIZE"] / calls[k]["WRITE_SIZE"]
-        traffic[prof_name(k)] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024), "avg_us": dur[k] / max(ncall[k], 1)}
+        traffic[prof_name(k) or k] = {"fetch_kib_raw": f, "write_kib": w, "bytes_per_launch": int((2 * f + w) * 1024), "avg_us": dur[k] / max(ncall[k], 1)}
 if len(sys.argv) > 2:
     json.dump(traffic, open(sys.argv[2], "w"), indent=1)

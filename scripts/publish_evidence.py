@@ -12,4 +12,21 @@ shutil.copy(os.path.join(src, R, "bench_sparse.json"), os.path.join(dst, "%s_ben
 for mode in ("dense", "sparse"):
     shutil.copy(os.path.join(src, "pmc_%s_%s" % (R, mode), "summary.txt"), os.path.join(dst, "%s_pmc_per_kernel_b%d_%s.csv" % (R, B, mode)))
     shutil.copy(os.path.join(src, "pmc_%s_%s" % (R, mode), "traffic.json"), os.path.join(dst, "pmc_traffic_b%d_%s.json" % (B, mode)))
+for extra in ("bench_spawn_w1.json", "single_pair_latency.txt", "bench_profiled.json"):
+    f = os.path.join(src, R, extra)
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s" % (R, extra)))
+for f in glob.glob(os.path.join(src, R, "bench_*_*.json")):
+    name = os.path.basename(f)
+    if name.startswith(("bench_superpoint", "bench_xfeat", "bench_disk")) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s" % (R, name)))
+for net in ("superpoint", "disk_lightglue", "xfeat"):
+    d = os.path.join(src, "pmc_%s_%s" % (R, net))
+    if os.path.exists(os.path.join(d, "summary.txt")):
+        shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, "%s_pmc_per_kernel_%s.csv" % (R, net)))
+        if os.path.exists(os.path.join(d, "traffic.json")):
+            shutil.copy(os.path.join(d, "traffic.json"), os.path.join(dst, "%s_pmc_traffic_%s.json" % (R, net)))
+for f in glob.glob(os.path.join(src, R, "runner_rate*.json")) + glob.glob(os.path.join(src, R, "parity_sweep*.json")):
+    if os.path.getsize(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s" % (R, os.path.basename(f))))
 print("published", R, "value", b["value"], "roofline", {k: b["roofline"][k] for k in ("kernel", "frac", "avg_ms", "traffic")})
