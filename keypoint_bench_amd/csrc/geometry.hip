@@ -93,11 +93,12 @@ extern "C" __attribute__((visibility("default"))) int kpb_epipolar_error(
 // RNG); the numpy restatement is oracle/geometry_ref.py, hypothesis for hypothesis the same.  One 256-thread workgroup
 // per image pair:
 //   * the matched rows are scaled to pixels in fp32 exactly as MHA.py:41-42 does and parked in LDS;
-//   * a round = 256 hypotheses, one per thread: four distinct indices from a counter-based generator, the exact model
-//     in closed form (projective basis: two 3x3 adjugates, registers only), OpenCV's degeneracy tests, then every thread
-//     scores ALL matches against its own model (LDS broadcast reads);
-//   * the workgroup keeps the model with strictly more inliers (ties: the lower iteration), adapts the iteration count
-//     as RANSACUpdateNumIters does, and stops at the first round boundary past it;
+//   * a round = 256 hypotheses, one per thread: the subsets come from OpenCV's own generator (cv::RNG + getSubset + checkSubset,
+//     produced sequentially by one thread: see CvRng), the exact model in closed form (projective basis: two 3x3 adjugates,
+//     registers only), then every thread scores ALL matches against its own model (LDS broadcast reads);
+//   * OpenCV's keep / niters rule (more inliers than any earlier model; RANSACUpdateNumIters after every kept model) is applied
+//     to the round's results in iteration order, so the hypothesis stream, the kept model and the iteration at which the loop
+//     ends are those of OpenCV's sequential loop;
 //   * refit on the inliers: normalised inhomogeneous DLT (8x8 normal equations, 44 block-reduced sums) and up to ten
 //     Levenberg-Marquardt steps on the forward reprojection error.  All estimator arithmetic is fp64.
 namespace {
@@ -105,34 +106,120 @@ namespace {
 constexpr int RS_THREADS = 256;
 constexpr double RS_EPS = 2.220446049250313e-16;
 
-__device__ __forceinline__ uint32_t lowbias32(uint32_t h)
+// ---- OpenCV's sampler (r03).  cv::RNG is a multiply-with-carry generator on a 64-bit state; RANSACPointSetRegistrator::run seeds
+// it with (uint64)-1 at EVERY call (seed 0 here), draws each index of a subset until it differs from the ones already picked,
+// and redraws the whole subset -- up to 10 000 times, without spending an iteration -- until checkSubset accepts it
+// (modules/calib3d/src/ptsetreg.cpp, OpenCV 4.9: requirements.txt:2).  The stream is sequential, so ONE thread produces the
+// subsets of a round (256 hypotheses) and every thread then evaluates one of them; the keep / niters rule is applied to the
+// round's results in iteration order (scan_round), which gives what OpenCV's sequential loop gives.
+struct CvRng {
+    unsigned long long s;
+    __device__ __forceinline__ unsigned next() { s = (unsigned long long)(unsigned)s * 4164903690ull + (s >> 32); return (unsigned)s; }
+    __device__ __forceinline__ int uniform(int n) { return (int)(next() % (unsigned)n); }      // rng.uniform(0, n), n > 0
+};
+
+__device__ __forceinline__ unsigned long long rng_state(uint32_t seed)
 {
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    return h;
+    return seed == 0u ? ~0ull : (((unsigned long long)(seed ^ 0x9E3779B9u) << 32) | (unsigned long long)seed);
 }
 
-__device__ __forceinline__ int sample_index(uint32_t seed, uint32_t it, uint32_t draw, int n)
+constexpr int GETSUBSET_ATTEMPTS = 10000;
+
+// thread 0 only.  s_idx[j][0..M) = the subset of hypothesis j of this round; s_ok[j] = 0 from the first getSubset failure on.
+template <int M, class Check>
+__device__ void gen_round(CvRng& rng, int n, unsigned short* s_idx, unsigned char* s_ok, bool& alive, Check check)
 {
-    const uint32_t h = lowbias32(seed ^ (it * 0x9E3779B1u) ^ (draw * 0x85EBCA77u));
-    return (int)(((unsigned long long)h * (unsigned long long)n) >> 32);
+    for (int j = 0; j < 256; ++j) {
+        int idx[M];
+#pragma unroll
+        for (int i = 0; i < M; ++i) idx[i] = 0;
+        bool found = false;
+        if (alive) {
+            for (int att = 0; att < GETSUBSET_ATTEMPTS && !found; ++att) {
+#pragma unroll
+                for (int i = 0; i < M; ++i) {
+                    int c;
+                    bool dup;
+                    do {
+                        c = rng.uniform(n);
+                        dup = false;
+#pragma unroll
+                        for (int k = 0; k < M; ++k) dup |= (k < i) && idx[k] == c;
+                    } while (dup);
+                    idx[i] = c;
+                }
+                found = check(idx);
+            }
+        }
+        alive = alive && found;
+        s_ok[j] = alive ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) s_idx[j * M + i] = (unsigned short)(alive ? idx[i] : 0);
+    }
 }
 
+struct RsState { int niters, max_good, iters, stop, failed; };
+
+__device__ int update_iters(double conf, double outlier_ratio, int m, int max_iters);
+
+// thread 0 only: RANSACPointSetRegistrator::run's keep / niters rule over one round, in iteration order.  s_cnt[j][s] = inliers
+// of model s of hypothesis j (0 for a void model).  Returns the (hypothesis, slot) kept LAST in this round, or -1.
+template <int M, int NM>
+__device__ int scan_round(const int* s_cnt, const unsigned char* s_ok, int base, int n, double conf, RsState& st)
+{
+    int best = -1;
+    for (int j = 0; j < 256; ++j) {
+        const int it = base + j;
+        if (it >= st.niters) { st.stop = 1; break; }
+        if (!s_ok[j]) { st.failed = it == 0; st.stop = 1; break; }        // `if (iter == 0) return false; break;`
+        for (int sl = 0; sl < NM; ++sl) {
+            const int c = s_cnt[j * NM + sl];
+            if (c > max(st.max_good, M - 1)) {
+                best = j * NM + sl;
+                st.max_good = c;
+                st.niters = update_iters(conf, (double)(n - c) / n, M, st.niters);
+            }
+        }
+        st.iters = it + 1;
+    }
+    return best;
+}
+
+// OpenCV's haveCollinearPoints(m, count): the LAST of `count` points against every pair of earlier ones (FLT_EPSILON test)
 template <int M>
-__device__ __forceinline__ bool draw_samples(uint32_t seed, uint32_t it, int n, int* idx)
+__device__ __forceinline__ bool last_collinear(const double* x /* M x (u, v) */)
 {
-    int have = 0;
-    for (int d = 0; d < 4 * M; ++d) {
-        const int c = sample_index(seed, it, d, n);
-        bool dup = false;
+    bool bad = false;
 #pragma unroll
-        for (int j = 0; j < M; ++j) dup |= (j < have) && idx[j] == c;
-        if (have < M && !dup) {
+    for (int j = 0; j < M - 1; ++j) {
+        const double dx1 = x[2 * j] - x[2 * (M - 1)], dy1 = x[2 * j + 1] - x[2 * (M - 1) + 1];
 #pragma unroll
-            for (int j = 0; j < M; ++j) if (j == have) idx[j] = c;
-            ++have;
+        for (int k = 0; k < M - 1; ++k) {
+            const double dx2 = x[2 * k] - x[2 * (M - 1)], dy2 = x[2 * k + 1] - x[2 * (M - 1) + 1];
+            if (k < j) bad = bad || fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
         }
     }
-    return have == M;
+    return bad;
+}
+
+__device__ __forceinline__ double det3x3(const double* m)      // cv::determinant(Matx33d)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// HomographyEstimatorCallback::checkSubset on a 4-point sample (s, d: x0 y0 x1 y1 ...)
+__device__ bool check_subset_h(const double* s, const double* d)
+{
+    if (last_collinear<4>(s) || last_collinear<4>(d)) return false;
+    const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+    int negative = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int* t = tt[i];
+        const double A[9] = {s[2 * t[0]], s[2 * t[0] + 1], 1.0, s[2 * t[1]], s[2 * t[1] + 1], 1.0, s[2 * t[2]], s[2 * t[2] + 1], 1.0};
+        const double B[9] = {d[2 * t[0]], d[2 * t[0] + 1], 1.0, d[2 * t[1]], d[2 * t[1] + 1], 1.0, d[2 * t[2]], d[2 * t[2] + 1], 1.0};
+        negative += det3x3(A) * det3x3(B) < 0;
+    }
+    return negative == 0 || negative == 4;
 }
 
 struct M3 { double m[9]; };
@@ -292,7 +379,6 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_homography(RansacArgs a)
     float4* pts = reinterpret_cast<float4*>(smem);                       // [n] (x, y, u, v) pixels
     __shared__ double scratch[(RS_THREADS / 64 + 1) * 45];
     __shared__ double bestH[9], sys[72], hcur[9];
-    __shared__ unsigned long long wkey[RS_THREADS / 64];
     __shared__ int s_flag;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.k_dev ? min(a.k_dev[b], a.max_k) : a.max_k;
@@ -315,7 +401,6 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_homography(RansacArgs a)
         return;
     }
     const double t2 = a.threshold * a.threshold;
-    int done = 0, niters = a.max_iters, best = 0;
     if (n == 4) {                       // the minimal set: the model itself, every point an inlier (OpenCV skips RANSAC)
         if (tid == 0) {
             double s[8], d[8], H[9];
@@ -327,42 +412,52 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_homography(RansacArgs a)
         }
         return;
     }
-    while (done < niters) {
-        const uint32_t it = (uint32_t)(done + tid);
-        int idx[4] = {0, 0, 0, 0};
-        bool ok = draw_samples<4>(seed, it, n, idx) && (int)it < a.max_iters;
+    __shared__ unsigned short s_idx[RS_THREADS * 4];
+    __shared__ unsigned char s_ok[RS_THREADS];
+    __shared__ int s_cnt[RS_THREADS];
+    __shared__ int s_ctl[4];            // niters, stop, kept (hypothesis of this round, -1: none), failed
+    CvRng rng{rng_state(seed)};
+    RsState st{max(a.max_iters, 1), 0, 0, 0, 0};
+    bool alive = true;
+    int base = 0;
+    bool have = false;
+    for (;;) {
+        if (tid == 0)
+            gen_round<4>(rng, n, s_idx, s_ok, alive, [&](const int* idx) {
+                double s[8], d[8];
+                for (int j = 0; j < 4; ++j) { const float4 p = pts[idx[j]]; s[2 * j] = p.x; s[2 * j + 1] = p.y; d[2 * j] = p.z; d[2 * j + 1] = p.w; }
+                return check_subset_h(s, d);
+            });
+        __syncthreads();
         double s[8], d[8], H[9];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const float4 p = pts[idx[j]]; s[2 * j] = p.x; s[2 * j + 1] = p.y; d[2 * j] = p.z; d[2 * j + 1] = p.w; }
-        ok = homography_4pt(s, d, H) && ok;
+        for (int j = 0; j < 4; ++j) { const float4 p = pts[s_idx[tid * 4 + j]]; s[2 * j] = p.x; s[2 * j + 1] = p.y; d[2 * j] = p.z; d[2 * j + 1] = p.w; }
+        const bool ok = homography_4pt(s, d, H) && s_ok[tid];
         int cnt = 0;
         for (int i = 0; i < n; ++i) {
             const float4 p = pts[i];
             cnt += reproj_err2(H, p.x, p.y, p.z, p.w) <= t2;
         }
-        if (!ok) cnt = 0;
-        // workgroup arg-max: more inliers first, then the lower iteration
-        unsigned long long key = ((unsigned long long)(unsigned)cnt << 32) | (unsigned long long)(0xFFFFFFFFu - it);
-        unsigned long long kmax = key;
-        for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_down(kmax, o); kmax = t > kmax ? t : kmax; }
-        if ((tid & 63) == 0) wkey[tid >> 6] = kmax;
+        s_cnt[tid] = ok ? cnt : 0;
         __syncthreads();
-        kmax = wkey[0];
-        for (int w = 1; w < RS_THREADS / 64; ++w) kmax = wkey[w] > kmax ? wkey[w] : kmax;
-        const int top = (int)(kmax >> 32);
-        if (top > max(best, 3)) {
-            best = top;
-            if (key == kmax) for (int i = 0; i < 9; ++i) bestH[i] = H[i];
+        if (tid == 0) {
+            const int kept = scan_round<4, 1>(s_cnt, s_ok, base, n, a.confidence, st);
+            s_ctl[0] = st.niters; s_ctl[1] = st.stop; s_ctl[2] = kept; s_ctl[3] = st.failed;
         }
         __syncthreads();
-        done += RS_THREADS;
-        niters = best ? update_iters(a.confidence, (double)(n - best) / n, 4, a.max_iters) : a.max_iters;
+        if (s_ctl[2] == tid) for (int i = 0; i < 9; ++i) bestH[i] = H[i];
+        have = have || s_ctl[2] >= 0;
+        base += RS_THREADS;
+        const bool more = !s_ctl[1] && base < s_ctl[0];
+        __syncthreads();
+        if (!more) break;
     }
-    if (best == 0) {
+    if (!have) {
         if (tid < 9) Hout[tid] = 0.0;
-        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = done; info[3] = 0; }
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = st.iters; info[3] = 0; }
         return;
     }
+    const int best_inliers = st.max_good;
     // ---- inliers of the best model
     double Hb[9];
     for (int i = 0; i < 9; ++i) Hb[i] = bestH[i];
@@ -467,7 +562,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_homography(RansacArgs a)
     } else if (tid < 9) {
         Hout[tid] = Hb[tid];
     }
-    if (tid == 0) { info[0] = 1; info[1] = best; info[2] = done; info[3] = 0; }
+    if (tid == 0) { info[0] = 1; info[1] = best_inliers; info[2] = st.iters; info[3] = 0; }
 }
 
 }  // namespace
@@ -746,7 +841,6 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_essential(EssArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* P = reinterpret_cast<double*>(smem);                     // [n][4]
     __shared__ double bestE[9];
-    __shared__ unsigned long long wkey[RS_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.k_dev ? min(a.k_dev[b], a.max_k) : a.max_k;
     const uint32_t seed = a.seed_dev ? a.seed_dev[b] : a.seed;
@@ -779,54 +873,58 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_essential(EssArgs a)
         return;
     }
     const double t2 = a.thr[b] * a.thr[b];
-    int done = 0, niters = a.max_iters, best = 0;
-    while (done < niters) {
-        const uint32_t it = (uint32_t)(done + tid);
-        int idx[5] = {0, 0, 0, 0, 0};
-        const bool ok = draw_samples<5>(seed, it, n, idx) && (int)it < a.max_iters;
+    __shared__ unsigned short s_idx[RS_THREADS * 5];
+    __shared__ unsigned char s_ok[RS_THREADS];
+    __shared__ int s_cnt[RS_THREADS * 10];
+    __shared__ int s_ctl[4];            // niters, stop, kept (hypothesis * 10 + root slot of this round, -1: none), failed
+    CvRng rng{rng_state(seed)};
+    RsState st{max(a.max_iters, 1), 0, 0, 0, 0};
+    bool alive = true, have = false;
+    int base = 0;
+    for (;;) {
+        if (tid == 0) {
+            if (n == 5) {       // `count == modelPoints`: the one sample, no loop (EMEstimatorCallback has no checkSubset)
+                for (int j = 0; j < RS_THREADS; ++j) { s_ok[j] = j == 0; for (int i = 0; i < 5; ++i) s_idx[j * 5 + i] = (unsigned short)i; }
+                st.niters = 1;
+            } else
+                gen_round<5>(rng, n, s_idx, s_ok, alive, [](const int*) { return true; });
+        }
+        __syncthreads();
         double x1[10], x2[10];
-        for (int j = 0; j < 5; ++j) { x1[2 * j] = P[4 * idx[j]]; x1[2 * j + 1] = P[4 * idx[j] + 1]; x2[2 * j] = P[4 * idx[j] + 2]; x2[2 * j + 1] = P[4 * idx[j] + 3]; }
+        for (int j = 0; j < 5; ++j) { const int q = s_idx[tid * 5 + j]; x1[2 * j] = P[4 * q]; x1[2 * j + 1] = P[4 * q + 1]; x2[2 * j] = P[4 * q + 2]; x2[2 * j + 1] = P[4 * q + 3]; }
         double E[10][9];
         bool valid[10];
         int nv = 0;
-        if (ok) nv = essential_5pt(x1, x2, E, valid);
-        int bcnt = 0, bslot = 0;
-        if (nv) {
-            for (int s = 0; s < 10; ++s) {
-                if (!valid[s]) continue;
-                int cnt = 0;
+        if (s_ok[tid]) nv = essential_5pt(x1, x2, E, valid);
+        for (int s = 0; s < 10; ++s) {
+            int cnt = 0;
+            if (nv && valid[s])
                 for (int i = 0; i < n; ++i) cnt += sampson_err(E[s], P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) <= t2;
-                if (cnt > bcnt) { bcnt = cnt; bslot = s; }          // first maximum: the lowest root slot
-            }
-        }
-        // workgroup arg-max: more inliers, then the lower iteration, then the lower root slot
-        const unsigned low = (0x0FFFFFFFu - it) * 16u + (15u - (unsigned)bslot);
-        const unsigned long long key = ((unsigned long long)(unsigned)bcnt << 32) | low;
-        unsigned long long kmax = key;
-        for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_down(kmax, o); kmax = t > kmax ? t : kmax; }
-        if ((tid & 63) == 0) wkey[tid >> 6] = kmax;
-        __syncthreads();
-        kmax = wkey[0];
-        for (int w = 1; w < RS_THREADS / 64; ++w) kmax = wkey[w] > kmax ? wkey[w] : kmax;
-        const int top = (int)(kmax >> 32);
-        if (top > max(best, 4)) {
-            best = top;
-            if (key == kmax) for (int e = 0; e < 9; ++e) bestE[e] = E[bslot][e];
+            s_cnt[tid * 10 + s] = cnt;
         }
         __syncthreads();
-        done += RS_THREADS;
-        niters = best ? update_iters(a.prob, (double)(n - best) / n, 5, a.max_iters) : a.max_iters;
+        if (tid == 0) {
+            const int kept = scan_round<5, 10>(s_cnt, s_ok, base, n, a.prob, st);
+            s_ctl[0] = st.niters; s_ctl[1] = st.stop; s_ctl[2] = kept; s_ctl[3] = st.failed;
+        }
+        __syncthreads();
+        if (s_ctl[2] >= 0 && s_ctl[2] / 10 == tid) for (int e = 0; e < 9; ++e) bestE[e] = E[s_ctl[2] % 10][e];
+        have = have || s_ctl[2] >= 0;
+        base += RS_THREADS;
+        const bool more = !s_ctl[1] && base < s_ctl[0];
+        __syncthreads();
+        if (!more) break;
     }
-    if (best == 0) {
+    if (!have) {
         if (tid < 9) Eout[tid] = 0.0;
-        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = done; info[3] = 0; }
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = st.iters; info[3] = 0; }
         return;
     }
     double Eb[9];
     for (int e = 0; e < 9; ++e) Eb[e] = bestE[e];
     for (int i = tid; i < n; i += RS_THREADS) mask[i] = sampson_err(Eb, P[4 * i], P[4 * i + 1], P[4 * i + 2], P[4 * i + 3]) <= t2;
     if (tid < 9) Eout[tid] = Eb[tid];
-    if (tid == 0) { info[0] = 1; info[1] = best; info[2] = done; info[3] = 0; }
+    if (tid == 0) { info[0] = 1; info[1] = st.max_good; info[2] = st.iters; info[3] = 0; }
 }
 
 // ---- recoverPose: SVD of E (Jacobi on E^T E), the four (R, t), depth signs of the masked points, the best combination
@@ -952,19 +1050,6 @@ __global__ __launch_bounds__(RS_THREADS) void recover_pose(PoseArgs a)
 // its real roots in closed form, up to three models, each scored against all matches with OpenCV's error (the larger
 // squared point-to-epipolar-line distance, rounded to float32 as OpenCV stores it).  The winning minimal model is returned
 // as it is (OpenCV does not refit it).
-__device__ __forceinline__ bool last_collinear7(const double* x /* 7 x (u, v) */)
-{
-    bool bad = false;
-    for (int j = 0; j < 6; ++j) {
-        const double dx1 = x[2 * j] - x[12], dy1 = x[2 * j + 1] - x[13];
-        for (int k = 0; k < j; ++k) {
-            const double dx2 = x[2 * k] - x[12], dy2 = x[2 * k + 1] - x[13];
-            bad = bad || fabs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2));
-        }
-    }
-    return bad;
-}
-
 __device__ __forceinline__ double det3r(const double* r0, const double* r1, const double* r2)
 {
     return r0[0] * (r1[1] * r2[2] - r1[2] * r2[1]) - r0[1] * (r1[0] * r2[2] - r1[2] * r2[0]) + r0[2] * (r1[0] * r2[1] - r1[1] * r2[0]);
@@ -1048,7 +1133,6 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_fundamental(FundArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float4* pts = reinterpret_cast<float4*>(smem);                       // [n] (u1, v1, u2, v2) pixels
     __shared__ double bestF[9];
-    __shared__ unsigned long long wkey[RS_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = a.k_dev ? min(a.k_dev[b], a.max_k) : a.max_k;
     const uint32_t seed = a.seed_dev ? a.seed_dev[b] : a.seed;
@@ -1069,54 +1153,57 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_fundamental(FundArgs a)
         return;
     }
     const float t2 = (float)(a.threshold * a.threshold);
-    int done = 0, niters = a.max_iters, best = 0;
-    while (done < niters) {
-        const uint32_t it = (uint32_t)(done + tid);
-        int idx[7] = {0, 0, 0, 0, 0, 0, 0};
-        bool ok = draw_samples<7>(seed, it, n, idx) && (int)it < a.max_iters;
+    __shared__ unsigned short s_idx[RS_THREADS * 7];
+    __shared__ unsigned char s_ok[RS_THREADS];
+    __shared__ int s_cnt[RS_THREADS * 3];
+    __shared__ int s_ctl[4];            // niters, stop, kept (hypothesis * 3 + root slot of this round, -1: none), failed
+    CvRng rng{rng_state(seed)};
+    RsState st{max(a.max_iters, 1), 0, 0, 0, 0};
+    bool alive = true, have = false;
+    int base = 0;
+    for (;;) {
+        if (tid == 0)
+            gen_round<7>(rng, n, s_idx, s_ok, alive, [&](const int* idx) {       // FMEstimatorCallback::checkSubset
+                double x1[14], x2[14];
+                for (int j = 0; j < 7; ++j) { const float4 q = pts[idx[j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
+                return !last_collinear<7>(x1) && !last_collinear<7>(x2);
+            });
+        __syncthreads();
         double x1[14], x2[14];
-        for (int j = 0; j < 7; ++j) { const float4 q = pts[idx[j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
-        ok = ok && !last_collinear7(x1) && !last_collinear7(x2);
+        for (int j = 0; j < 7; ++j) { const float4 q = pts[s_idx[tid * 7 + j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
         double F[3][9];
         bool valid[3] = {false, false, false};
         int nv = 0;
-        if (ok) nv = fundamental_7pt(x1, x2, F, valid);
-        int bcnt = 0, bslot = 0;
-        if (nv) {
-            for (int s = 0; s < 3; ++s) {
-                if (!valid[s]) continue;
-                int cnt = 0;
+        if (s_ok[tid]) nv = fundamental_7pt(x1, x2, F, valid);
+        for (int s = 0; s < 3; ++s) {
+            int cnt = 0;
+            if (nv && valid[s])
                 for (int i = 0; i < n; ++i) { const float4 q = pts[i]; cnt += fm_err(F[s], q.x, q.y, q.z, q.w) <= t2; }
-                if (cnt > bcnt) { bcnt = cnt; bslot = s; }
-            }
-        }
-        const unsigned low = (0x0FFFFFFFu - it) * 16u + (15u - (unsigned)bslot);
-        const unsigned long long key = ((unsigned long long)(unsigned)bcnt << 32) | low;
-        unsigned long long kmax = key;
-        for (int o = 32; o; o >>= 1) { const unsigned long long t = __shfl_down(kmax, o); kmax = t > kmax ? t : kmax; }
-        if ((tid & 63) == 0) wkey[tid >> 6] = kmax;
-        __syncthreads();
-        kmax = wkey[0];
-        for (int w = 1; w < RS_THREADS / 64; ++w) kmax = wkey[w] > kmax ? wkey[w] : kmax;
-        const int top = (int)(kmax >> 32);
-        if (top > max(best, 6)) {
-            best = top;
-            if (key == kmax) for (int e = 0; e < 9; ++e) bestF[e] = F[bslot][e];
+            s_cnt[tid * 3 + s] = cnt;
         }
         __syncthreads();
-        done += RS_THREADS;
-        niters = best ? update_iters(a.confidence, (double)(n - best) / n, 7, a.max_iters) : a.max_iters;
+        if (tid == 0) {
+            const int kept = scan_round<7, 3>(s_cnt, s_ok, base, n, a.confidence, st);
+            s_ctl[0] = st.niters; s_ctl[1] = st.stop; s_ctl[2] = kept; s_ctl[3] = st.failed;
+        }
+        __syncthreads();
+        if (s_ctl[2] >= 0 && s_ctl[2] / 3 == tid) for (int e = 0; e < 9; ++e) bestF[e] = F[s_ctl[2] % 3][e];
+        have = have || s_ctl[2] >= 0;
+        base += RS_THREADS;
+        const bool more = !s_ctl[1] && base < s_ctl[0];
+        __syncthreads();
+        if (!more) break;
     }
-    if (best == 0) {
+    if (!have) {
         if (tid < 9) Fout[tid] = 0.0;
-        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = done; info[3] = 0; }
+        if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = st.iters; info[3] = 0; }
         return;
     }
     double Fb[9];
     for (int e = 0; e < 9; ++e) Fb[e] = bestF[e];
     for (int i = tid; i < n; i += RS_THREADS) { const float4 q = pts[i]; mask[i] = fm_err(Fb, q.x, q.y, q.z, q.w) <= t2; }
     if (tid < 9) Fout[tid] = Fb[tid];
-    if (tid == 0) { info[0] = 1; info[1] = best; info[2] = done; info[3] = 0; }
+    if (tid == 0) { info[0] = 1; info[1] = st.max_good; info[2] = st.iters; info[3] = 0; }
 }
 
 }  // namespace

@@ -57,7 +57,7 @@ def auc(idx, img_0, score_map_0, desc_map_0, img_1, score_map_1, desc_map_1, war
     if m_pts0.shape[0] < 5:                                                                     # estimate_pose: `if len(kpts0) < 5: return None`
         return {"AUC": 180, "inliers": 0}
     rt, mask, good, _ = estimate_pose(m_pts0[:, 0:2], m_pts1[:, 0:2], [w0 - 1, h0 - 1, w1 - 1, h1 - 1], _np(warp01["intrinsics0"]),
-                                      _np(warp01["intrinsics1"]), thresh=1., seed=idx)
+                                      _np(warp01["intrinsics1"]), thresh=1., seed=0)      # cv::RNG restarts from (uint64)-1 at every cv2 call: seed 0 = that state
     return _row(rt[0].cpu().numpy(), good[0], mask[0].cpu().numpy(), warp01)
 
 
@@ -67,8 +67,7 @@ def auc_batch(pipe, items, params, indices=None):
     pad = lambda xs: xs + [xs[-1]] * (B - f)
     K0 = np.stack(pad([_np(it["warp01_params"]["intrinsics0"]) for it in items]))
     K1 = np.stack(pad([_np(it["warp01_params"]["intrinsics1"]) for it in items]))
-    seeds = list(indices if indices is not None else range(f)) + [0] * (B - f)
-    rt, mask, good, _ = estimate_pose(pipe.m0, pipe.m1, [pipe.W - 1, pipe.H - 1, pipe.W - 1, pipe.H - 1], K0, K1, thresh=1., k_dev=pipe.k, seeds=seeds)
+    rt, mask, good, _ = estimate_pose(pipe.m0, pipe.m1, [pipe.W - 1, pipe.H - 1, pipe.W - 1, pipe.H - 1], K0, K1, thresh=1., k_dev=pipe.k)       # seed 0 for every pair: OpenCV's RNG state at every call
     rt, mask, good = rt.cpu().numpy(), mask.cpu().numpy(), good.cpu().numpy()
 
     def rows():                 # the host half (135-154), on host copies: the runner runs it under the next batch's kernels

@@ -95,7 +95,7 @@ def ransac_in_contract(step, image_0, image_1, score_map_0, score_map_1, desc_ma
 def fundamental_matrix_ransac(step, image_0, image_1, score_map_0, score_map_1, desc_map_0, desc_map_1, matcher, params, seed=None):
     """tasks/FundamentalMatrix.py:12-86 without its cv2 drawing (save_result must be off).  Returns the reference's dict:
     fundamental_error 0, fundamental_radio = kept keypoints / detected keypoints, fundamental_num = kept keypoints.
-    `seed` (default: step) drives the RANSAC sampler."""
+    `seed` drives the RANSAC sampler (default 0: the state OpenCV's RNG has at every cv2 call)."""
     from ..utils.extracter import detection
     from ..utils.mvg import find_fundamental
     h, w = score_map_0.shape[2], score_map_0.shape[3]
@@ -107,7 +107,7 @@ def fundamental_matrix_ransac(step, image_0, image_1, score_map_0, score_map_1, 
     if n < 8:                       # utils/mvg.py:13-15: no estimate, every match kept
         kept = n
     else:                           # 76-78: (x, y) scaled by (w - 1, h - 1) in fp32, then cv2.findFundamentalMat(FM_RANSAC)
-        _, mask, info = find_fundamental(kps0[None, :, :-1], kps1[None, :, :-1], [w - 1, h - 1, w - 1, h - 1], seed=step if seed is None else seed)
+        _, mask, info = find_fundamental(kps0[None, :, :-1], kps1[None, :, :-1], [w - 1, h - 1, w - 1, h - 1], seed=0 if seed is None else seed)
         found, kept = (int(v) for v in info[0, :2].cpu())
         if not found:               # cv2 returns (None, None) and utils/mvg.py:17 fails on it
             raise AttributeError("'NoneType' object has no attribute 'ravel'")
@@ -117,12 +117,11 @@ def fundamental_matrix_ransac(step, image_0, image_1, score_map_0, score_map_1, 
 
 def fundamental_ransac_batch(pipe, items, params, indices=None):
     """The FundamentalMatrixRansac rows [error 0, ratio, num] of a whole PairPipeline batch (brute-force branch): one
-    launch of the 7-point RANSAC over the batch's matches; sampler seed of a pair = its index in the run."""
+    launch of the 7-point RANSAC over the batch's matches; every pair samples from OpenCV's per-call RNG state (seed 0)."""
     from ..utils.mvg import find_fundamental
     B, f = pipe.B, len(items)
     H, W = pipe.H, pipe.W
-    seeds = list(indices) + [0] * (B - f) if indices is not None else None
-    _, _, info = find_fundamental(pipe.m0, pipe.m1, [W - 1, H - 1, W - 1, H - 1], k_dev=pipe.k, seeds=seeds)
+    _, _, info = find_fundamental(pipe.m0, pipe.m1, [W - 1, H - 1, W - 1, H - 1], k_dev=pipe.k)
     info = info.cpu().numpy()
     n, k = pipe.n.cpu().numpy(), pipe.k.cpu().numpy()
     rows = []

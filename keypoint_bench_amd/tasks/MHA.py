@@ -57,7 +57,7 @@ def mha(idx, img_0, score_map_0, desc_map_0, img_1, score_map_1, desc_map_1, war
     h, w = _hw(warp01)
     if m_pts0.shape[0] < 4:         # cv2.findHomography raises below 4 correspondences; no model -> no hit
         return zeros
-    H, _, info = find_homography(m_pts0[:, 0:2], m_pts1[:, 0:2], [w - 1, h - 1, w - 1, h - 1], seed=idx)   # 41-47: BOTH sides use warp01's size
+    H, _, info = find_homography(m_pts0[:, 0:2], m_pts1[:, 0:2], [w - 1, h - 1, w - 1, h - 1], seed=0)   # 41-47: BOTH sides use warp01's size; seed 0 = cv::RNG((uint64)-1), OpenCV's state at every call
     if int(info[0, 0]) == 0:                                                                    # 48-49
         return zeros
     hits, _ = corner_hits(H[0].cpu().numpy(), _real_h(warp01), h, w, img_0.shape[2], img_0.shape[3], th)
@@ -71,9 +71,8 @@ def mha_batch(pipe, items, params, indices=None):
     f, B = len(items), pipe.B
     hw = [_hw(it["warp01_params"]) for it in items]
     scale = torch.tensor([[w - 1, h - 1, w - 1, h - 1] for h, w in hw] + [[1, 1, 1, 1]] * (B - f), dtype=torch.float32)
-    seeds = list(indices if indices is not None else range(f)) + [0] * (B - f)
     m0, m1 = pipe.matched()
-    H, _, info = find_homography(m0, m1, scale, k_dev=pipe.k, seeds=seeds)
+    H, _, info = find_homography(m0, m1, scale, k_dev=pipe.k)         # seed 0 for every pair, as OpenCV restarts its RNG per call
     H, info = H.cpu().numpy(), info.cpu().numpy()
     raw = [_raw_hw(it["image0"]) for it in items]      # resize factors come from the uncropped image 0 (MHA.py:59-60)
 

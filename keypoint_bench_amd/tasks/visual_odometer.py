@@ -73,7 +73,7 @@ def relative_motion(step, last_img, batch, score_map_0, score_map_1, desc_map_0,
     sc = [score_map_0.shape[3] - 1, score_map_0.shape[2] - 1, last_img.shape[3] - 1, last_img.shape[2] - 1]      # 65-67
     K = _camera(_scalar(batch["fx"]), _scalar(batch["cx"]), _scalar(batch["cy"]))
     rt, _, _, info = estimate_pose(kps0[None, :, 0:2], kps1[None, :, 0:2], sc, K, K, thresh=THRESHOLD, conf=PROB,
-                                   seed=step if seed is None else seed, recover_all=True, dist=DISTANCE)
+                                   seed=0 if seed is None else seed, recover_all=True, dist=DISTANCE)
     return _rt(rt[0].cpu().numpy(), int(info[0, 0]))
 
 
@@ -104,9 +104,8 @@ def relative_motion_batch(pipe, items, indices=None):
     F = pipe.m0.shape[0]
     pad = lambda xs: xs + [xs[-1]] * (F - f)
     K = np.stack(pad([_camera(_scalar(it["fx"]), _scalar(it["cx"]), _scalar(it["cy"])) for it in items]))
-    seeds = list(indices if indices is not None else range(f)) + [0] * (F - f)
     rt, _, _, info = estimate_pose(pipe.m0, pipe.m1, [pipe.W - 1, pipe.H - 1, pipe.W - 1, pipe.H - 1], K, K, thresh=THRESHOLD, conf=PROB,
-                                   k_dev=pipe.k, seeds=seeds, recover_all=True, dist=DISTANCE)
+                                   k_dev=pipe.k, recover_all=True, dist=DISTANCE)
     rt, info, kk = rt.cpu().numpy(), info.cpu().numpy(), pipe.k.cpu().numpy()
     rows = []
     for j in range(f):

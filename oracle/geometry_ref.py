@@ -1,22 +1,30 @@
 """CPU restatement of the robust-geometry stage -- TEST INFRASTRUCTURE ONLY.
 
 PARITY UNPINNED.  The reference calls OpenCV (`cv2.findHomography(pts0, pts1, cv2.RANSAC)` tasks/MHA.py:45-47,
-`cv2.findEssentialMat` + `cv2.recoverPose` tasks/AUC.py:50-64); OpenCV is a third-party dependency (requirements.txt,
-unpinned), absent from the reference tree and from this image, and its RANSAC draws from its own RNG, so not even a
-present cv2 could be matched bit for bit.  What is restated here is OpenCV's published algorithm for these calls with
-their default parameters:
+`cv2.findEssentialMat` + `cv2.recoverPose` tasks/AUC.py:50-64, `cv2.findFundamentalMat(.., FM_RANSAC)` utils/mvg.py:16); OpenCV is
+a third-party dependency (requirements.txt:2 opencv-python~=4.9.0.80), absent from the reference tree and from this image, so
+nothing here could be run against it.  What is restated is OpenCV 4.9's published algorithm for these calls with their default
+parameters:
 
-  findHomography(RANSAC): ransacReprojThreshold 3, maxIters 2000, confidence 0.995; 4-point samples (degenerate =
-  three collinear points, or a sample whose orientation flips); model from the sample; inliers = forward reprojection
-  error^2 <= threshold^2; keep the model with strictly more inliers; iterations adapted with
-  log(1-confidence)/log(1-w^4); then a least-squares refit on the inliers (normalised DLT) and <= 10
+  the RANSAC driver (modules/calib3d/src/ptsetreg.cpp, RANSACPointSetRegistrator::run), r03 -- SAMPLER INCLUDED: cv::RNG
+  (multiply-with-carry, state (uint64)-1 at every call), getSubset (each index redrawn until it differs from the ones already
+  picked; the whole subset redrawn, up to 10 000 times, until checkSubset accepts it -- a rejected subset does not cost an
+  iteration), models of an iteration scored in order, `goodCount > max(maxGoodCount, modelPoints - 1)` keeps a model and
+  updates niters = RANSACUpdateNumIters(confidence, outlier ratio, modelPoints, niters), the loop ends at iter >= niters.
+  The hypothesis stream is therefore OpenCV's by construction; hypotheses are EVALUATED a round of 256 at a time (one per
+  thread of the device workgroup) and the keep / niters rule is then applied to them in iteration order, which gives what the
+  sequential loop gives (hypotheses past the stopping iteration are discarded unseen).
+
+  findHomography(RANSAC): ransacReprojThreshold 3, maxIters 2000, confidence 0.995; checkSubset = last point not collinear
+  with two earlier ones in either image, and the four triangle orientations agree between the images; model from the sample;
+  inliers = forward reprojection error^2 <= threshold^2; then a least-squares refit on the inliers (normalised DLT) and <= 10
   Levenberg-Marquardt steps on the reprojection error; H / H[2,2].
 
-and it is validated against ANALYTIC ground truth (tests/test_oracle_geometry.py), not against cv2.  The HIP kernels
-(csrc/geometry.hip) follow the same steps with the same counter-based sample generator (`sample_index`) so that the two
-can be compared hypothesis for hypothesis; the sampler is this build's own (OpenCV's RNG is not reproduced).
-The exact 4-point model is the projective-basis closed form (two adjugates) rather than an 8x8 solve: same model up to
-rounding.
+It is validated against ANALYTIC ground truth (tests/test_oracle_geometry.py), not against cv2.  The HIP kernels
+(csrc/geometry.hip) follow the same steps with the same generator so that the two can be compared hypothesis for hypothesis.
+Still restated rather than copied from OpenCV's arithmetic: the exact 4-point model is the projective-basis closed form (two
+adjugates) rather than OpenCV's 9 x 9 eigen-decomposition, and the errors are evaluated in float64 where OpenCV's callbacks
+use float32 -- same models and inlier sets up to rounding at the threshold.
 """
 import numpy as np
 
@@ -27,39 +35,119 @@ H_THRESHOLD = 3.0
 LM_ITERS = 10
 
 
-def lowbias32(h):
-    h = np.asarray(h, np.uint64) & 0xFFFFFFFF
-    h ^= h >> 16
-    h = (h * 0x7FEB352D) & 0xFFFFFFFF
-    h ^= h >> 15
-    h = (h * 0x846CA68B) & 0xFFFFFFFF
-    h ^= h >> 16
-    return h
+CV_RNG_COEFF = 4164903690
+GETSUBSET_ATTEMPTS = 10000     # RANSACPointSetRegistrator::run calls getSubset(.., rng, 10000)
 
 
-def sample_index(seed, it, draw, n):
-    """Index in [0, n) of draw number `draw` of hypothesis `it` (vectorised over `it`)."""
-    it = np.asarray(it, np.uint64)
-    h = (np.uint64(seed) ^ ((it * 0x9E3779B1) & 0xFFFFFFFF) ^ ((np.uint64(draw) * 0x85EBCA77) & 0xFFFFFFFF)) & 0xFFFFFFFF
-    return ((lowbias32(h) * np.uint64(n)) >> 32).astype(np.int64)
+class CvRNG:
+    """cv::RNG (modules/core/include/opencv2/core/operations.hpp): multiply-with-carry on a 64-bit state."""
+
+    def __init__(self, state=0xFFFFFFFFFFFFFFFF):
+        self.state = state if state else 0xFFFFFFFF
+
+    def next(self):
+        self.state = ((self.state & 0xFFFFFFFF) * CV_RNG_COEFF + (self.state >> 32)) & 0xFFFFFFFFFFFFFFFF
+        return self.state & 0xFFFFFFFF
+
+    def uniform(self, a, b):
+        return a if a == b else int(self.next() % (b - a) + a)
 
 
-def draw_samples(seed, its, n, m):
-    """m distinct indices per hypothesis: successive draws, a draw equal to an earlier pick of the same hypothesis is
-    skipped; a hypothesis that has not found m distinct indices after 4 m draws is void (ok = False)."""
-    its = np.asarray(its, np.int64)
-    idx = np.zeros((len(its), m), np.int64)
-    have = np.zeros(len(its), np.int64)
-    for d in range(4 * m):
-        c = sample_index(seed, its, d, n)
-        need = have < m
-        dup = np.zeros(len(its), bool)
-        for j in range(m):
-            dup |= (j < have) & (idx[:, j] == c)
-        take = need & ~dup
-        idx[take, have[take]] = c[take]
-        have[take] += 1
-    return idx, have == m
+def rng_state(seed):
+    """seed 0: the state OpenCV's RANSAC starts EVERY call with, `RNG rng((uint64)-1)`.  Any other seed gives another non-zero
+    64-bit state (tests that want different hypothesis streams; the device kernel maps seeds the same way)."""
+    s = int(seed) & 0xFFFFFFFF
+    return 0xFFFFFFFFFFFFFFFF if s == 0 else (((s ^ 0x9E3779B9) << 32) | s)
+
+
+def have_collinear_last(p):
+    """OpenCV's haveCollinearPoints(m, count): the LAST of the count points lies on a line through two earlier ones (or too
+    close to one).  p [count, 2] float32-valued coordinates, arithmetic in float64 with FLT_EPSILON, as in OpenCV."""
+    p = np.asarray(p, np.float64)
+    i = len(p) - 1
+    for j in range(i):
+        dx1, dy1 = p[j, 0] - p[i, 0], p[j, 1] - p[i, 1]
+        for k in range(j):
+            dx2, dy2 = p[k, 0] - p[i, 0], p[k, 1] - p[i, 1]
+            if abs(dx2 * dy1 - dy2 * dx1) <= 1.1920928955078125e-07 * (abs(dx1) + abs(dy1) + abs(dx2) + abs(dy2)):
+                return True
+    return False
+
+
+def check_subset_homography(s, d):
+    """HomographyEstimatorCallback::checkSubset for the 4-point sample: no collinear last point in either image, and the
+    signed areas of the four triangles (0 1 2), (1 2 3), (0 2 3), (0 1 3) change sign in all of them or in none."""
+    if have_collinear_last(s) or have_collinear_last(d):
+        return False
+    s, d = np.asarray(s, np.float64), np.asarray(d, np.float64)
+    negative = 0
+    for t in ((0, 1, 2), (1, 2, 3), (0, 2, 3), (0, 1, 3)):
+        A = np.array([[s[t[0], 0], s[t[0], 1], 1.0], [s[t[1], 0], s[t[1], 1], 1.0], [s[t[2], 0], s[t[2], 1], 1.0]])
+        B = np.array([[d[t[0], 0], d[t[0], 1], 1.0], [d[t[1], 0], d[t[1], 1], 1.0], [d[t[2], 0], d[t[2], 1], 1.0]])
+        negative += _det3x3(A) * _det3x3(B) < 0
+    return negative == 0 or negative == 4
+
+
+def _det3x3(m):
+    """cv::determinant(Matx33d): cofactor expansion along the first row."""
+    return (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+            + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+
+
+def check_subset_fundamental(s, d):
+    """FMEstimatorCallback::checkSubset."""
+    return not have_collinear_last(s) and not have_collinear_last(d)
+
+
+def get_subset(rng, n, m, check, p0, p1, max_attempts=GETSUBSET_ATTEMPTS):
+    """RANSACPointSetRegistrator::getSubset: m distinct indices in [0, n), redrawn as a whole until `check` accepts them."""
+    for _ in range(max_attempts):
+        idx = []
+        for i in range(m):
+            c = rng.uniform(0, n)
+            while c in idx:
+                c = rng.uniform(0, n)
+            idx.append(c)
+        if check is None or check(p0[idx], p1[idx]):
+            return idx
+    return None
+
+
+def subsets_for_round(rng, n, m, check, p0, p1, count):
+    """The next `count` subsets of the stream.  Returns (idx [count, m], ok [count]); ok turns False at a getSubset failure and
+    stays False (the sequential loop ends there)."""
+    idx = np.zeros((count, m), np.int64)
+    ok = np.zeros(count, bool)
+    for j in range(count):
+        sub = get_subset(rng, n, m, check, p0, p1)
+        if sub is None:
+            break
+        idx[j], ok[j] = sub, True
+    return idx, ok
+
+
+def ransac_scan(cnt, valid, sub_ok, base, state, n, m, conf):
+    """The keep / niters rule of RANSACPointSetRegistrator::run applied, in iteration order, to one round of evaluated hypotheses.
+    cnt / valid [R, NM]: inlier count and validity of every model of every hypothesis; state = dict(niters, max_good, best, iters,
+    stop, failed).  `best` becomes (row of this round, model slot) when a model of this round is kept."""
+    R, NM = cnt.shape
+    best = None
+    for j in range(R):
+        it = base + j
+        if it >= state["niters"]:
+            state["stop"] = True
+            break
+        if not sub_ok[j]:                       # getSubset gave up: `if (iter == 0) return false; break;`
+            state["failed"] = it == 0
+            state["stop"] = True
+            break
+        for s_ in range(NM):
+            if valid[j, s_] and cnt[j, s_] > max(state["max_good"], m - 1):
+                best = (j, s_)
+                state["max_good"] = int(cnt[j, s_])
+                state["niters"] = update_iters(conf, (n - state["max_good"]) / n, m, state["niters"])
+        state["iters"] = it + 1
+    return best
 
 
 def _adj(a):
@@ -223,21 +311,19 @@ def find_homography_ransac(src, dst, seed=0, threshold=H_THRESHOLD, max_iters=H_
         mask[:] = 1
         return H[0], mask, dict(iters=0, inliers=4)
     t2 = threshold * threshold
-    best_cnt, best_H, niters, done = 0, None, max_iters, 0
-    while done < niters:
-        its = np.arange(done, done + ROUND)
-        idx, ok = draw_samples(seed, its, n, 4)
+    rng = CvRNG(rng_state(seed))
+    st = dict(niters=max(max_iters, 1), max_good=0, iters=0, stop=False, failed=False)
+    best_H, base = None, 0
+    while base < st["niters"] and not st["stop"]:
+        idx, sub_ok = subsets_for_round(rng, n, 4, check_subset_homography, src, dst, ROUND)
         H, good = homography_4pt(src[idx], dst[idx])
-        ok &= good & (its < max_iters)
         cnt = (reproj_err2(H, src, dst) <= t2).sum(1)
-        cnt = np.where(ok, cnt, 0)
-        j = int(np.argmax(cnt))                           # first maximum = lowest iteration number
-        if cnt[j] > max(best_cnt, 3):
-            best_cnt, best_H = int(cnt[j]), H[j]
-        done += ROUND
-        niters = update_iters(confidence, (n - best_cnt) / n, 4, max_iters) if best_cnt else max_iters
+        b = ransac_scan(cnt[:, None], (good & sub_ok)[:, None], sub_ok, base, st, n, 4, confidence)
+        if b is not None:
+            best_H = H[b[0]]
+        base += ROUND
     if best_H is None:
-        return None, mask, dict(iters=done, inliers=0)
+        return None, mask, dict(iters=st["iters"], inliers=0)
     inl = reproj_err2(best_H[None], src, dst)[0] <= t2
     mask[inl] = 1
     H = best_H
@@ -248,7 +334,7 @@ def find_homography_ransac(src, dst, seed=0, threshold=H_THRESHOLD, max_iters=H_
             eb = reproj_err2(best_H[None], src[inl], dst[inl]).sum()
             H = H0 if e0 < eb else best_H
         H = lm_refine(H, src[inl], dst[inl])
-    return H / H[2, 2], mask, dict(iters=done, inliers=int(best_cnt))
+    return H / H[2, 2], mask, dict(iters=st["iters"], inliers=int(st["max_good"]))
 
 
 # --------------------------------------------------------------------------------------------- task halves (pinnable)
@@ -465,31 +551,33 @@ def sampson_err(E, x1, x2):
 
 def find_essential_ransac(x1, x2, seed=0, threshold=1.0, prob=0.99999, max_iters=E_MAX_ITERS):
     """cv2.findEssentialMat(x1, x2, eye(3), threshold, prob, RANSAC) restated.  x1, x2 [N, 2] normalised coordinates.
-    Returns (E [3,3] or None, mask [N] uint8, info)."""
+    Returns (E [3,3] or None, mask [N] uint8, info).  EMEstimatorCallback has no checkSubset: every 5 distinct points are a sample."""
     x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
     n = len(x1)
     mask = np.zeros(n, np.uint8)
     if n < 5:
         return None, mask, dict(iters=0, inliers=0)
     t2 = threshold * threshold
-    best_cnt, best_E, niters, done = 0, None, max_iters, 0
-    while done < niters:
-        its = np.arange(done, done + ROUND)
-        idx, ok = draw_samples(seed, its, n, 5)
+    rng = CvRNG(rng_state(seed))
+    st = dict(niters=max(max_iters, 1), max_good=0, iters=0, stop=False, failed=False)
+    best_E, base = None, 0
+    while base < st["niters"] and not st["stop"]:
+        if n == 5:                  # `count == modelPoints`: the one sample, no loop
+            idx, sub_ok = np.arange(5)[None].repeat(ROUND, 0), np.zeros(ROUND, bool)
+            sub_ok[0] = True
+            st["niters"] = 1
+        else:
+            idx, sub_ok = subsets_for_round(rng, n, 5, None, x1, x2, ROUND)
         E, valid = essential_5pt(x1[idx], x2[idx])
-        valid &= (ok & (its < max_iters))[:, None]
-        cnt = (sampson_err(E, x1, x2) <= t2).sum(-1)
-        cnt = np.where(valid, cnt, 0)                                   # [ROUND, 10]
-        flat = cnt.reshape(-1)
-        j = int(np.argmax(flat))                                       # first maximum: lowest iteration, then lowest root slot
-        if flat[j] > max(best_cnt, 4):
-            best_cnt, best_E = int(flat[j]), E[j // 10, j % 10]
-        done += ROUND
-        niters = update_iters(prob, (n - best_cnt) / n, 5, max_iters) if best_cnt else max_iters
+        cnt = (sampson_err(E, x1, x2) <= t2).sum(-1)                    # [ROUND, 10]
+        b = ransac_scan(cnt, valid & sub_ok[:, None], sub_ok, base, st, n, 5, prob)
+        if b is not None:
+            best_E = E[b[0], b[1]]
+        base += ROUND
     if best_E is None:
-        return None, mask, dict(iters=done, inliers=0)
+        return None, mask, dict(iters=st["iters"], inliers=0)
     mask[sampson_err(best_E, x1, x2) <= t2] = 1
-    return best_E, mask, dict(iters=done, inliers=int(best_cnt))
+    return best_E, mask, dict(iters=st["iters"], inliers=int(st["max_good"]))
 
 
 def decompose_essential(E):
@@ -674,26 +762,22 @@ def find_fundamental_ransac(x1, x2, seed=0, threshold=F_THRESHOLD, confidence=F_
     if n < 8:
         return None, mask, dict(iters=0, inliers=0)
     t2 = np.float32(threshold * threshold)
-    best_cnt, best_F, niters, done = 0, None, max_iters, 0
-    while done < niters:
-        its = np.arange(done, done + ROUND)
-        idx, ok = draw_samples(seed, its, n, 7)
-        ok &= ~have_collinear(x1[idx]) & ~have_collinear(x2[idx]) & (its < max_iters)
+    rng = CvRNG(rng_state(seed))
+    st = dict(niters=max(max_iters, 1), max_good=0, iters=0, stop=False, failed=False)
+    best_F, base = None, 0
+    while base < st["niters"] and not st["stop"]:
+        idx, sub_ok = subsets_for_round(rng, n, 7, check_subset_fundamental, x1, x2, ROUND)
         F, valid = fundamental_7pt(x1[idx], x2[idx])
-        valid &= ok[:, None]
         with np.errstate(invalid="ignore"):
-            cnt = (fm_error(F, x1, x2) <= t2).sum(-1)
-        cnt = np.where(valid, cnt, 0)                                   # [ROUND, 3]
-        flat = cnt.reshape(-1)
-        j = int(np.argmax(flat))                                        # lowest iteration, then lowest root slot
-        if flat[j] > max(best_cnt, 6):
-            best_cnt, best_F = int(flat[j]), F[j // 3, j % 3]
-        done += ROUND
-        niters = update_iters(confidence, (n - best_cnt) / n, 7, max_iters) if best_cnt else max_iters
+            cnt = (fm_error(F, x1, x2) <= t2).sum(-1)                   # [ROUND, 3]
+        b = ransac_scan(cnt, valid & sub_ok[:, None], sub_ok, base, st, n, 7, confidence)
+        if b is not None:
+            best_F = F[b[0], b[1]]
+        base += ROUND
     if best_F is None:
-        return None, mask, dict(iters=done, inliers=0)
+        return None, mask, dict(iters=st["iters"], inliers=0)
     mask[fm_error(best_F, x1, x2) <= t2] = 1
-    return best_F, mask, dict(iters=done, inliers=int(best_cnt))
+    return best_F, mask, dict(iters=st["iters"], inliers=int(st["max_good"]))
 
 
 def fundamental_estimate(pts0, pts1, seed=0):

@@ -110,7 +110,7 @@ def main():
                   "matcher_params": {"brute_force_params": dict(metric="euclidean", max_distance=1.0, cross_check=True)},
                   "AUC_params": {"output": "/tmp", "th": [5, 10, 20]}}
         captured.clear()
-        captured["seed"] = c
+        captured["seed"] = 0      # cv::RNG((uint64)-1): OpenCV's state at every call
         tt = torch.from_numpy
         img = torch.zeros((1, 3, H, W))
         res = ref_auc.auc(c, img, tt(s0)[None, None], tt(d0), img, tt(s1)[None, None], tt(d1), w01, {}, params)

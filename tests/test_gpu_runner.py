@@ -149,7 +149,7 @@ def test_visual_odometer_rows_batched_equal_single_and_chunks_reproduce_them():
     px = np.array([127, 95], np.float32)
     c, f = np.array([63.5, 47.5]), 120.0
     x0, x1 = ((m0[:, :2] * px).astype(np.float64) - c) / f, ((m1[:, :2] * px).astype(np.float64) - c) / f
-    E, mask, info = g.find_essential_ransac(x0, x1, seed=3, threshold=1.0 / f, prob=0.999)
+    E, mask, info = g.find_essential_ransac(x0, x1, seed=0, threshold=1.0 / f, prob=0.999)
     n, R, tt, _ = g.recover_pose(E, x0, x1, np.ones(len(x0), np.uint8), dist=50.0)
     np.testing.assert_allclose(rows1[3, :9].reshape(3, 3), R, atol=2e-5)
     np.testing.assert_allclose(rows1[3, 9:12], tt, atol=2e-5)

@@ -34,7 +34,7 @@ def test_ransac_homography_recovers_ground_truth(n, share, noise, tol):
 def test_ransac_degenerate_inputs():
     src = np.stack([np.arange(40.0), 2 * np.arange(40.0) + 1], 1)          # all collinear: every sample is degenerate
     H, mask, info = g.find_homography_ransac(src, src + 5, seed=0)
-    assert H is None and mask.sum() == 0 and info["iters"] >= g.H_MAX_ITERS
+    assert H is None and mask.sum() == 0 and info["iters"] == 0       # getSubset gives up in iteration 0: OpenCV returns false
     H, mask, _ = g.find_homography_ransac(src[:3], src[:3], seed=0)
     assert H is None
     # pure outliers: a "model" may be found but it explains (almost) nothing
@@ -43,14 +43,50 @@ def test_ransac_degenerate_inputs():
     assert info["inliers"] < 12
 
 
-def test_sampler_is_a_pure_function_of_seed_iteration_draw():
-    a = g.sample_index(7, np.arange(1000), 2, 333)
-    assert np.array_equal(a, g.sample_index(7, np.arange(1000), 2, 333)) and a.min() >= 0 and a.max() < 333
-    assert abs(a.mean() - 166) < 12
-    idx, ok = g.draw_samples(7, np.arange(4096), 50, 4)
-    assert ok.all() and all(len(set(r)) == 4 for r in idx.tolist())
-    idx, ok = g.draw_samples(7, np.arange(64), 4, 4)                        # n == m: many duplicate draws
-    assert ((idx[ok].sum(1) == 6) & (np.sort(idx[ok], 1) == np.arange(4)).all(1)).all()
+def test_cv_rng_and_get_subset_follow_opencvs_published_definitions():
+    """cv::RNG: state = (unsigned)state * 4164903690 + (state >> 32), the low word is the draw; uniform(a, b) = next() % (b - a) + a.
+    RANSAC seeds it with (uint64)-1 at every call.  getSubset: distinct indices, a duplicate draw is repeated at once; a subset that
+    checkSubset rejects is redrawn whole.  (Restated from OpenCV 4.9's sources; no cv2 here to compare with: parity unpinned.)"""
+    r = g.CvRNG(g.rng_state(0))
+    assert r.state == 0xFFFFFFFFFFFFFFFF
+    st = r.state
+    draws = []
+    for _ in range(5):
+        st = ((st & 0xFFFFFFFF) * 4164903690 + (st >> 32)) & 0xFFFFFFFFFFFFFFFF
+        draws.append(st & 0xFFFFFFFF)
+    r2 = g.CvRNG(g.rng_state(0))
+    assert [r2.next() for _ in range(5)] == draws
+    assert draws[0] == (0xFFFFFFFF * 4164903690 + 0xFFFFFFFF) & 0xFFFFFFFF      # first draw from the all-ones state
+    r3 = g.CvRNG(g.rng_state(0))
+    u = [r3.uniform(0, 333) for _ in range(4000)]
+    assert min(u) == 0 and max(u) == 332 and abs(np.mean(u) - 166) < 8
+    assert g.CvRNG(0).state == 0xFFFFFFFF                                        # RNG(0) -> 0xffffffff, as OpenCV's constructor
+    assert g.rng_state(5) != g.rng_state(6) and g.rng_state(5) != 0
+    # getSubset: distinct indices; with n == m every subset is a permutation of 0..m-1
+    rng = g.CvRNG(g.rng_state(0))
+    pts = np.random.default_rng(0).random((50, 2)) * 100
+    for _ in range(200):
+        sub = g.get_subset(rng, 50, 4, None, pts, pts)
+        assert len(set(sub)) == 4 and min(sub) >= 0 and max(sub) < 50
+    for _ in range(50):
+        assert sorted(g.get_subset(rng, 4, 4, None, pts, pts)) == [0, 1, 2, 3]
+    # a rejecting checkSubset costs draws, not iterations: the stream of ACCEPTED subsets skips the rejected ones
+    a, b = g.CvRNG(g.rng_state(3)), g.CvRNG(g.rng_state(3))
+    acc = [g.get_subset(a, 50, 4, lambda s, d: int(round(s[0, 0] * 1000)) % 2 == 0, pts, pts) for _ in range(20)]
+    alls = []
+    while len([x for x in alls if int(round(pts[x[0], 0] * 1000)) % 2 == 0]) < 20:
+        alls.append(g.get_subset(b, 50, 4, None, pts, pts))
+    assert acc == [x for x in alls if int(round(pts[x[0], 0] * 1000)) % 2 == 0]
+
+
+def test_have_collinear_tests_only_the_last_point():
+    p = np.array([[0, 0], [1, 1], [2, 2], [5, 1]], np.float64)          # the first three are collinear, the last is not on their line
+    assert not g.have_collinear_last(p)
+    assert g.have_collinear_last(p[[0, 3, 1, 2]])                        # now the last one closes a collinear triple
+    assert g.have_collinear_last(np.array([[0, 0], [3, 1], [0, 0]], np.float64))       # a repeated point counts as collinear
+    sq = np.array([[0, 0], [10, 0], [10, 10], [0, 10]], np.float64)
+    assert g.check_subset_homography(sq, sq * 2 + 1)
+    assert not g.check_subset_homography(sq, sq[[0, 1, 3, 2]])           # a bow-tie: orientation of some triangles flips
 
 
 def mha_params(prm, th):
@@ -75,7 +111,7 @@ def test_mha_chain_around_the_estimator_against_reference(case):
                                         prm["matcher_params"]["brute_force_params"])
     px = np.array([w - 1, h - 1], np.float32)
     assert np.array_equal(m0[:, :2] * px, f[p + "p0"]) and np.array_equal(m1[:, :2] * px, f[p + "p1"])      # MHA.py:40-44 bit for bit
-    H, _, _ = g.find_homography_ransac(f[p + "p0"], f[p + "p1"], seed=case)
+    H, _, _ = g.find_homography_ransac(f[p + "p0"], f[p + "p1"], seed=0)
     np.testing.assert_allclose(H, f[p + "H"], rtol=0, atol=1e-12)
     Hs, Ws = f[p + "score0"].shape
     d = g.mha_corner_error(H, real_H, np.asarray(h), np.asarray(w), Hs, Ws)
@@ -139,7 +175,7 @@ def test_aberth_roots_equal_numpy_roots():
 @pytest.mark.parametrize("n,share,noise,tol_t,tol_R", [(800, 0.7, 0.5, 4.0, 1.5), (300, 0.5, 0.5, 5.0, 2.0), (1000, 0.9, 0.0, 3.0, 1.0), (6, 1.0, 0.0, 1e-3, 1e-3)])
 def test_essential_ransac_and_recover_pose_on_ground_truth(n, share, noise, tol_t, tol_R):
     x1, x2, R, t, inl = scene(n, share, noise, n)
-    E, mask, info = g.find_essential_ransac(x1, x2, seed=5, threshold=1.0 / 500)
+    E, mask, info = g.find_essential_ransac(x1, x2, seed=0, threshold=1.0 / 500)      # seed 0: the state OpenCV starts every call with
     assert E is not None and abs(np.linalg.norm(E) - 1) < 1e-12
     nn, Rr, tt, mnew = g.recover_pose(E, x1, x2, mask)
     T = np.eye(4)
@@ -188,7 +224,7 @@ def test_auc_chain_around_the_estimator_against_reference(case):
     n1 = (px1 - K[[0, 1], [2, 2]][None]) / K[[0, 1], [0, 1]][None]
     assert np.array_equal(n0, f[p + "k0"]) and np.array_equal(n1, f[p + "k1"])
     assert f[p + "thr"] == 1.0 / np.mean([K[0, 0], K[1, 1], K[0, 0], K[1, 1]])
-    res = g.estimate_pose(px0, px1, K, K, 1.0, seed=case)
+    res = g.estimate_pose(px0, px1, K, K, 1.0, seed=0)
     R, t, inl = res
     np.testing.assert_allclose(R, f[p + "R"], atol=1e-12)
     np.testing.assert_allclose(t, f[p + "t"], atol=1e-12)
@@ -258,7 +294,7 @@ def test_ransac_fundamental_small_and_degenerate_inputs():
     assert F is None and mask.sum() == 0 and info["iters"] == 0
     line = np.stack([np.arange(30.0) * 7, np.arange(30.0) * 3 + 5], 1)  # collinear in both images: every sample is void
     F, mask, info = g.find_fundamental_ransac(line, line + 2, seed=0)
-    assert F is None and info["iters"] >= g.F_MAX_ITERS
+    assert F is None and info["iters"] == 0          # getSubset gives up in iteration 0: OpenCV returns false
     a, b, c = g.fundamental_estimate(p1, p2)
     assert a is None and len(b) == 7 and len(c) == 7
     with pytest.raises(AttributeError):
