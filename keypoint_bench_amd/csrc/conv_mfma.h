@@ -243,8 +243,16 @@ __device__ __forceinline__ float cm_wave_max(float v)
 // slab (or the next tile's first slab) into registers before the taps of the current one ran 2 % faster on conv1b at two
 // waves per SIMD and 20 % slower on DISK's up_3 (the 44 registers of the slab in flight cost the third wave).)
 // PF: with POOL_IN the input is max-pooled PF x PF (2 or 4) while it is staged (ALike.py:139-143).
+// waves per SIMD the register allocation is held to: what r02's code reached without being told (accumulators 16 MT NTB) --
+// left alone, the allocator keeps a second copy of the accumulators in VGPRs for the rare rescale below (+64 registers, a wave
+// per SIMD lost on every two-tile layer)
+constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
+{
+    return MT * NTB >= 4 ? ((KS == 5 && CC == 32) || POOL_IN ? 2 : 3) : (MT * NTB == 2 ? (KS == 3 && CC == 16 ? 3 : 4) : 5);
+}
+
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2>
-__global__ __launch_bounds__(256) void conv_mfma_h(ConvM a)
+__global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
