@@ -20,6 +20,9 @@ struct ConvV {
     const float* in; float* out; const float* w; const float* bias;
     const float* xf;    // optional [B][CIN][4] input transform (see ConvM)
     int Hi, Wi, H, W, CIN, COUT, COUT8, KS, S, PAD, relu;
+    // conv_valu_t only, optional: XFeat's skip connection (XFeat.py:27-28, 127) added in the epilogue of the layer it joins --
+    // out[c] += skw[c] * avg_pool4(gray)(pixel) + skb[c] for c < skn; gray is [B][4 H][4 W]
+    const float* gray = nullptr; const float* skw = nullptr; const float* skb = nullptr; int skn = 0;
 };
 
 __global__ __launch_bounds__(256) void conv_valu(ConvV a)
@@ -102,15 +105,32 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
         }
     }
     float* o = a.out + ((size_t)b * a.H * a.W + pix) * a.COUT + cg * CPT;
+    if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = relu(acc[j]);
+    }
+    if (a.gray) {       // the skip connection: AvgPool2d(4) of the normalised grey image -> Conv2d(1, skn, 1), added AFTER the ReLU
+        const int Wg = 4 * a.W;
+        const float* g = a.gray + (size_t)b * (4 * a.H) * Wg + (size_t)(4 * oy) * Wg + 4 * ox;       // W is a multiple of 32: rows are 16-byte aligned
+        float sacc = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) {
+            const float4 r = *reinterpret_cast<const float4*>(g + (size_t)dy * Wg);
+            sacc += r.x; sacc += r.y; sacc += r.z; sacc += r.w;                        // the order avg_pool2d's sum is restated in
+        }
+        const float avg = sacc * (1.0f / 16.0f);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if (cg * CPT + j < a.skn) acc[j] += fmaf(avg, a.skw[cg * CPT + j], a.skb[cg * CPT + j]);
+    }
     if (a.COUT % 4 == 0 && cg * CPT + CPT <= a.COUT) {
 #pragma unroll
         for (int q = 0; q < CPT / 4; ++q)
-            *reinterpret_cast<float4*>(o + 4 * q) = a.relu ? make_float4(relu(acc[4 * q]), relu(acc[4 * q + 1]), relu(acc[4 * q + 2]), relu(acc[4 * q + 3]))
-                                                           : make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+            *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     } else {
 #pragma unroll
         for (int j = 0; j < CPT; ++j)
-            if (cg * CPT + j < a.COUT) o[j] = a.relu ? relu(acc[j]) : acc[j];
+            if (cg * CPT + j < a.COUT) o[j] = acc[j];
     }
 }
 
@@ -232,31 +252,6 @@ __global__ void instnorm_apply(float* gray, const double* stats, size_t P)
     gray[b * P + i] = (gray[b * P + i] - (float)mean) * (1.0f / sqrtf((float)var + 1e-5f));
 }
 
-// XFeat.py:27-28: skip1 = AvgPool2d(4) -> Conv2d(1, 24, 1); added to block1's output (XFeat.py:127): out += w*avg + b
-__global__ void skip_add(const float* gray, float* x1, const float* w, const float* bias, int H, int W, int cstride)
-{
-    const int H4 = H / 4, W4 = W / 4;
-    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (i >= H4 * W4) return;
-    const int y = i / W4, x = i - y * W4;
-    const float* g = gray + (size_t)b * H * W + (size_t)(4 * y) * W + 4 * x;      // W is a multiple of 32: rows are 16-byte aligned
-    float sacc = 0.0f;
-#pragma unroll
-    for (int dy = 0; dy < 4; ++dy) {
-        const float4 r = *reinterpret_cast<const float4*>(g + (size_t)dy * W);
-        sacc += r.x; sacc += r.y; sacc += r.z; sacc += r.w;                        // the order avg_pool2d's sum is restated in
-    }
-    const float avg = sacc * (1.0f / 16.0f);
-    float* o = x1 + ((size_t)b * H4 * W4 + i) * cstride;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        float4 v = *reinterpret_cast<float4*>(o + 4 * q);
-        v.x += fmaf(avg, w[4 * q], bias[4 * q]); v.y += fmaf(avg, w[4 * q + 1], bias[4 * q + 1]);
-        v.z += fmaf(avg, w[4 * q + 2], bias[4 * q + 2]); v.w += fmaf(avg, w[4 * q + 3], bias[4 * q + 3]);
-        *reinterpret_cast<float4*>(o + 4 * q) = v;
-    }
-}
-
 // XFeat.py:133-135: x3 + interpolate(x4, size(x3), bilinear) + interpolate(x5, ...) (align_corners=False), 64 channels
 __device__ __forceinline__ float4 bilerp4(const float* m, int Hs, int Ws, int Hd, int Wd, int y, int x, int c4)
 {
@@ -368,9 +363,10 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
 }
 
 int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool relu_, const float* xf = nullptr)
+                bool relu_, const float* xf = nullptr, const float* gray = nullptr, const float* skw = nullptr, const float* skb = nullptr, int skn = 0)
 {
     ConvV a;
+    a.gray = gray; a.skw = skw; a.skb = skb; a.skn = skn;
     a.in = in; a.out = out; a.w = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf;
     a.Hi = Hi; a.Wi = Wi; a.KS = L.ks; a.S = L.stride; a.PAD = L.ks / 2;
     a.H = (Hi + 2 * a.PAD - L.ks) / L.stride + 1; a.W = (Wi + 2 * a.PAD - L.ks) / L.stride + 1;
@@ -384,7 +380,10 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     else if (t3 && L.cin == 8 && L.stride == 2 && a.COUT8 == 32)
         KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2, 32>), dim3(grid.x, 1, grid.z), block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2>), grid, block, 0, st, a);
-    else KPB_LAUNCH(ctx, name, conv_valu, grid, block, 0, st, a);
+    else {
+        if (gray) return kpb_fail(ctx, KPB_E_INVALID, "conv_valu: the fused skip connection needs a templated instance");
+        KPB_LAUNCH(ctx, name, conv_valu, grid, block, 0, st, a);
+    }
     return KPB_OK;
 }
 
@@ -546,8 +545,14 @@ struct XFeatNet : kpb_net {
         if ((rc = conv("block1.0", gray, a1, batch, H, W))) return rc;
         if ((rc = conv("block1.1", a1, b1, batch, H, W))) return rc;
         if ((rc = conv("block1.2", b1, c1, batch, H2, W2))) return rc;
-        if ((rc = conv("block1.3", c1, x1, batch, H2, W2))) return rc;
-        KPB_LAUNCH(ctx, "xf_skip_add", skip_add, dim3(cdiv(H4 * W4, 256), batch), dim3(256), 0, st, gray, x1, wp("skip1.w"), wp("skip1.b"), H, W, 32);
+        // block1's last layer with the skip connection (AvgPool2d(4) -> Conv2d(1, 24, 1), XFeat.py:27-28, 127) added in its epilogue:
+        // as a kernel of its own (r02: xf_skip_add, 1.12 ms per 512 images) it read x1 back and wrote it again
+        {
+            const Layer& l = L.at("block1.3");
+            if (l.mfma || l.ks != 3 || l.cin != 8 || l.stride != 2 || ((l.cout + 7) / 8) * 8 != 32)
+                return kpb_fail(ctx, KPB_E_INVALID, "XFeat block1.3: unexpected layer plan");
+            if ((rc = launch_valu(ctx, "xf_block1.3", this, l, c1, x1, batch, H2, W2, relu_of.at("block1.3"), nullptr, gray, wp("skip1.w"), wp("skip1.b"), 24))) return rc;
+        }
         if ((rc = conv("block2.0", x1, t2, batch, H4, W4))) return rc;
         if ((rc = conv("block2.1", t2, x2, batch, H4, W4))) return rc;
         if ((rc = conv("block3.0", x2, u8[0], batch, H4, W4))) return rc;
