@@ -220,12 +220,17 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 {
     constexpr int LH = TH + 4 * R, LW = TW + 4 * R;
     constexpr int IW = LW - 2 * R, IH = LH - 2 * R;            // inset region: whole window inside the tile
-    constexpr int NHS = (IW + 7) / 8, NVS = (IH + 7) / 8;       // strips per row / per column
+    constexpr int NHS = (IW + 7) / 8;                           // 8-pixel strips per row
+    // vertical strips: as few per column as one pass of the workgroup can take (threads >= NVS * IW), so that the column pass is
+    // ONE trip of the thread loop (r = 6: three strips of 12 rows, 228 of 256 threads; five strips of 8 took two trips, the second
+    // half empty)
+    constexpr int NVS = (3 * IW <= NMS_THREADS) ? 3 : (4 * IW <= NMS_THREADS ? 4 : (IH + 7) / 8), VS = (IH + NVS - 1) / NVS;
+    static_assert(VS <= 16, "vertical strip too tall for the hit mask / register budget");
     constexpr int PITCH = ((8 * NHS + 2 * R) + 3) / 4 * 4;      // floats per LDS row of t (16-byte aligned rows)
     constexpr int EP = 8 * NHS;                                 // floats per row of e; e[y][x'] belongs to tile column x' + R
-    constexpr int ROWS = 8 * NVS + 2 * R;                       // rows incl. zero padding read by the last strip
+    constexpr int ROWS = (VS * NVS + 2 * R > LH) ? VS * NVS + 2 * R : LH;      // rows incl. zero padding read by the last strip
     constexpr int HIN = 8 + 2 * R, HQ = (HIN + 3) / 4;          // floats / float4s one horizontal strip reads
-    constexpr int KS = 2 * R + 1, KS2 = KS * KS;
+    constexpr int KS = 2 * R + 1;
     // the working map carries the state in the sign: > 0 alive, 0 dead, < 0 confirmed maximum (its value negated);
     // confirmed maxima are never re-derived, a tile only has to clear what they still cover
     __shared__ __attribute__((aligned(16))) float t[ROWS * PITCH];
@@ -298,12 +303,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     __syncthreads();
     if (neg && first) a.negflag[img] = 1;    // only the input map may not be negative; later sweeps use the sign themselves
 
-    float orig[TH * TW / NMS_THREADS];
+    // write-back ownership: thread o < TH * TW / 8 owns the eight pixels (oy, ox .. ox + 7) of the tile
+    static_assert(TH * TW / 8 <= NMS_THREADS && TW % 8 == 0, "write-back mapping");
+    const bool owner = tid < TH * TW / 8;
+    const int oy = tid / (TW / 8), ox = 8 * (tid - oy * (TW / 8));
+    float orig[8];
 #pragma unroll
-    for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
-        const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
-        orig[k] = t[(oy + 2 * R) * PITCH + ox + 2 * R];
-    }
+    for (int k = 0; k < 8; ++k) orig[k] = owner ? t[(oy + 2 * R) * PITCH + ox + 2 * R + k] : 0.0f;
 
     // appends the positions flagged by `hit` to maxlist with one LDS atomic per wave
     auto append = [&](bool hit, int pos, int par) {
@@ -321,13 +327,36 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     };
     // zeroes the window of every listed maximum; no two maxima lie within R of each other, so nothing but dead or
     // doomed pixels is overwritten and no read is needed (extracter.py:81-96)
+    // (one thread per window ROW: 2r+1 stores at constant offsets; a thread per window CELL spent twenty instructions of
+    // index arithmetic on every store and the kill was a seventh of the sweep)
     auto kill = [&](int nmax, bool mark_centre) {
-        for (int i = tid; i < nmax * KS2; i += NMS_THREADS) {
-            const int m = i / KS2, c = i - m * KS2;
-            const int dy = c / KS - R, dx = c - (dy + R) * KS - R;
-            const int pos = maxlist[m] + dy * PITCH + dx;
-            if (dy == 0 && dx == 0) { if (mark_centre) t[pos] = -t[pos]; }
-            else t[pos] = 0.0f;
+        for (int i = tid; i < nmax * KS; i += NMS_THREADS) {
+            const int m = i / KS, dy = i - m * KS - R;
+            const int c = maxlist[m];
+            float* row = t + c + dy * PITCH - R;
+            if (dy != 0) {
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) row[dx] = 0.0f;
+            } else {
+                const float centre = row[R];
+#pragma unroll
+                for (int dx = 0; dx < KS; ++dx) if (dx != R) row[dx] = 0.0f;
+                if (mark_centre) row[R] = -centre;
+            }
+        }
+    };
+    // appends the set bits of a lane's hit mask (positions base_pos + k * stride) to maxlist: one LDS atomic per lane that has
+    // any -- maxima and undecided pixels are sparse, a ballot per bit was most of the column pass
+    auto append_mask = [&](unsigned mask, int base_pos, int stride, int par) {
+        if (mask) {
+            int slot = atomicAdd(&s_n[par], __popc(mask));
+            while (mask) {
+                const int k = __ffs((int)mask) - 1;
+                mask &= mask - 1;
+                if (slot < MAXLIST) maxlist[slot] = base_pos + k * stride;
+                else s_over = 1;
+                ++slot;
+            }
         }
     };
 
@@ -364,28 +393,28 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
             *reinterpret_cast<float4*>(er + 4) = make_float4(o[4], o[5], o[6], o[7]);
         }
         __syncthreads();
-        // vertical pass on 8-row strips: a pixel is a maximum iff it is alive, equals its row maximum,
+        // vertical pass on VS-row strips: a pixel is a maximum iff it is alive, equals its row maximum,
         // is > every row maximum above and >= every one below (argmax = first index, extracter.py:69-70),
         // and is > the R cells to its left.
         for (int i0 = 0; i0 < NVS * IW; i0 += NMS_THREADS) {
             const int i = i0 + tid;
             const bool in_range = i < NVS * IW;
             const int s8 = in_range ? i / IW : 0, x = in_range ? i - s8 * IW + R : R;
-            const int y0 = R + 8 * s8;
-            float tv[8];
+            const int y0 = R + VS * s8;
+            float tv[VS];
             bool any_alive = false;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { tv[k] = t[(y0 + k) * PITCH + x]; any_alive |= tv[k] > 0.0f; }
+            for (int k = 0; k < VS; ++k) { tv[k] = t[(y0 + k) * PITCH + x]; any_alive |= tv[k] > 0.0f; }
             any_alive &= in_range;
             unsigned hits = 0;
             if (any_alive) {
-                float col[8 + 2 * R];
+                float col[VS + 2 * R];
 #pragma unroll
-                for (int k = 0; k < 8 + 2 * R; ++k) col[k] = e[(y0 - R + k) * EP + x - R];
-                float wr[8 + R + 1];
-                window_max<R, 8 + R + 1, 8 + 2 * R>(col, wr);    // wr[j] = max col[j .. j+R-1]
+                for (int k = 0; k < VS + 2 * R; ++k) col[k] = e[(y0 - R + k) * EP + x - R];
+                float wr[VS + R + 1];
+                window_max<R, VS + R + 1, VS + 2 * R>(col, wr);    // wr[j] = max col[j .. j+R-1]
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < VS; ++k) {
                     const int y = y0 + k;
                     const float v = tv[k];
                     if (y < LH - R && v > 0.0f && v == col[k + R] && v > wr[k] && v >= wr[k + R + 1]) {
@@ -396,8 +425,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
                     }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) append((hits >> k) & 1u, (y0 + k) * PITCH + x, par);
+            append_mask(hits, y0 * PITCH + x, PITCH, par);
         }
         __syncthreads();
         const int nmax = min(s_n[par], MAXLIST);
@@ -410,65 +438,72 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 
     const int by = ty * TH, bx = tx * TW;
     int changed = 0;
-    if (first && a.ulist) {     // the local rounds are over: maxlist and its counter are reused for the undecided pixels
+    if (first && (a.ulist || a.clist)) {     // the local rounds are over: maxlist and its counter are reused for the undecided pixels
         __syncthreads();
         if (tid == 0) { s_n[0] = 0; s_over = 0; s_nc = 0; }
         __syncthreads();
     }
-#pragma unroll
-    for (int k = 0; k < TH * TW / NMS_THREADS; ++k) {
-        const int o = tid + k * NMS_THREADS, oy = o / TW, ox = o - oy * TW;
+    {   // write-back: eight pixels per owner thread, 16-byte stores where the row allows them
         const int gy = by + oy, gx = bx + ox;
-        bool undecided = false;
-        if (gy < a.H && gx < a.W) {
-            const float v = t[(oy + 2 * R) * PITCH + ox + 2 * R];
-            if (v != orig[k]) changed = 1;
-            if (first || v != orig[k]) out[(size_t)gy * a.W + gx] = v;
-            undecided = v > 0.0f;
-        }
-        if (first && a.ulist) append(undecided, gy * a.W + gx, 0);     // what this tile could not settle goes to nms_tail
-        if (first && a.clist) {     // scores of the maxima confirmed here that the detection could output (wave-aggregated LDS append)
-            bool hit = false;
-            float sc = 0.0f;
-            if (gy < a.H && gx < a.W) {
-                const float v = t[(oy + 2 * R) * PITCH + ox + 2 * R];
-                sc = -v;
-                hit = v < 0.0f && sc > a.cmin && gx >= a.border && gx < a.W - a.border && gy >= a.border && gy < a.H - a.border;
+        unsigned umask = 0, cmask = 0;
+        float v[8];
+        if (owner && gy < a.H && gx < a.W) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = t[(oy + 2 * R) * PITCH + ox + 2 * R + k];
+            float* o = out + (size_t)gy * a.W + gx;
+            const bool whole = gx + 8 <= a.W;
+            unsigned diff = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if ((whole || gx + k < a.W) && v[k] != orig[k]) diff |= 1u << k;
+            if (diff) changed = 1;
+            if (first && whole && (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if ((whole || gx + k < a.W) && (first || ((diff >> k) & 1u))) o[k] = v[k];
             }
-            const unsigned long long bal = __ballot(hit);
-            if (bal) {
-                int base = 0;
-                if (lane == __ffsll((long long)bal) - 1) base = atomicAdd(&s_nc, __popcll(bal));
-                base = __shfl(base, __ffsll((long long)bal) - 1, 64);
-                const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (hit && slot < CLOCAL) clocal[slot] = sc;
+            if (first) {
+                const bool rows_in = gy >= a.border && gy < a.H - a.border;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool in = whole || gx + k < a.W;
+                    if (in && v[k] > 0.0f) umask |= 1u << k;        // what this tile could not settle goes to nms_tail
+                    // scores of the maxima confirmed here that the detection could output
+                    if (in && v[k] < 0.0f && -v[k] > a.cmin && rows_in && gx + k >= a.border && gx + k < a.W - a.border) cmask |= 1u << k;
+                }
             }
         }
-    }
-    if (first && a.clist) {
-        __syncthreads();
-        const int cnt = s_nc;
-        if (tid == 0) s_cbase = cnt ? atomicAdd(&a.ccount[img], cnt > CLOCAL ? a.ccap + cnt : cnt) : 0;     // overflow of the tile's list: poison the count
-        __syncthreads();
-        const int cb = s_cbase;
-        for (int i = tid; i < min(cnt, CLOCAL); i += NMS_THREADS)
-            if (cb + i < a.ccap) a.clist[(size_t)img * a.ccap + cb + i] = clocal[i];
-    }
-    if (first && a.ulist) {
-        __syncthreads();
-        const int cnt = min(s_n[0], MAXLIST);
-        if (tid == 0) s_n[1] = cnt ? atomicAdd(&a.ucount[img], s_over ? a.ucap + cnt : cnt) : 0;   // overflow of the tile's list: poison the count
-        __syncthreads();
-        const int base = s_n[1];
-        for (int i = tid; i < cnt; i += NMS_THREADS)
-            if (base + i < a.ucap) a.ulist[(size_t)img * 2 * a.ucap + base + i] = make_int2(maxlist[i], -1);
+        if (first && a.ulist) append_mask(umask, gy * a.W + gx, 1, 0);
+        if (first && a.clist && cmask) {
+            int slot = atomicAdd(&s_nc, __popc(cmask));
+            while (cmask) {
+                const int k = __ffs((int)cmask) - 1;
+                cmask &= cmask - 1;
+                if (slot < CLOCAL) clocal[slot] = -v[k];
+                ++slot;
+            }
+        }
     }
     if (changed) s_changed = 1;
     __syncthreads();
-    if (tid == 0) {
+    // both lists are flushed in one phase: their two global counters are bumped by two different waves, in flight together
+    const int cnt_c = (first && a.clist) ? s_nc : 0;
+    const int cnt_u = (first && a.ulist) ? min(s_n[0], MAXLIST) : 0;
+    if (tid == 0 && cnt_c) s_cbase = atomicAdd(&a.ccount[img], cnt_c > CLOCAL ? a.ccap + cnt_c : cnt_c);     // overflow of the tile's list: poison the count
+    if (tid == 64 && cnt_u) s_n[1] = atomicAdd(&a.ucount[img], s_over ? a.ucap + cnt_u : cnt_u);            // likewise
+    if (tid == 128) {
         const int flag = (s_changed || unconverged) ? 1 : 0;
         tcur[tile] = flag;
         if (flag) atomicMax(&a.lastchg[img], a.sweep + 1);
+    }
+    if (cnt_c || cnt_u) {
+        __syncthreads();
+        const int cb = s_cbase, ub = s_n[1];
+        for (int i = tid; i < min(cnt_c, CLOCAL); i += NMS_THREADS)
+            if (cb + i < a.ccap) a.clist[(size_t)img * a.ccap + cb + i] = clocal[i];
+        for (int i = tid; i < cnt_u; i += NMS_THREADS)
+            if (ub + i < a.ucap) a.ulist[(size_t)img * 2 * a.ucap + ub + i] = make_int2(maxlist[i], -1);
     }
 }
 
