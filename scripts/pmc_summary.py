@@ -11,7 +11,7 @@ ncall = collections.defaultdict(int)
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
     n = re.sub(r"^void ", "", n)
-    return n.split("(")[0][:48]
+    return n.split("(")[0][:120]
 
 for f in glob.glob(os.path.join(root, "p*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -25,13 +25,14 @@ for f in glob.glob(os.path.join(root, "p1", "**", "*kernel_trace.csv"), recursiv
         ncall[k] += 1
 names = sorted(dur, key=lambda k: -dur[k])
 ctrs = sorted({c for k in agg for c in agg[k]})
-print("kernel,calls,total_us,avg_us," + ",".join(ctrs))
+out = csv.writer(sys.stdout, lineterminator="\n")           # kernel names carry template commas: quoted
+out.writerow(["kernel", "calls", "total_us", "avg_us"] + ctrs)
 for k in names:
     row = [k, str(ncall[k]), "%.1f" % dur[k], "%.1f" % (dur[k] / max(ncall[k], 1))]
     for c in ctrs:
         n = calls[k].get(c, 0)
         row.append("%.4g" % (agg[k][c] / n) if n else "")
-    print(",".join(row))
+    out.writerow(row)
 
 # HBM traffic per launch for the kernels bench.py can name (MI355X_MICROARCH.md, "HBM": FETCH_SIZE and
 # WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled; WRITE_SIZE exact).
