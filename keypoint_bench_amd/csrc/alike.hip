@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             keep = v;
         } else {        // max_pool2d(x1, 2, 2): the row pair in registers, the other pixel of the pair two lane groups away
             float4 m = make_float4(fmaxf(keep.x, v.x), fmaxf(keep.y, v.y), fmaxf(keep.z, v.z), fmaxf(keep.w, v.w));
-            m.x = fmaxf(m.x, __shfl_xor(m.x, 32, 64)); m.y = fmaxf(m.y, __shfl_xor(m.y, 32, 64));
-            m.z = fmaxf(m.z, __shfl_xor(m.z, 32, 64)); m.w = fmaxf(m.w, __shfl_xor(m.w, 32, 64));
+            m.x = kpb_max32(m.x); m.y = kpb_max32(m.y);
+            m.z = kpb_max32(m.z); m.w = kpb_max32(m.w);
             const int py = gy >> 1, pxl = (tx0 >> 1) + pr;
             if (sN == 0 && py < H2 && pxl < W2) *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + py) * W2 + pxl) * 8 + c0) = m;
         }
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         }
         float sg = fmaf(av.w, wsg.w, fmaf(av.z, wsg.z, fmaf(av.y, wsg.y, av.x * wsg.x)));      // this group's share of the score logit
         sg += __shfl_xor(sg, 16, 64);
-        sg += __shfl_xor(sg, 32, 64);
+        sg = kpb_sum32(sg);
         if (g == 0 && ok) S2[(size_t)gy * a.W + gx] = sg;
     }
     if (a.p2) {     // columns: lanes px, px ^ 1, px ^ 2, px ^ 3 hold the four pixels of a pooled cell
@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
             const float4 w = *reinterpret_cast<const float4*>(&Wsz[h * 16 + 4 * q]);
             sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
         }
-        sc += __shfl_xor(sc, 32, 64);
+        sc = kpb_sum32(sc);
         sc += (1.0f - lx3) * v3[t3 * ESTRIDE + 64] + lx3 * v3[(t3 + 1) * ESTRIDE + 64];
         sc += (1.0f - lx4) * v4[t4 * ESTRIDE + 64] + lx4 * v4[(t4 + 1) * ESTRIDE + 64];
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
@@ -1289,7 +1289,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
             const float4 w = *reinterpret_cast<const float4*>(&Wsz[h * 16 + 4 * q]);
             sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
         }
-        sc += __shfl_xor(sc, 32, 64);
+        sc = kpb_sum32(sc);
         sc += (1.0f - lx3) * v3[t3 * ESTRIDE + 64] + lx3 * v3[(t3 + 1) * ESTRIDE + 64];
         sc += (1.0f - lx4) * v4[t4 * ESTRIDE + 64] + lx4 * v4[(t4 + 1) * ESTRIDE + 64];
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)

@@ -1,6 +1,7 @@
 // conv_mfma.h -- the generic fp32 NHWC convolution / linear layer on v_mfma_f32_32x32x2_f32 shared by the extractor
 // nets (convnet.hip) and the LightGlue matcher (lightglue.hip, where a Linear over tokens is a 1x1 convolution).
 #pragma once
+#include <type_traits>
 #include "net.h"
 
 #include <algorithm>
@@ -225,11 +226,22 @@ __device__ __forceinline__ float cm_amax4(float m, const float4 v)
 {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
 }
+// maximum of a NON-NEGATIVE value over the wave, in every lane.  Six DPP steps on the vector ALU (quad swaps, the two row mirrors,
+// the two row broadcasts; lanes a step does not reach read 0, which a non-negative maximum ignores) and one v_readlane of lane 63:
+// the butterfly of __shfl_xor is six ds_bpermute round trips through the LDS crossbar (1.3 k cycles in block 1's prologue).
 __device__ __forceinline__ float cm_wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    auto step = [](float x, auto ctrl, auto rows) {
+        const int y = __builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(rows)::value, 0xF, true);
+        return fmaxf(x, __int_as_float(y));
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});     // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});     // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});    // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});    // row_mirror: every lane holds its row's maximum
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});    // row_bcast:15 into rows 1 and 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});    // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // XC: one more output channel than the tiles hold (DISK's 129 = 4 x 32 + 1) is accumulated on the VALU from the same LDS

@@ -13,6 +13,19 @@
 
 #include "../../include/kpb.h"
 
+// The two 32-lane halves of a wave exchanged on the vector ALU (gfx950's v_permlane32_swap): `lo` = the value of lane & 31 in
+// every lane, `hi` = that of lane | 32.  A commutative op(lo, hi) equals op(v, __shfl_xor(v, 32)) bit for bit in every lane,
+// without the ds_bpermute round trip through the LDS crossbar.
+__device__ __forceinline__ void kpb_halves32(float v, float& lo, float& hi)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float kpb_max32(float v) { float a, b; kpb_halves32(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float kpb_min32(float v) { float a, b; kpb_halves32(v, a, b); return fminf(a, b); }
+__device__ __forceinline__ float kpb_sum32(float v) { float a, b; kpb_halves32(v, a, b); return a + b; }
+
 struct kpb_buf {
     void* p = nullptr;
     size_t cap = 0;

@@ -181,13 +181,13 @@ __global__ __launch_bounds__(256) void lg_flash(FlashArgs a)
             sc[r] = key < nk ? st[r] * a.scale : -INFINITY;
             mx = fmaxf(mx, sc[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = kpb_max32(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = (m_run == -INFINITY) ? 0.0f : expf(m_run - m_new);
         float ps = 0.0f, pr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { pr[r] = (sc[r] == -INFINITY) ? 0.0f : expf(sc[r] - m_new); ps += pr[r]; }
-        ps += __shfl_xor(ps, 32, 64);
+        ps = kpb_sum32(ps);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         // rescale O: its rows are queries (r&3) + 8*(r>>2) + 4h, whose alpha lives in the lane of that query
@@ -369,13 +369,13 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
             sc[r] = key < nk ? st[r] * kscale : -INFINITY;
             mx = fmaxf(mx, sc[r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = kpb_max32(mx);
         const float m_new = fmaxf(m_run, mx);
         const float alpha = (m_run == -INFINITY) ? 0.0f : __expf(m_run - m_new);
         float ps = 0.0f, pr[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { pr[r] = (sc[r] == -INFINITY) ? 0.0f : __expf(sc[r] - m_new); ps += pr[r]; }
-        ps += __shfl_xor(ps, 32, 64);
+        ps = kpb_sum32(ps);
         l_run = l_run * alpha + ps;
         m_run = m_new;
         if (__ballot(alpha != 1.0f)) {      // once the running maxima have settled every alpha is exactly 1: skip the 16 lane exchanges

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void match_approx(ApxArgs a)
         }
         if (PASS == 0) {            // column minimum over this wave's rows: over the four lane groups, then one atomic per column
             cm = fminf(cm, __shfl_xor(cm, 16, 64));
-            cm = fminf(cm, __shfl_xor(cm, 32, 64));
+            cm = kpb_min32(cm);
             if (g == 0 && j < m) atomicMin(&a.colmin[(size_t)b * a.max_m + j], __float_as_uint(cm));
         }
     }
