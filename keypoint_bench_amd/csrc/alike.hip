@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             const bool ok = i < NIN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
 #pragma unroll
             for (int c = 0; c < 3; ++c) buf[k][c] = ok ? img[c * P + (size_t)gy * a.W + gx] : 0.0f;
-            am = fmaxf(fmaxf(am, fabsf(buf[k][0])), fmaxf(fabsf(buf[k][1]), fabsf(buf[k][2])));
+            am = kpb_pmax(kpb_pmax(am, fabsf(buf[k][0])), kpb_pmax(fabsf(buf[k][1]), fabsf(buf[k][2])));
         }
         am = cm_wave_max(am);
         if (lane == 0) s_amax[wv] = am;
@@ -357,14 +357,14 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         const float4 v = make_float4(relu(fmaf(acc[0], un2, bias2.x)), relu(fmaf(acc[1], un2, bias2.y)), relu(fmaf(acc[2], un2, bias2.z)), relu(fmaf(acc[3], un2, bias2.w)));
         if (gy < a.H && gx < a.W) {
             *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8 + c0) = v;
-            xmax = fmaxf(fmaxf(xmax, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+            xmax = kpb_pmax(kpb_pmax(xmax, kpb_pmax(v.x, v.y)), kpb_pmax(v.z, v.w));      // (x1 >= 0: integer maxima)
         }
         if ((rr & 1) == 0) {
             keep = v;
         } else {        // max_pool2d(x1, 2, 2): the row pair in registers, the other pixel of the pair two lane groups away
-            float4 m = make_float4(fmaxf(keep.x, v.x), fmaxf(keep.y, v.y), fmaxf(keep.z, v.z), fmaxf(keep.w, v.w));
-            m.x = kpb_max32(m.x); m.y = kpb_max32(m.y);
-            m.z = kpb_max32(m.z); m.w = kpb_max32(m.w);
+            float4 m = make_float4(kpb_pmax(keep.x, v.x), kpb_pmax(keep.y, v.y), kpb_pmax(keep.z, v.z), kpb_pmax(keep.w, v.w));
+            m.x = kpb_pmax32(m.x); m.y = kpb_pmax32(m.y);
+            m.z = kpb_pmax32(m.z); m.w = kpb_pmax32(m.w);
             const int py = gy >> 1, pxl = (tx0 >> 1) + pr;
             if (sN == 0 && py < H2 && pxl < W2) *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + py) * W2 + pxl) * 8 + c0) = m;
         }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         const bool ok = gy < a.H && gx < a.W;
         const float4 v = make_float4(relu(fmaf(acc[0], un_c2, bsum.x)), relu(fmaf(acc[1], un_c2, bsum.y)), relu(fmaf(acc[2], un_c2, bsum.z)), relu(fmaf(acc[3], un_c2, bsum.w)));
         if (ok && !a.p2) *reinterpret_cast<float4*>(x2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = v;
-        pm = make_float4(fmaxf(pm.x, v.x), fmaxf(pm.y, v.y), fmaxf(pm.z, v.z), fmaxf(pm.w, v.w));
+        pm = make_float4(kpb_pmax(pm.x, v.x), kpb_pmax(pm.y, v.y), kpb_pmax(pm.z, v.z), kpb_pmax(pm.w, v.w));
         {   // the x2 group, split, to this wave's LDS strip with the channel octets as slots: the B operand of agg2
             uint2 hi, lo;
             split4(make_float4(v.x * scx, v.y * scx, v.z * scx, v.w * scx), hi, lo);
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         const float4 av = make_float4(relu(ag[0] * un_a), relu(ag[1] * un_a), relu(ag[2] * un_a), relu(ag[3] * un_a));
         if (ok) {
             *reinterpret_cast<float4*>(a2 + ((size_t)gy * a.W + gx) * 16 + 4 * g) = av;
-            amx = fmaxf(fmaxf(amx, fmaxf(av.x, av.y)), fmaxf(av.z, av.w));
+            amx = kpb_pmax(kpb_pmax(amx, kpb_pmax(av.x, av.y)), kpb_pmax(av.z, av.w));
         }
         float sg = fmaf(av.w, wsg.w, fmaf(av.z, wsg.z, fmaf(av.y, wsg.y, av.x * wsg.x)));      // this group's share of the score logit
         sg += __shfl_xor(sg, 16, 64);
@@ -735,10 +735,10 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         if (g == 0 && ok) S2[(size_t)gy * a.W + gx] = sg;
     }
     if (a.p2) {     // columns: lanes px, px ^ 1, px ^ 2, px ^ 3 hold the four pixels of a pooled cell
-        pm.x = fmaxf(pm.x, __shfl_xor(pm.x, 1, 64)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, 1, 64));
-        pm.z = fmaxf(pm.z, __shfl_xor(pm.z, 1, 64)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, 1, 64));
-        pm.x = fmaxf(pm.x, __shfl_xor(pm.x, 2, 64)); pm.y = fmaxf(pm.y, __shfl_xor(pm.y, 2, 64));
-        pm.z = fmaxf(pm.z, __shfl_xor(pm.z, 2, 64)); pm.w = fmaxf(pm.w, __shfl_xor(pm.w, 2, 64));
+        pm.x = kpb_pmax(pm.x, __shfl_xor(pm.x, 1, 64)); pm.y = kpb_pmax(pm.y, __shfl_xor(pm.y, 1, 64));
+        pm.z = kpb_pmax(pm.z, __shfl_xor(pm.z, 1, 64)); pm.w = kpb_pmax(pm.w, __shfl_xor(pm.w, 1, 64));
+        pm.x = kpb_pmax(pm.x, __shfl_xor(pm.x, 2, 64)); pm.y = kpb_pmax(pm.y, __shfl_xor(pm.y, 2, 64));
+        pm.z = kpb_pmax(pm.z, __shfl_xor(pm.z, 2, 64)); pm.w = kpb_pmax(pm.w, __shfl_xor(pm.w, 2, 64));
         const int gy = ty0 + 4 * (wv >> 1), gx = tx0 + (wv & 1) * 16 + px;
         if ((px & 3) == 0 && gy < a.H && gx < a.W)
             *reinterpret_cast<float4*>(a.p2 + (size_t)b * (P / 16) * 16 + ((size_t)(gy >> 2) * (a.W >> 2) + (gx >> 2)) * 16 + 4 * g) = pm;

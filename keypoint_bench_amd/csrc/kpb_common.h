@@ -22,6 +22,10 @@ __device__ __forceinline__ void kpb_halves32(float v, float& lo, float& hi)
     lo = __uint_as_float(r[0]);
     hi = __uint_as_float(r[1]);
 }
+// maximum of two NON-NEGATIVE floats (ReLU outputs, magnitudes) on the integer ALU: their bit patterns order like the values, and no
+// canonicalising `v_max_f32 x, x` is spent on operands the compiler cannot prove quiet (8 % of block 1's vector instructions)
+__device__ __forceinline__ float kpb_pmax(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
+__device__ __forceinline__ float kpb_pmax32(float v) { float a, b; kpb_halves32(v, a, b); return kpb_pmax(a, b); }
 __device__ __forceinline__ float kpb_max32(float v) { float a, b; kpb_halves32(v, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float kpb_min32(float v) { float a, b; kpb_halves32(v, a, b); return fminf(a, b); }
 __device__ __forceinline__ float kpb_sum32(float v) { float a, b; kpb_halves32(v, a, b); return a + b; }
