@@ -795,15 +795,43 @@ constexpr int ESTRIDE = 68;             // channels of a projected map: 64 descr
 // out = relu(w . in) (ALike.py:147-150); smap = this group's share of the score logit; with E != null also the group's
 // share of every head row, E[p][o] = sum_c wproj[c][o] out[p][c] (see alike_head: the head commutes with upsampling)
 template <int CIN>
-__global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out, const float* w /*[CIN][16]*/, const float* wsg /*[16]*/,
-                                                    float* smap, size_t npix, const float* wproj /*[16][64]*/, float* E /*[npix][ESTRIDE]*/)
+__global__ __launch_bounds__(256) void conv1x1_relu(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ w /*[CIN][16]*/,
+                                                    const float* __restrict__ wsg /*[16]*/, float* __restrict__ smap, size_t npix,
+                                                    const float* __restrict__ wproj /*[16][64]*/, float* __restrict__ E /*[npix][ESTRIDE]*/)
+// (__restrict__ matters: the projection weights are read AFTER the stores of out / smap; without it the compiler could not prove them
+//  unclobbered and fetched all 1 024 of them with per-lane vector loads, 256 serialised round trips per wave -- 0.46 ms for agg3)
 {
     const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = p < npix;        // (dead lanes of the last workgroup still help to copy the projected rows out)
+    // One LDS region per wave, used twice: first to turn the wave's 64 pixels x CIN floats -- contiguous in memory, read with
+    // consecutive lanes on consecutive 16-byte pieces -- into one pixel per lane (a lane reading its own pixel straight from global
+    // memory touches 64 different lines per load instruction: r03 measured 0.46 ms for agg3 against 0.14 ms of traffic), at the end
+    // for the projected rows (below).  A wave's LDS operations execute in order: no barrier.
+    constexpr bool STAGE_IN = CIN <= 32;                   // (CIN = 64: 70 KB, and agg4 runs on 1/1024 of the pixels)
+    constexpr int XP = CIN + 4;                            // floats per staged pixel: lanes 36 floats apart read 16 bytes without bank conflicts
+    constexpr int WREG = STAGE_IN && 64 * XP > 16 * ESTRIDE ? 64 * XP : 16 * ESTRIDE;
+    __shared__ __attribute__((aligned(16))) float wlds[4][WREG];
+    float* wreg = wlds[threadIdx.x >> 6];
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
     const float* x = in + (live ? p : 0) * CIN;
+    if (STAGE_IN) {
+        const int ln = threadIdx.x & 63;
+        const size_t pw = (size_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;     // first pixel of this wave
+        float4 ld[CIN / 4];
+#pragma unroll
+        for (int i = 0; i < CIN / 4; ++i) {
+            const int j = ln + 64 * i, px = j / (CIN / 4);
+            ld[i] = pw + px < npix ? *reinterpret_cast<const float4*>(in + pw * CIN + 4 * (size_t)j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < CIN / 4; ++i) {
+            const int j = ln + 64 * i, px = j / (CIN / 4), q = j - px * (CIN / 4);
+            *reinterpret_cast<float4*>(wreg + px * XP + 4 * q) = ld[i];
+        }
+        x = wreg + ln * XP;
+    }
 #pragma unroll 2
     for (int c4 = 0; c4 < CIN / 4; ++c4) {
         const float4 v4 = *reinterpret_cast<const float4*>(x + c4 * 4);
@@ -827,9 +855,8 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* in, float* out,
         // 68 floats per pixel, 272 bytes apart: written per thread they would be 17 scattered 16-byte pieces per lane.
         // Instead each wave passes its pixels through LDS 16 at a time and writes the 16 x 272 contiguous bytes with
         // consecutive lanes on consecutive float4s (a wave's LDS operations execute in order: no barrier)
-        __shared__ __attribute__((aligned(16))) float stage[4][16 * ESTRIDE];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        float* st = stage[wv];
+        float* st = wreg;
         const size_t p0 = (size_t)blockIdx.x * 256 + wv * 64;          // first pixel of this wave
         float4 r[17];
 #pragma unroll
