@@ -730,15 +730,15 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             amx = kpb_pmax(kpb_pmax(amx, kpb_pmax(av.x, av.y)), kpb_pmax(av.z, av.w));
         }
         float sg = fmaf(av.w, wsg.w, fmaf(av.z, wsg.z, fmaf(av.y, wsg.y, av.x * wsg.x)));      // this group's share of the score logit
-        sg += __shfl_xor(sg, 16, 64);
+        sg = kpb_sum16(sg);
         sg = kpb_sum32(sg);
         if (g == 0 && ok) S2[(size_t)gy * a.W + gx] = sg;
     }
     if (a.p2) {     // columns: lanes px, px ^ 1, px ^ 2, px ^ 3 hold the four pixels of a pooled cell
-        pm.x = kpb_pmax(pm.x, __shfl_xor(pm.x, 1, 64)); pm.y = kpb_pmax(pm.y, __shfl_xor(pm.y, 1, 64));
-        pm.z = kpb_pmax(pm.z, __shfl_xor(pm.z, 1, 64)); pm.w = kpb_pmax(pm.w, __shfl_xor(pm.w, 1, 64));
-        pm.x = kpb_pmax(pm.x, __shfl_xor(pm.x, 2, 64)); pm.y = kpb_pmax(pm.y, __shfl_xor(pm.y, 2, 64));
-        pm.z = kpb_pmax(pm.z, __shfl_xor(pm.z, 2, 64)); pm.w = kpb_pmax(pm.w, __shfl_xor(pm.w, 2, 64));
+        pm.x = kpb_pmax(pm.x, kpb_xor1(pm.x)); pm.y = kpb_pmax(pm.y, kpb_xor1(pm.y));
+        pm.z = kpb_pmax(pm.z, kpb_xor1(pm.z)); pm.w = kpb_pmax(pm.w, kpb_xor1(pm.w));
+        pm.x = kpb_pmax(pm.x, kpb_xor2(pm.x)); pm.y = kpb_pmax(pm.y, kpb_xor2(pm.y));
+        pm.z = kpb_pmax(pm.z, kpb_xor2(pm.z)); pm.w = kpb_pmax(pm.w, kpb_xor2(pm.w));
         const int gy = ty0 + 4 * (wv >> 1), gx = tx0 + (wv & 1) * 16 + px;
         if ((px & 3) == 0 && gy < a.H && gx < a.W)
             *reinterpret_cast<float4*>(a.p2 + (size_t)b * (P / 16) * 16 + ((size_t)(gy >> 2) * (a.W >> 2) + (gx >> 2)) * 16 + 4 * g) = pm;

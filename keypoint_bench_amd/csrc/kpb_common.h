@@ -26,6 +26,15 @@ __device__ __forceinline__ void kpb_halves32(float v, float& lo, float& hi)
 // canonicalising `v_max_f32 x, x` is spent on operands the compiler cannot prove quiet (8 % of block 1's vector instructions)
 __device__ __forceinline__ float kpb_pmax(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
 __device__ __forceinline__ float kpb_pmax32(float v) { float a, b; kpb_halves32(v, a, b); return kpb_pmax(a, b); }
+// likewise for lanes 16 apart (v_permlane16_swap: rows 1 / 3 of one operand against rows 0 / 2 of the other) and, for the quad
+// neighbours lane ^ 1 and lane ^ 2, DPP quad permutes -- none of which the compiler derives from __shfl_xor (it emits ds_bpermute)
+__device__ __forceinline__ float kpb_sum16(float v)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float kpb_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
+__device__ __forceinline__ float kpb_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
 __device__ __forceinline__ float kpb_max32(float v) { float a, b; kpb_halves32(v, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float kpb_min32(float v) { float a, b; kpb_halves32(v, a, b); return fminf(a, b); }
 __device__ __forceinline__ float kpb_sum32(float v) { float a, b; kpb_halves32(v, a, b); return a + b; }
