@@ -18,8 +18,11 @@ OBJ = os.path.join(HERE, "_obj")
 SO = os.path.join(HERE, "libkpb.so")
 SOURCES = ["api.hip", "detect.hip", "match.hip", "net_api.hip", "alike.hip", "convnet.hip", "lightglue.hip", "covis.hip", "lk.hip",
            "preprocess.hip", "geometry.hip"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary vector registers.  gfx950's register file is unified, so accumulation
+# registers buy no occupancy, and every value that crosses between them and the vector ALUs costs a v_accvgpr_read / _write: 240 of
+# them in lg_flash_h (192 -> 145 registers without), 24 in alike_block2, 8 in alike_block1_h (r03, found in the ISA).
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-result", "-fvisibility=hidden"]
+         "-Wall", "-Wno-unused-result", "-fvisibility=hidden", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _headers():
