@@ -288,6 +288,11 @@ __global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) v
     __shared__ __attribute__((aligned(16))) float s_amax[4];       // the four waves' largest staged magnitude of the slab in flight
     float xacc = 0.0f;
     int e_cur = 24;              // exponent the accumulators' activation scale belongs to (workgroup-uniform)
+    // the lane's biases are requested now: read in the epilogue, each cost an exposed L2 round trip behind the last MFMA (r03 stamps:
+    // the epilogue of SuperPoint's conv1b took 11 k of the workgroup's 70 k cycles)
+    float biasv[NTB];
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) biasv[n] = a.bias[(nt0 + n) * 32 + p];
     f32x16 acc[MT][NTB];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) v
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
             const int co = (nt0 + n) * 32 + p;
-            const float bias = a.bias[co];
+            const float bias = biasv[n];
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -496,6 +501,9 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)a.NCH * NKB * 4 * 32;
     unsigned char* wt = tile + wv * WBUF;
+    float biasv[NTB];            // requested now, used in the epilogue (see conv_mfma_h)
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) biasv[n] = a.bias[(nt0 + n) * 32 + p];
 
     f32x16 acc[MT][NTB];
 #pragma unroll
@@ -587,7 +595,7 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
             const int co = (nt0 + n) * 32 + p;
-            const float bias = a.bias[co];
+            const float bias = biasv[n];
             if (co >= a.COUT) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
