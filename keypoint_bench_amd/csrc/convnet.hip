@@ -374,7 +374,9 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     const dim3 grid(cdiv(a.H * a.W, 256), a.COUT8 / 8, B), block(256);
     hipStream_t st = ctx->stream;
     const bool t3 = L.ks == 3 && !xf;
-    if (t3 && L.cin == 1 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 1, 1>), grid, block, 0, st, a);
+    if (t3 && L.cin == 1 && L.stride == 1 && L.cout == 4)      // XFeat block1.0: four output channels per thread, one 16-byte store (the 8-wide instance computed four padding channels and stored dword by dword)
+        KPB_LAUNCH(ctx, name, (conv_valu_t<3, 1, 1, 4>), dim3(grid.x, 1, grid.z), block, 0, st, a);
+    else if (t3 && L.cin == 1 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 1, 1>), grid, block, 0, st, a);
     else if (t3 && L.cin == 4 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 4, 2>), grid, block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 1>), grid, block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 2 && a.COUT8 == 32)
