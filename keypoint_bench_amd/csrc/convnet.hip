@@ -64,7 +64,9 @@ __global__ __launch_bounds__(256) void conv_valu(ConvV a)
 // The same layer with kernel size, input channels and stride known at compile time (XFeat's block1: 1->4, 4->8/2, 8->8,
 // 8->24/2, all 3x3): taps and channels unroll, a pixel's channels arrive as float4 loads, the weights of a tap are one
 // scalar burst.  Bounds are tested per tap (zero padding), as in conv_valu.
-template <int KS, int CIN, int S, int CPT = 8>      // CPT output channels per thread: the taps are read once per CPT
+// CREAL < CPT: the last CPT - CREAL channels are padding (zero weights and bias: XFeat's 24-channel stage is stored 32 wide for the
+// MFMA layers behind it) -- they are stored as the zeros they are without being multiplied.
+template <int KS, int CIN, int S, int CPT = 8, int CREAL = CPT>      // CPT output channels per thread: the taps are read once per CPT
 __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
 {
     constexpr int PAD = KS / 2;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
     const float* in = a.in + (size_t)b * a.Hi * a.Wi * CIN;
     float acc[CPT];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) acc[j] = a.bias[cg * CPT + j];
+    for (int j = 0; j < CPT; ++j) acc[j] = j < CREAL ? a.bias[cg * CPT + j] : 0.0f;
 #pragma unroll
     for (int ky = 0; ky < KS; ++ky) {
         const int iy = oy * S + ky - PAD;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
             for (int c = 0; c < CIN; ++c) {
                 const float vc = inside ? v[c] : 0.0f;
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) acc[j] = fmaf(vc, w[(size_t)c * a.COUT8 + j], acc[j]);
+                for (int j = 0; j < CREAL; ++j) acc[j] = fmaf(vc, w[(size_t)c * a.COUT8 + j], acc[j]);
             }
         }
     }
@@ -380,7 +382,10 @@ int launch_valu(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     else if (t3 && L.cin == 4 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 4, 2>), grid, block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 1) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 1>), grid, block, 0, st, a);
     else if (t3 && L.cin == 8 && L.stride == 2 && a.COUT8 == 32)
-        KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2, 32>), dim3(grid.x, 1, grid.z), block, 0, st, a);
+    {
+        if (skn == 24) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2, 32, 24>), dim3(grid.x, 1, grid.z), block, 0, st, a);      // XFeat block1.3: channels 24..31 are padding
+        else KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2, 32>), dim3(grid.x, 1, grid.z), block, 0, st, a);
+    }
     else if (t3 && L.cin == 8 && L.stride == 2) KPB_LAUNCH(ctx, name, (conv_valu_t<3, 8, 2>), grid, block, 0, st, a);
     else {
         if (gray) return kpb_fail(ctx, KPB_E_INVALID, "conv_valu: the fused skip connection needs a templated instance");
