@@ -194,13 +194,11 @@ __global__ __launch_bounds__(256) void softmax65_d2s(const float* semi, float* h
     const float* s = semi + ((size_t)b * ncell + cell) * 65;
     const float v = s[lane], d = s[64];
     float m = v;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    m = kpb_wave_fmax(m);
     m = fmaxf(m, d);
     const float e = expf(v - m), ed = expf(d - m);
     float sum = e;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = kpb_wave_sum(sum);
     sum += ed;
     const int cy = cell / Wc, cx = cell - cy * Wc;
     const int W = Wc * 8;
@@ -216,8 +214,7 @@ __global__ __launch_bounds__(256) void l2norm_nhwc(float* desc, int C, size_t np
     float* d = desc + pix * C;
     float ss = 0.0f;
     for (int c = lane; c < C; c += 64) ss = fmaf(d[c], d[c], ss);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = kpb_wave_sum(ss);
     float n = sqrtf(ss);
     if (eps_clamp > 0.0f) n = fmaxf(n, eps_clamp);     // F.normalize clamps; torch.norm + div does not
     for (int c = lane; c < C; c += 64) d[c] = __fdiv_rn(d[c], n);
@@ -720,8 +717,7 @@ __global__ __launch_bounds__(256) void disk_head(const float* feat, float* desc,
     const float* f = feat + pix * 129;
     const float a = f[lane], b = f[lane + 64];
     float ss = fmaf(a, a, b * b);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = kpb_wave_sum(ss);
     const float n = fmaxf(sqrtf(ss), 1e-12f);
     desc[pix * 128 + lane] = __fdiv_rn(a, n);
     desc[pix * 128 + lane + 64] = __fdiv_rn(b, n);

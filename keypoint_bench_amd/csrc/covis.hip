@@ -232,8 +232,8 @@ __device__ __forceinline__ float dm_cell(const float2 a0, const float2 a01, cons
     return (i == j && i < nd) ? 99999.f : d;
 }
 
-__device__ __forceinline__ float wave_min(float v) { for (int o = 32; o; o >>= 1) v = fminf(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ float wave_max(float v) { for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ float wave_min(float v) { return kpb_wave_fmin(v); }
+__device__ __forceinline__ float wave_max(float v) { return kpb_wave_fmax(v); }
 
 // wave w < M: row w (min over columns, max over columns); wave w >= M: column w - M
 __global__ __launch_bounds__(256) void covis_stats(ValArgs a)

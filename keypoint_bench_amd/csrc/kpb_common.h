@@ -10,6 +10,7 @@
 #include <set>
 #include <string>
 #include <vector>
+#include <type_traits>
 
 #include "../../include/kpb.h"
 
@@ -35,6 +36,59 @@ __device__ __forceinline__ float kpb_sum16(float v)
 }
 __device__ __forceinline__ float kpb_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float kpb_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // quad_perm [2,3,0,1]
+// __shfl_xor(v, N, 64) for the six butterfly distances without the LDS crossbar: the value of lane ^ N in every lane (bit-identical
+// to the shuffle, so any reduction written as `for (o = 32; o; o >>= 1) v = op(v, kpb_shfl_xor<o>(v))` keeps its result).
+//   1, 2: DPP quad permutes;  4: two row shifts, each written into the quads (banks) it is valid for;  8: row rotate by 8;
+//   16, 32: v_permlane16_swap / v_permlane32_swap give both halves, the lane keeps the one that is not its own.
+template <int N>
+__device__ __forceinline__ float kpb_shfl_xor(float v);
+template <int N>
+__device__ __forceinline__ int kpb_shfl_xor(int v) { return __float_as_int(kpb_shfl_xor<N>(__int_as_float(v))); }
+template <int N>
+__device__ __forceinline__ float kpb_shfl_xor(float v)
+{
+    static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16 || N == 32, "butterfly distances only");
+    const int x = __float_as_int(v);
+    if constexpr (N == 1) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, false));
+    else if constexpr (N == 2) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, false));
+    else if constexpr (N == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);      // row_shl:4 into quads 0 and 2: lane i reads lane i + 4
+        return __int_as_float(__builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false));     // row_shr:4 into quads 1 and 3: lane i reads lane i - 4
+    } else if constexpr (N == 8) return __int_as_float(__builtin_amdgcn_update_dpp(x, x, 0x128, 0xF, 0xF, false));   // row_ror:8
+    else if constexpr (N == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);      // r[0] = rows (0, 0, 2, 2), r[1] = rows (1, 1, 3, 3)
+        return __uint_as_float((__lane_id() & 16) ? r[0] : r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);      // r[0] = low half twice, r[1] = high half twice
+        return __uint_as_float((__lane_id() & 32) ? r[0] : r[1]);
+    }
+}
+// f(integral_constant<int, o>) for o = 32, 16, 8, 4, 2, 1: the loop `for (o = 32; o; o >>= 1)` with o a compile-time constant
+template <class F>
+__device__ __forceinline__ void kpb_butterfly(F&& f)
+{
+    f(std::integral_constant<int, 32>{}); f(std::integral_constant<int, 16>{}); f(std::integral_constant<int, 8>{});
+    f(std::integral_constant<int, 4>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 1>{});
+}
+// the butterflies themselves (same pairing and order as the __shfl_xor loops they replace)
+__device__ __forceinline__ float kpb_wave_sum(float v)
+{
+    v += kpb_shfl_xor<32>(v); v += kpb_shfl_xor<16>(v); v += kpb_shfl_xor<8>(v);
+    v += kpb_shfl_xor<4>(v); v += kpb_shfl_xor<2>(v); v += kpb_shfl_xor<1>(v);
+    return v;
+}
+__device__ __forceinline__ float kpb_wave_fmax(float v)
+{
+    v = fmaxf(v, kpb_shfl_xor<32>(v)); v = fmaxf(v, kpb_shfl_xor<16>(v)); v = fmaxf(v, kpb_shfl_xor<8>(v));
+    v = fmaxf(v, kpb_shfl_xor<4>(v)); v = fmaxf(v, kpb_shfl_xor<2>(v)); v = fmaxf(v, kpb_shfl_xor<1>(v));
+    return v;
+}
+__device__ __forceinline__ float kpb_wave_fmin(float v)
+{
+    v = fminf(v, kpb_shfl_xor<32>(v)); v = fminf(v, kpb_shfl_xor<16>(v)); v = fminf(v, kpb_shfl_xor<8>(v));
+    v = fminf(v, kpb_shfl_xor<4>(v)); v = fminf(v, kpb_shfl_xor<2>(v)); v = fminf(v, kpb_shfl_xor<1>(v));
+    return v;
+}
 __device__ __forceinline__ float kpb_max32(float v) { float a, b; kpb_halves32(v, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float kpb_min32(float v) { float a, b; kpb_halves32(v, a, b); return fminf(a, b); }
 __device__ __forceinline__ float kpb_sum32(float v) { float a, b; kpb_halves32(v, a, b); return a + b; }

@@ -40,11 +40,7 @@ __global__ __launch_bounds__(256) void lg_prepare(PrepArgs a)
         a.kpx[((size_t)s * a.MP + t) * 2] = x; a.kpx[((size_t)s * a.MP + t) * 2 + 1] = y;
         mnx = fminf(mnx, x); mny = fminf(mny, y); mxx = fmaxf(mxx, x); mxy = fmaxf(mxy, y);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = fminf(mnx, __shfl_xor(mnx, o, 64)); mny = fminf(mny, __shfl_xor(mny, o, 64));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o, 64)); mxy = fmaxf(mxy, __shfl_xor(mxy, o, 64));
-    }
+    mnx = kpb_wave_fmin(mnx); mny = kpb_wave_fmin(mny); mxx = kpb_wave_fmax(mxx); mxy = kpb_wave_fmax(mxy);
     if ((tid & 63) == 0) { red[tid >> 6][0] = mnx; red[tid >> 6][1] = mny; red[tid >> 6][2] = mxx; red[tid >> 6][3] = mxy; }
     __syncthreads();
     mnx = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0])); mny = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1]));
@@ -106,8 +102,7 @@ __global__ __launch_bounds__(256) void lg_sample(SampleArgs a)
             ss = fmaf(v[q], v[q], ss);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    ss = kpb_wave_sum(ss);
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);                      // F.normalize
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -435,14 +430,12 @@ __global__ __launch_bounds__(256) void lg_ln_gelu(float* hbuf, const float* g, c
     float v[8], sum = 0.0f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) { v[q] = x[lane + 64 * q]; sum += v[q]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = kpb_wave_sum(sum);
     const float mean = sum / 512.0f;
     float var = 0.0f;
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const float d = v[q] - mean; var = fmaf(d, d, var); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    var = kpb_wave_sum(var);
     const float rstd = 1.0f / sqrtf(var / 512.0f + 1e-5f);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -481,8 +474,7 @@ __global__ __launch_bounds__(256) void lg_conf(const float* cat, const float* wc
         const float4 c = *reinterpret_cast<const float4*>(wc + 4 * lane);
         zc = fmaf(x.x, c.x, fmaf(x.y, c.y, fmaf(x.z, c.z, x.w * c.w)));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { zc += __shfl_xor(zc, o, 64); zm += __shfl_xor(zm, o, 64); }
+    zc = kpb_wave_sum(zc); zm = kpb_wave_sum(zm);
     if (lane == 0) {
         const size_t o = (size_t)s * MP + t;
         zm += bm[0];
@@ -517,8 +509,7 @@ __global__ __launch_bounds__(256) void lg_decide(DecideArgs a)
             const int s = s0 + side, n = a.cnt[s];
             for (int t = tid; t < n; t += 256) unconf += a.conf[(size_t)s * a.MP + t] < a.thr;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) unconf += __shfl_xor(unconf, o, 64);
+        unconf = kpb_wave_sum(unconf);
         if (lane == 0) wsum[wid] = unconf;
         __syncthreads();
         if (tid == 0) {
@@ -636,12 +627,10 @@ __global__ __launch_bounds__(256) void lg_lse(const float* sim, float* mxo, floa
     const size_t stride = mode ? MP : 1;
     float mx = -INFINITY;
     for (int k = lane; k < len; k += 64) mx = fmaxf(mx, base[k * stride]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    mx = kpb_wave_fmax(mx);
     float sum = 0.0f;
     for (int k = lane; k < len; k += 64) sum += expf(base[k * stride] - mx);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = kpb_wave_sum(sum);
     if (lane == 0) { mxo[(size_t)(2 * b + mode) * MP + line] = mx; lgo[(size_t)(2 * b + mode) * MP + line] = logf(sum); }
 }
 
@@ -669,11 +658,11 @@ __global__ __launch_bounds__(256) void lg_best(const float* sim, const float* mx
         const float v = (s0 + s1) + (logsigmoid(zlog[r0 + i]) + logsigmoid(zlog[r1 + j]));
         if (v > bv) { bv = v; bi = k; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+    kpb_butterfly([&](auto o) {
+        constexpr int O = decltype(o)::value;
+        const float ov = kpb_shfl_xor<O>(bv); const int oi = kpb_shfl_xor<O>(bi);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    });
     if (lane == 0) { bestv[(size_t)(2 * b + mode) * MP + line] = bv; besti[(size_t)(2 * b + mode) * MP + line] = bi; }
 }
 

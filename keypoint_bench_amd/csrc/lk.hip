@@ -94,8 +94,7 @@ __global__ void lk_init(const float* pts1, const float* pts2, int stride, const 
 
 __device__ __forceinline__ float wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = kpb_wave_sum(v);
     return v;
 }
 

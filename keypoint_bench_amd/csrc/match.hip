@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void match_prep(PreArgs a)
             dst[lo_off + p8] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
         }
     }
-    nn += __shfl_xor(nn, 1, 64); nn += __shfl_xor(nn, 2, 64); nn += __shfl_xor(nn, 4, 64);       // the same tree for every row: deterministic
+    nn += kpb_shfl_xor<1>(nn); nn += kpb_shfl_xor<2>(nn); nn += kpb_shfl_xor<4>(nn);       // the same tree for every row: deterministic
     // The filter's error bound (match_margin) holds while every component is carried to 2^-20 relative or 2^-25 absolute, i.e.
     // while its hi half does not saturate: a component of magnitude >= 2^15 (un-normalised descriptors can be anything) hands
     // the whole pair to the exact kernel, like a non-finite one.
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void match_approx(ApxArgs a)
             }
         }
         if (PASS == 0) {            // column minimum over this wave's rows: over the four lane groups, then one atomic per column
-            cm = fminf(cm, __shfl_xor(cm, 16, 64));
+            cm = fminf(cm, kpb_shfl_xor<16>(cm));
             cm = kpb_min32(cm);
             if (g == 0 && j < m) atomicMin(&a.colmin[(size_t)b * a.max_m + j], __float_as_uint(cm));
         }
@@ -481,8 +481,8 @@ __global__ __launch_bounds__(256) void match_approx(ApxArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = rmin[rt][r];
-                v = fminf(v, __shfl_xor(v, 1, 64)); v = fminf(v, __shfl_xor(v, 2, 64));
-                v = fminf(v, __shfl_xor(v, 4, 64)); v = fminf(v, __shfl_xor(v, 8, 64));
+                v = fminf(v, kpb_shfl_xor<1>(v)); v = fminf(v, kpb_shfl_xor<2>(v));
+                v = fminf(v, kpb_shfl_xor<4>(v)); v = fminf(v, kpb_shfl_xor<8>(v));
                 const int i = i0 + 16 * rt + 4 * g + r;
                 if (c16 == 0 && i < n) a.rowmin[(size_t)b * a.max_n + i] = __float_as_uint(v);
             }
