@@ -184,31 +184,57 @@ __global__ void rgb_sum(const float* img, float* gray, size_t P)
 }
 
 // SuperPoint.py:64-69: softmax over the 65 logits of a cell, drop the dustbin, depth-to-space 8x8.
-// One wave per cell: lane c holds logit c, lane 0 also folds in logit 64.
-__global__ __launch_bounds__(256) void softmax65_d2s(const float* semi, float* heat, int Hc, int Wc, int ncell)
+// One wave per cell: lane c holds logit c, lane 0 also folds in logit 64.  A wave takes PXW cells in a row, all their loads in
+// flight before the first reduction: with one 260-byte cell per wave the kernel had 8 KB in flight per CU and ran at a quarter of
+// its HBM bound (r03).  Per cell the arithmetic is unchanged.
+constexpr int PXW = 8;
+__global__ __launch_bounds__(256) void softmax65_d2s(const float* __restrict__ semi, float* __restrict__ heat, int Hc, int Wc, int ncell)
 {
     const int lane = threadIdx.x & 63;
-    const int cell = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int cell0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PXW;
     const int b = blockIdx.y;
-    if (cell >= ncell) return;
-    const float* s = semi + ((size_t)b * ncell + cell) * 65;
-    const float v = s[lane], d = s[64];
-    float m = v;
-    m = kpb_wave_fmax(m);
-    m = fmaxf(m, d);
-    const float e = expf(v - m), ed = expf(d - m);
-    float sum = e;
-    sum = kpb_wave_sum(sum);
-    sum += ed;
-    const int cy = cell / Wc, cx = cell - cy * Wc;
+    if (cell0 >= ncell) return;
+    float v[PXW], d[PXW];
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        const float* s = semi + ((size_t)b * ncell + min(cell0 + i, ncell - 1)) * 65;
+        v[i] = s[lane]; d[i] = s[64];
+    }
     const int W = Wc * 8;
-    heat[(size_t)b * Hc * 8 * W + (size_t)(cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)] = __fdiv_rn(e, sum);
+#pragma unroll
+    for (int i = 0; i < PXW; ++i) {
+        const int cell = cell0 + i;
+        float m = kpb_wave_fmax(v[i]);
+        m = fmaxf(m, d[i]);
+        const float e = expf(v[i] - m), ed = expf(d[i] - m);
+        float sum = kpb_wave_sum(e);
+        sum += ed;
+        const int cy = cell / Wc, cx = cell - cy * Wc;
+        if (cell < ncell) heat[(size_t)b * Hc * 8 * W + (size_t)(cy * 8 + (lane >> 3)) * W + cx * 8 + (lane & 7)] = __fdiv_rn(e, sum);
+    }
 }
 
-// SuperPoint.py:61-62: desc / ||desc||_2 over the C channels of each pixel (no epsilon).  One wave per pixel.
+// SuperPoint.py:61-62: desc / ||desc||_2 over the C channels of each pixel (no epsilon).  One wave per pixel, PXW pixels per wave
+// when C = 64 (XFeat: one value per lane; see softmax65_d2s).
 __global__ __launch_bounds__(256) void l2norm_nhwc(float* desc, int C, size_t npix, float eps_clamp)
 {
     const int lane = threadIdx.x & 63;
+    if (C == 64) {
+        const size_t pix0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * PXW;
+        if (pix0 >= npix) return;
+        float x[PXW];
+#pragma unroll
+        for (int i = 0; i < PXW; ++i) x[i] = desc[min(pix0 + i, npix - 1) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < PXW; ++i) {
+            float ss = fmaf(x[i], x[i], 0.0f);
+            ss = kpb_wave_sum(ss);
+            float n = sqrtf(ss);
+            if (eps_clamp > 0.0f) n = fmaxf(n, eps_clamp);
+            if (pix0 + i < npix) desc[(pix0 + i) * 64 + lane] = __fdiv_rn(x[i], n);
+        }
+        return;
+    }
     const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= npix) return;
     float* d = desc + pix * C;
@@ -462,7 +488,7 @@ struct SuperPointNet : kpb_net {
         if ((rc = launch_mfma(ctx, "sp_convDa", this, L["convDa"], x4b, cda, batch, Hc, Wc, false, false, true))) return rc;    // :59
         if ((rc = launch_mfma(ctx, "sp_convDb", this, L["convDb"], cda, desc_out, batch, Hc, Wc, false, false, false))) return rc; // :60
         KPB_LAUNCH(ctx, "sp_l2norm", l2norm_nhwc, dim3((unsigned)((B * Hc * Wc + 3) / 4)), dim3(256), 0, st, desc_out, 256, B * Hc * Wc, 0.0f);
-        KPB_LAUNCH(ctx, "sp_softmax_d2s", softmax65_d2s, dim3(cdiv(Hc * Wc, 4), batch), dim3(256), 0, st, semi, score_out, Hc, Wc, Hc * Wc);
+        KPB_LAUNCH(ctx, "sp_softmax_d2s", softmax65_d2s, dim3(cdiv(Hc * Wc, 4 * PXW), batch), dim3(256), 0, st, semi, score_out, Hc, Wc, Hc * Wc);
         KPB_HIP(ctx, hipGetLastError());
         return KPB_OK;
     }
@@ -575,14 +601,14 @@ struct XFeatNet : kpb_net {
         if ((rc = conv("block_fusion.0", u8[3], u8[4], batch, H8, W8))) return rc;
         if ((rc = conv("block_fusion.1", u8[4], u8[5], batch, H8, W8))) return rc;
         if ((rc = conv("block_fusion.2", u8[5], desc_out, batch, H8, W8))) return rc;
-        KPB_LAUNCH(ctx, "xf_l2norm", l2norm_nhwc, dim3((unsigned)((B * H8 * W8 + 3) / 4)), dim3(256), 0, st, desc_out, 64, B * H8 * W8, 1e-12f);   // F.normalize
+        KPB_LAUNCH(ctx, "xf_l2norm", l2norm_nhwc, dim3((unsigned)((B * H8 * W8 + 4 * PXW - 1) / (4 * PXW))), dim3(256), 0, st, desc_out, 64, B * H8 * W8, 1e-12f);   // F.normalize
         // keypoint head on the 8x8-unfolded normalised image (XFeat.py:138-139)
         KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 64, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
         if ((rc = conv("keypoint_head.0", u8[0], u8[1], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.1", u8[1], u8[0], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.2", u8[0], u8[1], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.3", u8[1], semi, batch, H8, W8))) return rc;
-        KPB_LAUNCH(ctx, "xf_softmax_d2s", softmax65_d2s, dim3(cdiv(H8 * W8, 4), batch), dim3(256), 0, st, semi, score_out, H8, W8, H8 * W8);
+        KPB_LAUNCH(ctx, "xf_softmax_d2s", softmax65_d2s, dim3(cdiv(H8 * W8, 4 * PXW), batch), dim3(256), 0, st, semi, score_out, H8, W8, H8 * W8);
         KPB_HIP(ctx, hipGetLastError());
         return KPB_OK;
     }
