@@ -268,13 +268,17 @@ __global__ __launch_bounds__(256) void gray_mean_stats(const float* img, float* 
     }
 }
 
-__global__ void instnorm_apply(float* gray, const double* stats, size_t P)
+__global__ void instnorm_apply(float* gray, const double* stats, size_t P)       // four pixels per thread (P is a multiple of 1024: H and W are multiples of 32)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4, b = blockIdx.y;
     if (i >= P) return;
     const double mean = stats[2 * b] / (double)P;
     const double var = fmax(stats[2 * b + 1] / (double)P - mean * mean, 0.0);
-    gray[b * P + i] = (gray[b * P + i] - (float)mean) * (1.0f / sqrtf((float)var + 1e-5f));
+    const float m = (float)mean, r = 1.0f / sqrtf((float)var + 1e-5f);
+    float4* g = reinterpret_cast<float4*>(gray + b * P + i);
+    float4 v = *g;
+    v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+    *g = v;
 }
 
 // XFeat.py:133-135: x3 + interpolate(x4, size(x3), bilinear) + interpolate(x5, ...) (align_corners=False), 64 channels
@@ -307,14 +311,15 @@ __global__ void pyramid_sum(const float* x3, const float* x4, const float* x5, f
 }
 
 // XFeat.py:96-103 _unfold2d(x, ws=8): [B,1,H,W] -> [B,64,H/8,W/8], channel = wy*8 + wx (stored NHWC)
-__global__ void unfold8(const float* gray, float* out, int H, int W)
+__global__ void unfold8(const float* gray, float* out, int H, int W)       // four channels = four adjacent pixels of a cell row per thread
 {
     const int Wc = W / 8, Hc = H / 8;
-    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4, b = blockIdx.y;
     if (i >= Hc * Wc * 64) return;
     const int cell = i >> 6, c = i & 63;
     const int cy = cell / Wc, cx = cell - cy * Wc;
-    out[((size_t)b * Hc * Wc + cell) * 64 + c] = gray[(size_t)b * H * W + (size_t)(cy * 8 + (c >> 3)) * W + cx * 8 + (c & 7)];
+    *reinterpret_cast<float4*>(out + ((size_t)b * Hc * Wc + cell) * 64 + c) =
+        *reinterpret_cast<const float4*>(gray + (size_t)b * H * W + (size_t)(cy * 8 + (c >> 3)) * W + cx * 8 + (c & 7));
 }
 
 // ------------------------------------------------------------------------------------------------ host helpers
@@ -569,7 +574,7 @@ struct XFeatNet : kpb_net {
         hipStream_t st = ctx->stream;
         KPB_HIP(ctx, hipMemsetAsync(stats, 0, 2 * B * sizeof(double), st));
         KPB_LAUNCH(ctx, "xf_gray_stats", gray_mean_stats, dim3(64, batch), dim3(256), 0, st, img, gray, stats, P);
-        KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
+        KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P / 4 + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
         int rc;
         // block1 (XFeat.py:30-35) and the skip connection (27-28, 127)
         if ((rc = conv("block1.0", gray, a1, batch, H, W))) return rc;
@@ -603,7 +608,7 @@ struct XFeatNet : kpb_net {
         if ((rc = conv("block_fusion.2", u8[5], desc_out, batch, H8, W8))) return rc;
         KPB_LAUNCH(ctx, "xf_l2norm", l2norm_nhwc, dim3((unsigned)((B * H8 * W8 + 4 * PXW - 1) / (4 * PXW))), dim3(256), 0, st, desc_out, 64, B * H8 * W8, 1e-12f);   // F.normalize
         // keypoint head on the 8x8-unfolded normalised image (XFeat.py:138-139)
-        KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 64, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
+        KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 16, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
         if ((rc = conv("keypoint_head.0", u8[0], u8[1], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.1", u8[1], u8[0], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.2", u8[0], u8[1], batch, H8, W8))) return rc;
