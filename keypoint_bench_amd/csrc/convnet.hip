@@ -740,19 +740,31 @@ __global__ void make_xf(const double* sums, const float* slope, float* xf, size_
 }
 
 // disk.py:311-312: desc = F.normalize(feature[:, :128], dim=1), score = sigmoid(feature[:, 128]); feature is [.., 129]
-__global__ __launch_bounds__(256) void disk_head(const float* feat, float* desc, float* score, size_t npix)
+__global__ __launch_bounds__(256) void disk_head(const float* __restrict__ feat, float* __restrict__ desc, float* __restrict__ score, size_t npix)
 {
+    // one wave per pixel, DHW pixels per wave with their loads in flight together (see softmax65_d2s); per pixel unchanged
+    constexpr int DHW = 4;
     const int lane = threadIdx.x & 63;
-    const size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= npix) return;
-    const float* f = feat + pix * 129;
-    const float a = f[lane], b = f[lane + 64];
-    float ss = fmaf(a, a, b * b);
-    ss = kpb_wave_sum(ss);
-    const float n = fmaxf(sqrtf(ss), 1e-12f);
-    desc[pix * 128 + lane] = __fdiv_rn(a, n);
-    desc[pix * 128 + lane + 64] = __fdiv_rn(b, n);
-    if (lane == 0) score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-f[128]));
+    const size_t pix0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * DHW;
+    if (pix0 >= npix) return;
+    float a[DHW], b[DHW], sl[DHW];
+#pragma unroll
+    for (int i = 0; i < DHW; ++i) {
+        const float* f = feat + min(pix0 + i, npix - 1) * 129;
+        a[i] = f[lane]; b[i] = f[lane + 64]; sl[i] = f[128];
+    }
+#pragma unroll
+    for (int i = 0; i < DHW; ++i) {
+        const size_t pix = pix0 + i;
+        float ss = fmaf(a[i], a[i], b[i] * b[i]);
+        ss = kpb_wave_sum(ss);
+        const float n = fmaxf(sqrtf(ss), 1e-12f);
+        if (pix < npix) {
+            desc[pix * 128 + lane] = __fdiv_rn(a[i], n);
+            desc[pix * 128 + lane + 64] = __fdiv_rn(b[i], n);
+            if (lane == 0) score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sl[i]));
+        }
+    }
 }
 
 struct DiskNet : kpb_net {
@@ -828,7 +840,7 @@ struct DiskNet : kpb_net {
         upcat(u2, f1, c3, H / 2, W / 2, 64, 16);
         if ((rc = stats_xf(c3, P, 80, "up3.slope", sums, xf, batch))) return rc;
         if ((rc = launch_mfma(ctx, "disk_up3", this, L["up3"], c3, lg, batch, H, W, false, false, false, xf))) return rc;
-        KPB_LAUNCH(ctx, "disk_head", disk_head, dim3((unsigned)((B * P + 3) / 4)), dim3(256), 0, st, lg, desc_out, score_out, B * P);
+        KPB_LAUNCH(ctx, "disk_head", disk_head, dim3((unsigned)((B * P + 15) / 16)), dim3(256), 0, st, lg, desc_out, score_out, B * P);
         KPB_HIP(ctx, hipGetLastError());
         return KPB_OK;
     }
