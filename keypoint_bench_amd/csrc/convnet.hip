@@ -715,7 +715,16 @@ __global__ void chan_sums(const float* in, double* sums, size_t P, int C)
     const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
     const size_t b = blockIdx.y;
     double s = 0.0, q = 0.0;
-    for (size_t pix = (size_t)blockIdx.x * R + r; pix < P; pix += (size_t)gridDim.x * R) {
+    const size_t step = (size_t)gridDim.x * R;
+    size_t pix = (size_t)blockIdx.x * R + r;
+    for (; pix + 3 * step < P; pix += 4 * step) {        // four loads in flight, accumulated in the order of the plain loop
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = in[(b * P + pix + k * step) * C + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s += (double)v[k]; q += (double)v[k] * (double)v[k]; }
+    }
+    for (; pix < P; pix += step) {
         const float v = in[(b * P + pix) * C + c];
         s += (double)v; q += (double)v * (double)v;
     }
