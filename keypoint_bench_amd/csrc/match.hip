@@ -18,32 +18,49 @@ struct SampleArgs {
     long long sb, sc, sh, sw;
 };
 
+constexpr int SAMPLE_KPW = 4;       // keypoints per wave: their sixteen taps per channel are requested together (one keypoint per wave left 1 KB in flight per wave)
 __global__ __launch_bounds__(256) void sample_bilinear(SampleArgs a)
 {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SAMPLE_KPW;
     const int n = a.n ? min(a.n[b], a.max_n) : a.max_n;
-    if (i >= n) return;
-    const float* p = a.pts + ((size_t)b * a.max_n + i) * a.pts_cols;
-    // matcher.py:221-222 then ATen's align_corners=True un-normalisation (g + 1) * ((size - 1) / 2)
-    const float gx = (p[0] - 0.5f) * 2.0f, gy = (p[1] - 0.5f) * 2.0f;
-    const float x = (gx + 1.0f) * ((float)(a.Wd - 1) / 2.0f), y = (gy + 1.0f) * ((float)(a.Hd - 1) / 2.0f);
-    const float xw = floorf(x), yn = floorf(y);
-    const float w = x - xw, e = 1.0f - w, nn = y - yn, s = 1.0f - nn;
-    const float c_nw = s * e, c_ne = s * w, c_sw = nn * e, c_se = nn * w;
-    const long long x0 = (long long)xw, y0 = (long long)yn, x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = x0 >= 0 && x0 < a.Wd, vx1 = x1 >= 0 && x1 < a.Wd;
-    const bool vy0 = y0 >= 0 && y0 < a.Hd, vy1 = y1 >= 0 && y1 < a.Hd;
+    if (i0 >= n) return;
+    float cf[SAMPLE_KPW][4];
+    long long off[SAMPLE_KPW][4];
+    bool ok[SAMPLE_KPW][4];
+#pragma unroll
+    for (int k = 0; k < SAMPLE_KPW; ++k) {
+        const int i = min(i0 + k, n - 1);
+        const float* p = a.pts + ((size_t)b * a.max_n + i) * a.pts_cols;
+        // matcher.py:221-222 then ATen's align_corners=True un-normalisation (g + 1) * ((size - 1) / 2)
+        const float gx = (p[0] - 0.5f) * 2.0f, gy = (p[1] - 0.5f) * 2.0f;
+        const float x = (gx + 1.0f) * ((float)(a.Wd - 1) / 2.0f), y = (gy + 1.0f) * ((float)(a.Hd - 1) / 2.0f);
+        const float xw = floorf(x), yn = floorf(y);
+        const float w = x - xw, e = 1.0f - w, nn = y - yn, s = 1.0f - nn;
+        cf[k][0] = s * e; cf[k][1] = s * w; cf[k][2] = nn * e; cf[k][3] = nn * w;
+        const long long x0 = (long long)xw, y0 = (long long)yn, x1 = x0 + 1, y1 = y0 + 1;
+        const bool vx0 = x0 >= 0 && x0 < a.Wd, vx1 = x1 >= 0 && x1 < a.Wd;
+        const bool vy0 = y0 >= 0 && y0 < a.Hd, vy1 = y1 >= 0 && y1 < a.Hd;
+        ok[k][0] = vx0 && vy0; ok[k][1] = vx1 && vy0; ok[k][2] = vx0 && vy1; ok[k][3] = vx1 && vy1;
+        off[k][0] = ok[k][0] ? y0 * a.sh + x0 * a.sw : 0; off[k][1] = ok[k][1] ? y0 * a.sh + x1 * a.sw : 0;
+        off[k][2] = ok[k][2] ? y1 * a.sh + x0 * a.sw : 0; off[k][3] = ok[k][3] ? y1 * a.sh + x1 * a.sw : 0;
+    }
     const float* base = a.desc + (size_t)b * a.sb;
-    float* o = a.out + ((size_t)b * a.max_n + i) * a.C;
     for (int ch = lane; ch < a.C; ch += 64) {
         const float* q = base + (size_t)ch * a.sc;
-        const float nw = (vx0 && vy0) ? q[y0 * a.sh + x0 * a.sw] : 0.0f;   // zero padding
-        const float ne = (vx1 && vy0) ? q[y0 * a.sh + x1 * a.sw] : 0.0f;
-        const float sw = (vx0 && vy1) ? q[y1 * a.sh + x0 * a.sw] : 0.0f;
-        const float se = (vx1 && vy1) ? q[y1 * a.sh + x1 * a.sw] : 0.0f;
-        o[ch] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(nw, c_nw), __fmul_rn(ne, c_ne)), __fmul_rn(sw, c_sw)),
-                          __fmul_rn(se, c_se));
+        float t[SAMPLE_KPW][4];
+#pragma unroll
+        for (int k = 0; k < SAMPLE_KPW; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[k][c] = q[off[k][c]];
+#pragma unroll
+        for (int k = 0; k < SAMPLE_KPW; ++k) {
+            const float nw = ok[k][0] ? t[k][0] : 0.0f, ne = ok[k][1] ? t[k][1] : 0.0f;      // zero padding
+            const float sw = ok[k][2] ? t[k][2] : 0.0f, se = ok[k][3] ? t[k][3] : 0.0f;
+            if (i0 + k < n)
+                a.out[((size_t)b * a.max_n + i0 + k) * a.C + ch] =
+                    __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(nw, cf[k][0]), __fmul_rn(ne, cf[k][1])), __fmul_rn(sw, cf[k][2])), __fmul_rn(se, cf[k][3]));
+        }
     }
 }
 
@@ -551,7 +568,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_sample(kpb_ctx* ctx, c
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_sample: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     SampleArgs a{desc_dev, pts_dev, n_dev, out_dev, C, Hd, Wd, pts_cols, max_n, sb, sc, sh, sw};
-    KPB_LAUNCH(ctx, "sample_bilinear", sample_bilinear, dim3(cdiv(max_n, 4), batch), dim3(256), 0, ctx->stream, a);
+    KPB_LAUNCH(ctx, "sample_bilinear", sample_bilinear, dim3(cdiv(max_n, 4 * SAMPLE_KPW), batch), dim3(256), 0, ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
