@@ -616,18 +616,33 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     const float scx = cm_scale_of(ex), un_a = a.inv_wsa * cm_unscale_of(ex);
     {   // stage the (TH+4) x (TW+4) tile of p1, split, zero outside the image
         const float* in = a.p1 + (size_t)b * P * 8;
-        for (int i = tid; i < NP * 2; i += 256) {
+        // all of a thread's loads go out before the first is used, to a clamped address without a branch (r03 stamps: as a plain
+        // loop -- load, split, store, next -- the four round trips of this tile were 6.6 k of the workgroup's 23 k cycles)
+        constexpr int PER = (NP * 2 + 255) / 256;
+        float4 ld[PER];
+        unsigned okm = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = min(tid + 256 * k, NP * 2 - 1);
             const int pos = i >> 1, q = i & 1;
             const int y = pos / PW, x = pos - y * PW;
             const int gy = ty0 - 2 + y, gx = tx0 - 2 + x;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.W + gx) * 8 + 4 * q);
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) okm |= 1u << k;
+            ld[k] = *reinterpret_cast<const float4*>(in + ((size_t)min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1)) * 8 + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + 256 * k;
+            const int pos = i >> 1, q = i & 1;
+            float4 v = ((okm >> k) & 1u) ? ld[k] : make_float4(0.f, 0.f, 0.f, 0.f);
             v.x *= sc1; v.y *= sc1; v.z *= sc1; v.w *= sc1;
             uint2 hi, lo;
             split4(v, hi, lo);
-            uint2* d = reinterpret_cast<uint2*>(&pin[pos]) + q;
-            d[0] = hi;
-            d[2 * NP] = lo;
+            if (i < NP * 2) {
+                uint2* d = reinterpret_cast<uint2*>(&pin[pos]) + q;
+                d[0] = hi;
+                d[2 * NP] = lo;
+            }
         }
         if (tid == 0) zslot = make_uint4(0u, 0u, 0u, 0u);
     }
