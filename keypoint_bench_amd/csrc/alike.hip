@@ -259,6 +259,9 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         bhi[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 0) * 64 + lane]);
         blo[kb] = __builtin_bit_cast(h8v, ha.w2pk[(kb * 2 + 1) * 64 + lane]);
     }
+    // the lane's biases are requested with the weights: read where they are used, each was an exposed round trip behind a barrier
+    const float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + 4 * ((lane >> 4) & 1));
+    const float4 bias2 = *reinterpret_cast<const float4*>(a.b2 + 4 * ((lane >> 4) & 1));
     __shared__ __attribute__((aligned(16))) float s_amax[4];
     int e_img;      // exponent of this tile's largest |pixel|: the image is split at the scale that fits THIS tile (cm_scale_of)
     {   // stage the (TH+4) x 36 image tile split, three channels per position; all loads of a thread in flight first
@@ -298,7 +301,6 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
     const int sN = g >> 1, c0 = 4 * (g & 1);                          // ... and what its accumulator holds: pixel sN of the pair, channels c0 .. c0 + 3
     {   // conv1 + ReLU on the MH x MW halo'd positions, 16 pairs per MFMA group: group gi < MH = pairs 0..15 of row gi; the 17th
         // pair of every row goes to two extra groups (rows 0..15 and 16..17)
-        const float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + c0);
         const uint4* inq = reinterpret_cast<const uint4*>(inh);       // a piece = two adjacent positions = 16 bytes (even column)
         uint2* midh = reinterpret_cast<uint2*>(mid);
 #pragma unroll 1
@@ -335,7 +337,6 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
     // conv2 + ReLU: a wave owns TH/4 rows of the tile, one 32-pixel row = 16 pairs per MFMA group
     // piece (ky = kb, kx = g) of pair pr: tile column 2 pr + g of row + kb -> parity g & 1, slot pr + (g >> 1)
     const int abase = (g & 1) * PLANE + pr + (g >> 1);
-    const float4 bias2 = *reinterpret_cast<const float4*>(a.b2 + c0);
     const int H2 = a.H / 2, W2 = a.W / 2;
     float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
     float xmax = 0.0f;                  // this lane's largest x1 value (x1 >= 0)
@@ -605,6 +606,9 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
 #pragma unroll
     for (int kb = 0; kb < 5; ++kb) { w2h[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2) * 64 + lane]); w2l[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2 + 1) * 64 + lane]); }
     const h8v wah = __builtin_bit_cast(h8v, a.wapk[lane]), wal = __builtin_bit_cast(h8v, a.wapk[64 + lane]);
+    // the lane's biases and score weights are requested with the fragments (read where they are used, each was an exposed round trip)
+    const float4 b1v = *reinterpret_cast<const float4*>(a.b1 + 4 * (lane >> 4));
+    const float4 bsum = *reinterpret_cast<const float4*>(a.bsum + 4 * (lane >> 4)), wsg = *reinterpret_cast<const float4*>(a.wsg + 4 * (lane >> 4));
     // One activation scale for the block input AND conv1's output (conv2 accumulates pieces of both: the identity branch reads
     // the input tile): that of the larger of amax(p1) and conv1's bound.  x2 gets its own (agg2 is a separate product).
     const float am_p = __uint_as_float(a.amax_x1[b]);
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     const uint4* zp = &zslot;
     {   // conv1 + ReLU -> mid (split).  Groups gi < 2 MH = (row gi / 2, columns 16 (gi & 1) .. + 15); the two rightmost columns of
         // all rows go to two extra groups: slot k of extra group e is position ((16 e + k) / 2, 32 + (k & 1))
-        float4 bias1 = *reinterpret_cast<const float4*>(a.b1 + 4 * g);
+        float4 bias1 = b1v;
         bias1.x *= sc1; bias1.y *= sc1; bias1.z *= sc1; bias1.w *= sc1;       // conv1's output is split at the scale of its input: the scale rides on the bias
         uint2* midh = reinterpret_cast<uint2*>(mid);
         // fixed trip count (the last round is empty for waves 2 and 3) so that two groups can be in flight per wave
@@ -692,7 +696,6 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     // conv2 + identity branch + ReLU -> x2; agg2 + ReLU -> a2, S2.  16 groups of 16 pixels per tile, four per wave: a wave owns
     // four rows of one 16-column half, so the 4 x 4 max-pool block 3 starts with is a running maximum over its four groups and
     // two lane exchanges, and only the pooled map (a sixteenth of x2) goes to HBM.
-    const float4 bsum = *reinterpret_cast<const float4*>(a.bsum + 4 * g), wsg = *reinterpret_cast<const float4*>(a.wsg + 4 * g);
     float* x2 = a.x2 + (size_t)b * P * 16;
     float* a2 = a.a2 + (size_t)b * P * 16;
     float* S2 = a.S2 + (size_t)b * P;
