@@ -153,12 +153,14 @@ __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out,
     const float* g = gray + (size_t)b * H * W;
     const int y0 = blockIdx.y * rows_per_block, y1 = min(y0 + rows_per_block, H);
     auto ld = [&](int yy, int xx) { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? g[(size_t)yy * W + xx] : 0.0f; };
-    float r0[3], r1[3], r2[3];
+    // the row below is requested one iteration before it is used (requested and used in the same iteration, every row of the column
+    // walk waited for its own L2 round trip)
+    float r0[3], r1[3], r2[3], r3[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { r0[k] = ld(y0 - 1, x - 1 + k); r1[k] = ld(y0, x - 1 + k); }
+    for (int k = 0; k < 3; ++k) { r0[k] = ld(y0 - 1, x - 1 + k); r1[k] = ld(y0, x - 1 + k); r2[k] = ld(y0 + 1, x - 1 + k); }
     for (int y = y0; y < y1; ++y) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) r2[k] = ld(y + 1, x - 1 + k);
+        for (int k = 0; k < 3; ++k) r3[k] = ld(y + 2, x - 1 + k);
         float acc[4] = {bv[0], bv[1], bv[2], bv[3]};
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out,
             }
         *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * 64 + c4) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; }
+        for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; r2[k] = r3[k]; }
     }
 }
 
@@ -253,7 +255,22 @@ __global__ __launch_bounds__(256) void gray_mean_stats(const float* img, float* 
     __shared__ double s1[4], s2[4];
     const size_t b = blockIdx.y;
     double a = 0.0, q = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < P; i += (size_t)gridDim.x * 256) {
+    const size_t step = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < P; i += 4 * step) {          // twelve loads in flight per thread, accumulated in the order of the plain loop
+        float c[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) c[k][ch] = img[(b * 3 + ch) * P + i + k * step];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g = ((c[k][0] + c[k][1]) + c[k][2]) / 3.0f;
+            gray[b * P + i + k * step] = g;
+            a += (double)g; q += (double)g * (double)g;
+        }
+    }
+    for (; i < P; i += step) {
         const float g = ((img[(b * 3 + 0) * P + i] + img[(b * 3 + 1) * P + i]) + img[(b * 3 + 2) * P + i]) / 3.0f;
         gray[b * P + i] = g;
         a += (double)g; q += (double)g * (double)g;
