@@ -33,6 +33,8 @@ class ImagePairFiles:
     bytes, plus whatever else an item carries (warp01_params / warp10_params / dataset ...), passed through untouched.
     Items come back with the two images decoded to uint8 [H, W, 3]."""
 
+    thread_safe = True          # __getitem__ touches no shared state: Prefetcher may call it from several threads at once
+
     def __init__(self, records, root=None):
         self.records, self.root = list(records), root
 
@@ -56,15 +58,27 @@ class ImagePairFiles:
 class Prefetcher:
     """Iterates (index, dataset[index]) over `indices` in order, with up to `depth` items being fetched concurrently on
     `workers` threads.  An exception raised by dataset[index] is re-raised at that index's turn; close() (or exhausting /
-    abandoning the iterator inside a `with`) stops the pool."""
+    abandoning the iterator inside a `with`) stops the pool.
+
+    How many threads call `dataset.__getitem__` at once is the DATASET's decision, not the runner's: only a dataset that
+    declares `thread_safe = True` (ImagePairFiles does) gets the default pool of up to 16; any other dataset -- shared h5py or
+    video handles, stateful sequence readers, the global np.random of datasets/megadepth.py:195 -- is read by ONE thread, in
+    order, as a DataLoader worker would read its shard.  workers=0 means inline: no thread at all, dataset[i] runs on the
+    caller's thread when the iterator reaches i.  An explicit workers > 1 is the caller's promise that the dataset allows it."""
 
     def __init__(self, dataset, indices, workers=None, depth=None):
         self.dataset, self.indices = dataset, list(indices)
-        self.workers = workers or max(1, min(16, len(os.sched_getaffinity(0))))
-        self.depth = depth or 2 * self.workers
-        self.pool = ThreadPoolExecutor(max_workers=self.workers)
+        if workers is None:
+            workers = max(1, min(16, len(os.sched_getaffinity(0)))) if getattr(dataset, "thread_safe", False) else 1
+        self.workers = int(workers)
+        self.depth = depth if depth is not None else 2 * max(1, self.workers)
+        self.pool = ThreadPoolExecutor(max_workers=self.workers) if self.workers > 0 else None
 
     def __iter__(self):
+        if self.pool is None or self.depth <= 0:
+            for i in self.indices:
+                yield i, self.dataset[i]
+            return
         pending = []
         it = iter(self.indices)
         try:
@@ -81,7 +95,8 @@ class Prefetcher:
                 f.cancel()
 
     def close(self):
-        self.pool.shutdown(wait=True, cancel_futures=True)
+        if self.pool is not None:
+            self.pool.shutdown(wait=True, cancel_futures=True)
 
     def __enter__(self):
         return self

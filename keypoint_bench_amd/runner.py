@@ -243,12 +243,15 @@ class HostStager:
 
     def release(self):
         """Gives back the oldest slot still out (slots are consumed in the order they were filled).  Never blocks: a release
-        with no slot out is a caller's accounting error and is ignored rather than turned into a hang."""
+        with no slot out is a caller's accounting error -- it is reported (a warning, and `unmatched_releases` counts it for the
+        tests) rather than turned into a hang or silently dropped."""
         import queue
         try:
             self.free.put(self.order.get_nowait())
         except queue.Empty:
-            pass
+            import warnings
+            self.unmatched_releases = getattr(self, "unmatched_releases", 0) + 1
+            warnings.warn("HostStager.release() with no slot out: slot accounting error in the caller", RuntimeWarning, stacklevel=2)
 
     def fill(self, pinned, arrays):
         """pinned[j] <- arrays[j] for every j, in parallel."""
@@ -383,7 +386,7 @@ class PairRunner:
         self.batched_pairs = 0
         self.staged_batches = 0
         self._stager = None
-        self.decode_workers = None          # threads that run dataset[i] ahead of the staging thread (None: one per host core, at most 16)
+        self.decode_workers = None          # threads that run dataset[i] ahead of the staging thread: None = the dataset decides (`thread_safe = True`: one per host core, at most 16; otherwise ONE, in order); 0 = inline; n > 1 = the caller's promise
 
     # ---- single pair (model_interface.py:189-212 + the task call)
     def test_step(self, batch, idx):
@@ -571,7 +574,8 @@ class PairRunner:
             return tuple(a.shape[:2]) if is_decoded_u8(a) else tuple(a.shape[-2:])
 
         from .datasets import Prefetcher
-        fetched = Prefetcher(dataset, indices, workers=self.decode_workers)
+        fetched = None              # created inside the try below, so that close() runs whatever fails in between
+        stop = threading.Event()    # set when the consumer fails: the producer stops at its next item instead of staging the rest
 
         def produce():
             try:
@@ -589,6 +593,8 @@ class PairRunner:
                     group = []
 
                 for i, item in fetched:       # dataset[i], decoded / read a few items ahead on a thread pool (datasets.Prefetcher)
+                    if stop.is_set():
+                        return
                     a, b = _host_array(item["image0"]), _host_array(item["image1"])
                     single = a is None or b is None or (task_type not in ("AUC", "FundamentalMatrixRansac") and not _homo_only(item))
                     if not single:
@@ -612,7 +618,7 @@ class PairRunner:
                 q.put(("error", e, None))
 
         out = {}
-        copy_stream = torch.cuda.Stream(self.device)
+        copy_stream = None
         pending = None          # (group, device tensor, copy-done event): its PCIe copy runs under the previous group's kernels
         held = []               # copies whose pinned slot has not been given back yet (slot ownership, explicit)
 
@@ -647,9 +653,12 @@ class PairRunner:
                 for (i, _, _, _), r in zip(group, res):
                     out[i] = r
 
-        th = threading.Thread(target=produce, daemon=True)
-        th.start()
+        th = None
         try:
+            copy_stream = torch.cuda.Stream(self.device)
+            fetched = Prefetcher(dataset, indices, workers=self.decode_workers)
+            th = threading.Thread(target=produce, daemon=True)
+            th.start()
             while True:
                 kind, x, y = q.get()
                 if kind == "error":
@@ -671,15 +680,24 @@ class PairRunner:
                     pass
                 st.release()
             held.clear()
-            while th.is_alive():                # drain so that the producer can finish if the consumer failed
+            stop.set()
+
+            def drain():
                 try:
-                    kind, x, y = q.get(timeout=0.1)
-                    if kind == "batch":
-                        st.release()
+                    while True:
+                        kind, x, y = q.get_nowait() if th is None or not th.is_alive() else q.get(timeout=0.1)
+                        if kind == "batch":     # staged but never copied: its pinned slot goes back to the ring
+                            st.release()
                 except queue.Empty:
                     pass
-            th.join()
-            fetched.close()
+
+            while th is not None and th.is_alive():         # drain so that the producer can finish if the consumer failed
+                drain()
+            if th is not None:
+                th.join()
+            drain()                             # the producer's LAST item may still sit in q (maxsize 1) after it has exited
+            if fetched is not None:
+                fetched.close()
         return [out[i] for i in indices]
 
     # ---- batched sequence (BASELINE configs[3]: brute-force branch)

@@ -4,8 +4,10 @@ fp32 CPU chain (oracle/: torch-fp32 ALIKE-t restatement + C detection / sampling
 The stages are bit-exact on equal inputs; the net's score map differs from the CPU's by ~1e-6, which can flip an NMS decision
 between near-equal neighbours.  Prints, over `pairs` synthetic 640x480 pairs: max score / descriptor differences, the
 number of images whose keypoint index sets are identical, and the number of pairs whose match sets are identical.
-    python scripts/parity_sweep.py [pairs] [out.json]     (GPU box; the oracle is the checker, never the product)
-tests/test_gpu_parity_sweep.py runs `sweep(8)` as a test."""
+    python scripts/parity_sweep.py [pairs] [out.json] [--also-fp32]    (GPU box; the oracle is the checker, never the product)
+--also-fp32 repeats the sweep in a child process with KPB_FP32_MATRIX=1 (the strict-fp32 kernels; the library reads the knob once
+per process) and records its figures under "strict_fp32": how much of the score difference is the split-f16 products and how
+much is summation order.  tests/test_gpu_parity_sweep.py runs `sweep(8)` as a test."""
 import os
 import sys
 import time
@@ -82,6 +84,7 @@ def sweep(n, first=0, workers=None):
         diffm += len(got_m ^ want_m)
         nm += len(ref[i][1])
     return {"pairs": n, "first_pair_seed": first, "images": 2 * n, "size": "640x480", "extractor": EP, "matcher": BF,
+            "arithmetic": "strict fp32 (KPB_FP32_MATRIX=1)" if os.environ.get("KPB_FP32_MATRIX", "0") not in ("", "0") else "split-f16 MFMA triples",
             "max_abs_score_diff": ds, "max_abs_descriptor_diff": dd,
             "images_with_identical_keypoint_sets": int(same_kps), "images_in_identical_row_order": int(same_order),
             "keypoints": int(nk), "keypoints_differing": int(diffk // 2),
@@ -91,11 +94,21 @@ def sweep(n, first=0, workers=None):
 
 def main():
     import json
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    import subprocess
+    import tempfile
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(argv[0]) if argv else 32
     r = sweep(n)
+    if "--also-fp32" in sys.argv:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, "fp32.json")
+            subprocess.run([sys.executable, os.path.abspath(__file__), str(n), out], env=dict(os.environ, KPB_FP32_MATRIX="1"), check=True,
+                           stdout=subprocess.DEVNULL)
+            with open(out) as f:
+                r["strict_fp32"] = {k: v for k, v in json.load(f).items() if k not in ("extractor", "matcher", "size")}
     print(json.dumps(r))
-    if len(sys.argv) > 2:
-        with open(sys.argv[2], "w") as f:
+    if len(argv) > 1:
+        with open(argv[1], "w") as f:
             json.dump(r, f, indent=1)
 
 

@@ -1,6 +1,7 @@
 """SURVEY 8(f)2, decode stage (keypoint_bench_amd/datasets.py): PIL decoding as datasets/megadepth.py:149-152 does it, and the
 order-preserving prefetcher that runs dataset[i] ahead of the staging thread."""
 import io
+import os
 import threading
 import time
 
@@ -107,3 +108,52 @@ def test_prefetcher_with_one_worker_and_an_empty_index_list():
         assert list(pf) == []
     with datasets.Prefetcher([10, 11, 12], [2, 0], workers=1, depth=1) as pf:
         assert list(pf) == [(2, 12), (0, 10)]
+
+
+def test_a_dataset_that_does_not_declare_thread_safety_is_read_by_one_thread_in_order():
+    """shared file handles, stateful readers and the global np.random of datasets/megadepth.py:195 must not
+    be entered from 16 threads at once; the reference's DataLoader workers each read their items one after another."""
+    live, peak, order, tids, lock = [0], [0], [], set(), threading.Lock()
+
+    class Stateful:
+        def __getitem__(self, i):
+            with lock:
+                live[0] += 1
+                peak[0] = max(peak[0], live[0])
+                order.append(i)
+                tids.add(threading.get_ident())
+            time.sleep(0.005)
+            with lock:
+                live[0] -= 1
+            return i
+
+    with datasets.Prefetcher(Stateful(), range(12)) as pf:              # workers=None: the dataset decides
+        assert pf.workers == 1
+        assert [i for i, _ in pf] == list(range(12))
+    assert peak[0] == 1 and order == list(range(12)) and len(tids) == 1 and threading.get_ident() not in tids
+
+    class Safe(Stateful):
+        thread_safe = True
+
+    with datasets.Prefetcher(Safe(), range(4)) as pf:
+        assert pf.workers >= 1 and pf.workers == max(1, min(16, len(os.sched_getaffinity(0))))
+    assert datasets.ImagePairFiles.thread_safe is True
+
+
+def test_zero_workers_means_inline_on_the_callers_thread():
+    tids, calls = set(), []
+
+    class D:
+        def __getitem__(self, i):
+            tids.add(threading.get_ident())
+            calls.append(i)
+            return i * i
+
+    pf = datasets.Prefetcher(D(), [3, 1, 2], workers=0)
+    assert pf.pool is None
+    it = iter(pf)
+    assert calls == []                              # nothing is fetched ahead
+    assert next(it) == (3, 9) and calls == [3]
+    assert list(it) == [(1, 1), (2, 4)]
+    assert tids == {threading.get_ident()}
+    pf.close()

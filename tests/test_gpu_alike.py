@@ -145,8 +145,10 @@ def test_lazy_descriptors_survive_the_reference_call_pattern():
 
 
 def test_end_to_end_pair_against_reference_golden():
-    """image pair -> ALIKE-t -> detection -> brute-force match, against what the reference produced.
-    Keypoints are compared as sets because a score-map ulp can flip a near-tie (SURVEY 'Score-map ulps')."""
+    """image pair -> ALIKE-t -> detection -> brute-force match, against what the reference produced from the same pixels: the SAME
+    1000 + 1000 keypoint pixels and the SAME match pixel pairs (r04: exact; r03 accepted 99 % / 97 %).  Rows are compared as sets: a
+    score-map ulp may permute near-equal rows of the score-descending output (SURVEY 'Top-K ties'); 24 more reference pairs, with
+    viewpoint homographies, are in tests/test_gpu_metric_from_pixels.py."""
     from keypoint_bench_amd.models.ALike import alike_t
     from keypoint_bench_amd.utils.extracter import detection
     from keypoint_bench_amd.utils.matcher import brute_force_matcher
@@ -154,21 +156,16 @@ def test_end_to_end_pair_against_reference_golden():
     v0, v1 = synthetic.image_pair(0)
     p = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
     bf = {"metric": "euclidean", "max_distance": 5, "cross_check": True}
+    xy = lambda k: list(map(tuple, np.round(np.asarray(k)[:, :2] * np.array([640, 480]) - 0.5).astype(int).tolist()))
+    want_pairs = set(zip(xy(g["full.m0"]), xy(g["full.m1"])))
     for dense in (True, False):
         net = alike_t(dense_descriptors=dense).eval()
         s0, d0 = net(torch.from_numpy(v0)[None].to(DEV))
-        k0 = detection(s0, p)
-        if not dense:
-            f0 = d0.sample(k0)
         s1, d1 = net(torch.from_numpy(v1)[None].to(DEV))
-        k1 = detection(s1, p)
-        xy = lambda k: set(map(tuple, np.round(k[:, :2] * np.array([640, 480]) - 0.5).astype(int).tolist()))
+        k0, k1 = detection(s0, p), detection(s1, p)
         for got, want in ((k0, g["full.kps0"]), (k1, g["full.kps1"])):
-            a, b = xy(got.cpu().numpy()), xy(want)
-            assert len(a & b) >= 0.99 * len(b), "keypoint sets differ: %d common of %d" % (len(a & b), len(b))
-        if dense:
-            m0, m1 = brute_force_matcher(k0, k1, d0, d1, bf)
-            assert abs(m0.shape[0] - g["full.m0"].shape[0]) <= 0.02 * g["full.m0"].shape[0]
-            want_pairs = set(map(tuple, np.round(np.concatenate([g["full.m0"][:, :2], g["full.m1"][:, :2]], 1) * 1e4).astype(int).tolist()))
-            got_pairs = set(map(tuple, np.round(np.concatenate([m0.cpu().numpy()[:, :2], m1.cpu().numpy()[:, :2]], 1) * 1e4).astype(int).tolist()))
-            assert len(want_pairs & got_pairs) >= 0.97 * len(want_pairs)
+            a, b = set(xy(got.cpu().numpy())), set(xy(want))
+            assert a == b, "keypoint sets differ from the reference's: %d of %d" % (len(a ^ b) // 2, len(b))
+        m0, m1 = brute_force_matcher(k0, k1, d0, d1, bf)
+        got_pairs = set(zip(xy(m0.cpu().numpy()), xy(m1.cpu().numpy())))
+        assert got_pairs == want_pairs, "match sets differ from the reference's: %d of %d" % (len(got_pairs ^ want_pairs), len(want_pairs))
