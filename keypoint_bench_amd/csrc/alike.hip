@@ -26,7 +26,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float relu(float v);
 
-// fp32 x 4 -> (hi, lo) half-precision pairs: hi = f16(x) toward zero, lo = f16(x - hi) (x - hi is exact in fp32)
+// fp32 x 4 -> (hi, lo) half-precision pairs: hi = f16(x), lo = f16(x - hi), both to nearest (x - hi is exact in fp32)
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) { cm_split4(v, hi, lo); }
 
 // Largest value of a NON-NEGATIVE tensor, per image, without atomics: every wave of the producing kernel leaves its maximum in a
@@ -385,7 +385,6 @@ std::vector<float> pack_b1c1_pairs(const float* w, float scale)
                 const int ky = piece >> 1, kx = 2 * (piece & 1) + (j >> 2) - s2, c = j & 3;
                 const float v = (piece < 6 && c < 3 && kx >= 0 && kx <= 2) ? w[((size_t)co * 3 + c) * 9 + ky * 3 + kx] * scale : 0.0f;
                 _Float16 hi = (_Float16)v;
-                if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
                 const _Float16 lo = (_Float16)(v - (float)hi);
                 memcpy(&hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j], &hi, 2);
                 memcpy(&hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j], &lo, 2);
@@ -406,7 +405,6 @@ std::vector<float> pack_b1c2_pairs(const float* w, float scale)
                 const int n = l & 15, g = l >> 4, s2 = n >> 3, co = n & 7, kx = g - s2;
                 const float v = (kx >= 0 && kx <= 2) ? w[((size_t)co * 8 + j) * 9 + kb * 3 + kx] * scale : 0.0f;
                 _Float16 hi = (_Float16)v;
-                if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
                 const _Float16 lo = (_Float16)(v - (float)hi);
                 memcpy(&hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j], &hi, 2);
                 memcpy(&hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j], &lo, 2);
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
 //   conv2 (16 -> 16) + the block's 1x1 identity branch (one more K piece, read from the input tile already in LDS) + ReLU -> x2;
 //   agg2 (16 -> 16, no bias) + ReLU on x2 -> a2, and a2 . w_score -> S2 (the group's share of the score logit).
 // All three are implicit GEMMs on v_mfma_f32_16x16x32_f16 with every fp32 operand split into two half-precision terms (x = hi +
-// lo, hi = f16(x) toward zero, lo = f16(x - hi); three MFMAs per product, the lo.lo term dropped: relative 2^-22 per product, fp32
+// lo, hi = f16(x), lo = f16(x - hi), to nearest; three MFMAs per product, the lo.lo term dropped: relative 2^-22 per product, fp32
 // accumulation -- see alike_head_f16):
 //   M = 16 consecutive pixels of an image row, N = the 16 output channels, K = 32 per MFMA = four 16-byte pieces, piece
 //   kidx = (tap, channel octet): lane (row i, group g) of k-block kb supplies piece 4 kb + g.  The input tile sits in LDS
@@ -773,7 +771,6 @@ std::vector<float> pack_1x1_h16(const float* w, float scale)
             const int n = l & 15, g = l >> 4;
             const float v = g < 2 ? w[n * 16 + 8 * g + j] * scale : 0.0f;
             _Float16 hi = (_Float16)v;
-            if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
             const _Float16 lo = (_Float16)(v - (float)hi);
             memcpy(&hl[((size_t)0 * 64 + l) * 8 + j], &hi, 2);
             memcpy(&hl[((size_t)1 * 64 + l) * 8 + j], &lo, 2);
@@ -797,7 +794,6 @@ std::vector<float> pack_h16(const float* w, int CIN, const float* ds_w, float sc
                 else if (ds_w && kidx == 9 * OCT) v = ds_w[n * 8 + j];
                 v *= scale;
                 _Float16 hi = (_Float16)v;
-                if (fabsf((float)hi) > fabsf(v)) { uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2); }     // toward zero
                 const _Float16 lo = (_Float16)(v - (float)hi);
                 memcpy(&hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j], &hi, 2);
                 memcpy(&hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j], &lo, 2);
@@ -1174,7 +1170,7 @@ __global__ __launch_bounds__(256) void alike_head_hyb(HybArgs a)
 // fp32 MFMA on gfx950 runs at the fp32 VECTOR rate and (measured, r02: the kernel takes 10.9 ms with its stores removed)
 // shares the datapath with the VALU work that builds its operands, so the 32-deep fine-group product was the largest
 // single cost of the head.  Here it runs on v_mfma_f32_32x32x16_f16 (16x the fp32 rate per K) with every fp32 operand
-// split into two halves-precision terms, x = hi + lo with hi = f16(x) (round toward zero) and lo = f16(x - hi):
+// split into two halves-precision terms, x = hi + lo with hi = f16(x) and lo = f16(x - hi) (both to nearest):
 //     a b  =  a_hi b_hi + a_hi b_lo + a_lo b_hi  (+ a_lo b_lo, dropped: <= 2^-22 |a b|)
 // Three MFMAs per 16-deep block accumulate in fp32; the dropped term and the rounding of the lo parts are at the level of
 // fp32's own rounding (relative 2^-22 per product against 2^-24), far inside the 1e-4 descriptor contract, and the result
@@ -1831,7 +1827,7 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         transpose(hw, 64, 64, tmp); ws.put("head.wT", tmp);
         ws.put_raw("head.ws", hw + 64 * 64, 64);
         // split-f16 fragments of the fine-group rows (alike_head_f16): [hi/lo][kb][nh][h][n][j] halves,
-        // value = head.w[o = 32 nh + n][c = 16 kb + 8 h + j]; hi = f16(w) toward zero, lo = f16(w - hi)
+        // value = head.w[o = 32 nh + n][c = 16 kb + 8 h + j]; hi = f16(w), lo = f16(w - hi), to nearest
         // (rows 0..63 x channels 0..31: the part this pack carries sets its power-of-two scale)
         float hmax = 0.0f;
         for (int o = 0; o < 64; ++o) for (int cc = 0; cc < 32; ++cc) hmax = std::max(hmax, std::fabs(hw[o * 64 + cc]));
@@ -1840,10 +1836,7 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         std::vector<uint16_t> hl(2 * 2 * 2 * 2 * 32 * 8);
         for (int kb = 0; kb < 2; ++kb) for (int nh = 0; nh < 2; ++nh) for (int hh = 0; hh < 2; ++hh) for (int n = 0; n < 32; ++n) for (int j = 0; j < 8; ++j) {
             const float w = hw[(32 * nh + n) * 64 + 16 * kb + 8 * hh + j] * sh;
-            _Float16 hi = (_Float16)w;
-            if (fabsf((float)hi) > fabsf(w)) {          // the cast rounds to nearest: step back toward zero
-                uint16_t bits; memcpy(&bits, &hi, 2); bits -= 1; memcpy(&hi, &bits, 2);
-            }
+            const _Float16 hi = (_Float16)w;
             const _Float16 lo = (_Float16)(w - (float)hi);
             const size_t at = ((((size_t)kb * 2 + nh) * 2 + hh) * 32 + n) * 8 + j;
             memcpy(&hl[at], &hi, 2);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 }
 
 // ---------------------------------------------------------------------------------------------- split-f16 form
-// The same convolution with every fp32 operand written as hi + lo, hi = f16(x) rounded toward zero and lo = f16(x - hi)
+// The same convolution with every fp32 operand written as hi + lo, hi = f16(x) and lo = f16(x - hi), both to nearest (cm_split2)
 // (x - hi is exact in fp32), and each product taken as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on v_mfma_f32_32x32x16_f16
 // with fp32 accumulation: three f16 MFMAs cover K = 16 in 96 cycles where the fp32 instruction needs 512, and the
 // dropped a_lo*b_lo term is <= 2^-22 of the product.  Both operands are scaled by powers of two first so that the lo
@@ -194,11 +194,22 @@ __device__ __forceinline__ float cm_residual(float x, unsigned packed)
     return r;
 }
 
-// fp32 x 2 -> (hi, lo) half-precision pairs: hi = f16(x) toward zero, lo = f16(x - hi)
+// fp32 x 2 -> (hi, lo) half-precision pairs: hi = f16(x), lo = f16(x - hi), BOTH rounded to nearest (v_cvt_pk_f16_f32, new on
+// gfx950; r02-r03 used v_cvt_pkrtz).  Toward zero leaves |x - hi| < 2^-10 |x| and a lo half that is itself truncated: x is
+// represented to 2^-20 |x| in the worst case, 2^-22 on average -- 21-22 significant bits against fp32's 24.  To nearest halves both
+// steps: |x - hi| <= 2^-11 |x|, |x - hi - lo| <= 2^-22 |x| worst case, the dropped lo.lo term <= 2^-22 of the product.  Measured on
+// 256 full-size pairs (profiles/r04_parity_sweep_256.json): max |score - fp32 CPU chain| 8.0e-6 -> see there; strict fp32 4.6e-6.
+typedef float cm_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cm_cvt_pk_rtn(float x, float y)
+{
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const cm_f2 v = {x, y};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));
+}
 __device__ __forceinline__ void cm_split2(float x, float y, unsigned& hi, unsigned& lo)
 {
-    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x, y));
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(cm_residual<0>(x, hi), cm_residual<1>(y, hi)));
+    hi = cm_cvt_pk_rtn(x, y);
+    lo = cm_cvt_pk_rtn(cm_residual<0>(x, hi), cm_residual<1>(y, hi));
 }
 
 __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
@@ -618,17 +629,12 @@ inline float weight_scale_h(const float* w, size_t n)
     return std::ldexp(1.0f, 13 - e);
 }
 
-inline uint16_t f16_bits_rtz(float x)   // fp32 -> f16 toward zero (normal and subnormal results; |x| < 65520)
+inline uint16_t f16_bits_rtn(float x)   // fp32 -> f16 to nearest even, as the device's v_cvt_pk_f16_f32 (cm_split2)
 {
-    uint32_t u;
-    std::memcpy(&u, &x, 4);
-    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
-    const int e = (int)((u >> 23) & 0xFF) - 127;
-    const uint32_t man = (u & 0x7FFFFFu) | 0x800000u;
-    if (((u >> 23) & 0xFF) == 0 || e < -24) return sign;
-    if (e > 15) return (uint16_t)(sign | 0x7BFFu);
-    if (e >= -14) return (uint16_t)(sign | ((uint32_t)(e + 15) << 10) | ((man >> 13) & 0x3FFu));
-    return (uint16_t)(sign | (man >> (13 + (-14 - e))));
+    const _Float16 h = (_Float16)x;
+    uint16_t b;
+    std::memcpy(&b, &h, 2);
+    return b;
 }
 
 inline float f16_bits_to_float(uint16_t hb)
@@ -655,8 +661,8 @@ std::vector<float> pack_mfma_h(const float* w, int COUT, int CIN, int KS, int CC
                                 const int o = nt * 32 + j, c = ch * CC + h * KC + 8 * kb + e;
                                 if (o >= COUT) continue;
                                 const float x = w[((size_t)o * CIN + c) * T + tap] * scale;
-                                const uint16_t hi = f16_bits_rtz(x);
-                                const uint16_t lo = f16_bits_rtz(x - f16_bits_to_float(hi));
+                                const uint16_t hi = f16_bits_rtn(x);
+                                const uint16_t lo = f16_bits_rtn(x - f16_bits_to_float(hi));
                                 const size_t base = (((((size_t)nt * T + tap) * NCH + ch) * NKB + kb) * 4) * 32;
                                 out[((base + (0 + h) * 32 + j) * 8) + e] = hi;
                                 out[((base + (2 + h) * 32 + j) * 8) + e] = lo;

@@ -24,6 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 H, W = 480, 640
 EP = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
 BF = dict(metric="euclidean", max_distance=5, cross_check=True)
+EXACT, DIFFS = [], []       # filled by the per-case tests, written out by test_record_of_the_reference_fixture_comparison
 
 
 def _flat(k):
@@ -70,21 +71,62 @@ def test_full_size_pair_from_pixels_equals_the_reference(case, nets):
         s0, d0 = net(img0)
         s1, d1 = net(img1)
         k0, k1 = detection(s0, EP), detection(s1, EP)
-        for k, want, ws in ((k0, want_idx[0], g[case + ".score0"]), (k1, want_idx[1], g[case + ".score1"])):
+        for k, sm, want, ws in ((k0, s0, want_idx[0], g[case + ".score0"]), (k1, s1, want_idx[1], g[case + ".score1"])):
             got = _flat(k)
-            assert set(got.tolist()) == set(want.tolist()), "%s: %d keypoints differ from the reference's" % (case, len(set(got.tolist()) ^ set(want.tolist())) // 2)
-            o_g, o_w = np.argsort(got, kind="stable"), np.argsort(want, kind="stable")
-            np.testing.assert_allclose(k[:, 2].cpu().numpy()[o_g], ws[o_w], rtol=0, atol=1.5e-5)      # GPU vs oracle 1e-5, oracle vs reference 4e-6
+            extra, missing = set(got.tolist()) - set(want.tolist()), set(want.tolist()) - set(got.tolist())
+            if extra or missing:
+                # Not equal: the only admissible cause is the top-K cut falling between scores closer than the score tolerance (the
+                # reference's own argsort is unstable there, extracter.py:217-218).  Every swapped keypoint must sit within 2e-5 of the
+                # cutoff IN BOTH score sets; anything else is a real disagreement and fails.
+                cut_w, cut_g = float(ws.min()), float(k[:, 2].min())
+                flat_s = sm[0, 0].reshape(-1)
+                sg = {int(i): float(flat_s[int(i)]) for i in extra | missing}
+                sw = {int(i): float(v) for i, v in zip(want.tolist(), ws.tolist()) if int(i) in missing}
+                assert len(extra) == len(missing) and len(extra) <= 2, (case, extra, missing)
+                assert all(abs(sg[i] - cut_g) <= 2e-5 for i in extra | missing), (case, sg, cut_g)
+                assert all(abs(v - cut_w) <= 2e-5 for v in sw.values()), (case, sw, cut_w)
+                DIFFS.append({"case": case, "dense": net is nets[0], "extra": sorted(extra), "missing": sorted(missing), "gpu_scores": sg,
+                              "reference_scores": sw, "gpu_cut": cut_g, "reference_cut": cut_w})
+            common = np.array(sorted(set(got.tolist()) & set(want.tolist())))
+            pg, pw = {int(i): r for r, i in enumerate(got)}, {int(i): r for r, i in enumerate(want)}
+            np.testing.assert_allclose(k[:, 2].cpu().numpy()[[pg[int(i)] for i in common]], ws[[pw[int(i)] for i in common]], rtol=0, atol=1.5e-5)
+        swapped = {d["case"] for d in DIFFS if d["case"] == case}
         m0, m1 = brute_force_matcher(k0, k1, d0, d1, BF)
         got_m = set(zip(_flat(m0).tolist(), _flat(m1).tolist()))
-        assert got_m == want_m, "%s: %d match pairs differ from the reference's %d" % (case, len(got_m ^ want_m), len(want_m))
         rep = val_key_points(k0, k1, w01, w10, th=3)
         wr = g[case + ".rep"]
-        assert rep["num_feat"] == int(wr[0]) and float(rep["repeatability"]) == np.float32(wr[1]), (case, rep, wr)
-        assert abs(float(rep["mean_error"]) - wr[2]) <= 1e-5
         params = {"MHA_params": {"th": [3, 5, 7]}, "extractor_params": EP, "matcher_params": {"brute_force_params": BF}}
-        flags = mha(0, img0, s0, d0, img1, s1, d1, w01, w10, params)
-        assert [float(f) for f in flags] == g[case + ".mha"].tolist(), (case, flags, g[case + ".mha"])
+        flags = [float(f) for f in mha(0, img0, s0, d0, img1, s1, d1, w01, w10, params)]
+        EXACT.append({"case": case, "dense": net is nets[0], "keypoint_sets_equal": not swapped, "match_sets_equal": got_m == want_m,
+                      "repeatability": float(rep["repeatability"]), "reference_repeatability": float(wr[1]),
+                      "mha": flags, "reference_mha": g[case + ".mha"].tolist()})
+        if not swapped:         # the same 1000 + 1000 pixels: everything downstream is the reference's, exactly
+            assert got_m == want_m, "%s: %d match pairs differ from the reference's %d" % (case, len(got_m ^ want_m), len(want_m))
+            assert rep["num_feat"] == int(wr[0]) and float(rep["repeatability"]) == np.float32(wr[1]), (case, rep, wr)
+            assert abs(float(rep["mean_error"]) - wr[2]) <= 1e-5
+        else:                   # one keypoint swapped at the cutoff: at most its own matches / its own count may move
+            assert len(got_m ^ want_m) <= 4 and abs(float(rep["repeatability"]) - wr[1]) <= 2.0 / 1000 + 1e-9, (case, len(got_m ^ want_m), rep, wr)
+        assert flags == g[case + ".mha"].tolist(), (case, flags, g[case + ".mha"])
+
+
+def test_record_of_the_reference_fixture_comparison():
+    """Runs after the 24 cases: writes what was exactly equal and what was swapped at the top-K cutoff (gpurun_out/, copied to
+    profiles/ by the evidence script) and bounds the swaps: the means must still be inside north_star's +-0.001."""
+    if not EXACT:
+        pytest.skip("the per-case tests did not run in this session")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    dense = [e for e in EXACT if e["dense"]]
+    rec = {"pairs": len(dense), "pairs_with_identical_keypoint_sets": sum(e["keypoint_sets_equal"] for e in dense),
+           "pairs_with_identical_match_sets": sum(e["match_sets_equal"] for e in dense),
+           "mean_repeatability": float(np.mean([e["repeatability"] for e in dense])),
+           "reference_mean_repeatability": float(np.mean([e["reference_repeatability"] for e in dense])),
+           "mha": np.mean([e["mha"] for e in dense], 0).tolist(), "reference_mha": np.mean([e["reference_mha"] for e in dense], 0).tolist(),
+           "cutoff_swaps": DIFFS}
+    with open(os.path.join(ROOT, "gpurun_out", "e2e_reference_fixture.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert abs(rec["mean_repeatability"] - rec["reference_mean_repeatability"]) <= 1e-3, rec
+    assert rec["mha"] == rec["reference_mha"], rec
+    assert rec["pairs_with_identical_keypoint_sets"] >= len(dense) - 3, rec
 
 
 @pytest.mark.timeout(1500)
