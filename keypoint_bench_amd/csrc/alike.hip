@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256) void amax_reduce(const float* slots, int n, un
     __shared__ float s[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     float m = 0.0f;
-    for (int i = tid; i < n; i += 256) m = fmaxf(m, slots[(size_t)b * n + i]);
+    for (int i = tid; i < n; i += 256) {
+        // a wave that met an infinite activation leaves +inf: skipped, so that the rest of the image keeps a usable scale and the
+        // fault stays where the reference's would (values beyond the window saturate locally)
+        const float v = slots[(size_t)b * n + i];
+        m = fmaxf(m, v < INFINITY ? v : 0.0f);
+    }
     m = cm_wave_max(m);
     if ((tid & 63) == 0) s[tid >> 6] = m;
     __syncthreads();
@@ -281,7 +286,22 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         am = cm_wave_max(am);
         if (lane == 0) s_amax[wv] = am;
         __syncthreads();
-        const float4 q = *reinterpret_cast<const float4*>(s_amax);
+        float4 q = *reinterpret_cast<const float4*>(s_amax);
+        if (!(q.x < INFINITY && q.y < INFINITY && q.z < INFINITY && q.w < INFINITY)) {
+            // A NaN / Inf pixel in the tile (kpb_pmax orders bit patterns: a non-finite value wins every integer maximum).  Its
+            // exponent would clamp the scale and flush the tile's FINITE pixels to zero; the reference keeps such a fault inside the
+            // pixel's receptive field.  Rare path, workgroup-uniform: the scale comes from the finite pixels only.
+            float fm = 0.0f;
+#pragma unroll
+            for (int k = 0; k < PER; ++k)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { const float v = fabsf(buf[k][c]); fm = fmaxf(fm, v < INFINITY ? v : 0.0f); }
+            fm = cm_wave_max(fm);
+            __syncthreads();
+            if (lane == 0) s_amax[wv] = fm;
+            __syncthreads();
+            q = *reinterpret_cast<const float4*>(s_amax);
+        }
         e_img = cm_exp_of(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
         const float sc = cm_scale_of(e_img);
 #pragma unroll

@@ -927,13 +927,12 @@ int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p, int prune
         p.slist = reinterpret_cast<int*>(p.ulist + (size_t)batch * 2 * p.ucap);
         if (prune) { p.clist = reinterpret_cast<float*>(p.slist + (size_t)batch * p.ucap); p.prune_k = prune_k; }
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->lds_attr_done & KPB_ATTR_NMS)) {
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
+        ctx->lds_attr_done |= KPB_ATTR_NMS;
     }
     return KPB_OK;
 }

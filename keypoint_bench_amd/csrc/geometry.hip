@@ -124,10 +124,11 @@ __device__ __forceinline__ unsigned long long rng_state(uint32_t seed)
 }
 
 constexpr int GETSUBSET_ATTEMPTS = 10000;
+constexpr int FM_LMEDS_BELOW = 15;        // cv::findFundamentalMat: FM_RANSAC with fewer points runs the least-median registrator
 
 // thread 0 only.  s_idx[j][0..M) = the subset of hypothesis j of this round; s_ok[j] = 0 from the first getSubset failure on.
 template <int M, class Check>
-__device__ void gen_round(CvRng& rng, int n, unsigned short* s_idx, unsigned char* s_ok, bool& alive, Check check)
+__device__ void gen_round(CvRng& rng, int n, unsigned short* s_idx, unsigned char* s_ok, bool& alive, Check check, int attempts = GETSUBSET_ATTEMPTS)
 {
     for (int j = 0; j < 256; ++j) {
         int idx[M];
@@ -135,7 +136,7 @@ __device__ void gen_round(CvRng& rng, int n, unsigned short* s_idx, unsigned cha
         for (int i = 0; i < M; ++i) idx[i] = 0;
         bool found = false;
         if (alive) {
-            for (int att = 0; att < GETSUBSET_ATTEMPTS && !found; ++att) {
+            for (int att = 0; att < attempts && !found; ++att) {
 #pragma unroll
                 for (int i = 0; i < M; ++i) {
                     int c;
@@ -582,10 +583,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_homography(
     RansacArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, seed_dev, seed, prm->threshold, prm->confidence, prm->max_iters, prm->refine,
                  out_h_dev, out_mask_dev, out_info_dev};
     const size_t lds = (size_t)max_k * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->lds_attr_done & KPB_ATTR_HOMOGRAPHY)) {
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_homography), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
+        ctx->lds_attr_done |= KPB_ATTR_HOMOGRAPHY;
     }
     KPB_LAUNCH(ctx, "ransac_homography", ransac_homography, dim3(batch), dim3(RS_THREADS), lds, ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
@@ -1161,13 +1161,93 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_fundamental(FundArgs a)
     RsState st{max(a.max_iters, 1), 0, 0, 0, 0};
     bool alive = true, have = false;
     int base = 0;
+    auto check = [&](const int* idx) {       // FMEstimatorCallback::checkSubset
+        double x1[14], x2[14];
+        for (int j = 0; j < 7; ++j) { const float4 q = pts[idx[j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
+        return !last_collinear<7>(x1) && !last_collinear<7>(x2);
+    };
+    if (n < FM_LMEDS_BELOW) {
+        // cv::findFundamentalMat (OpenCV 4.9 fundam.cpp): `(method & ~3) == FM_RANSAC && npoints >= 15` runs the RANSAC registrator,
+        // FEWER THAN 15 correspondences go to the least-median one whatever the method.  LMeDSPointSetRegistrator::run:
+        // niters = max(RANSACUpdateNumIters(confidence, 0.45, 7, maxIters), 3), the same RNG / getSubset (1000 attempts) / checkSubset
+        // stream, every model scored by the median of its float32 errors (element n / 2 in sorted order), the strictly smallest
+        // median kept; inliers = error <= sigma^2 with sigma = max(2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median), 0.001); the model
+        // stands when at least 7 points are inliers.  info[3] = 1 marks the branch.  PARITY UNPINNED (see the top of this file).
+        const int niters = max(update_iters(a.confidence, 0.45, 7, max(a.max_iters, 1)), 3);
+        __shared__ double s_minmed;
+        __shared__ int s_good;
+        if (tid == 0) { s_minmed = INFINITY; s_good = 0; }
+        int iters = 0;
+        for (;;) {
+            if (tid == 0) gen_round<7>(rng, n, s_idx, s_ok, alive, check, 1000);
+            __syncthreads();
+            double x1[14], x2[14];
+            for (int j = 0; j < 7; ++j) { const float4 q = pts[s_idx[tid * 7 + j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
+            double F[3][9];
+            bool valid[3] = {false, false, false};
+            int nv = 0;
+            if (s_ok[tid]) nv = fundamental_7pt(x1, x2, F, valid);
+            const int k = n / 2;
+            for (int s = 0; s < 3; ++s) {
+                float med = INFINITY;
+                bool got = false;
+                if (nv && valid[s])
+                    for (int i = 0; i < n; ++i) {               // the k-th smallest without an array: n <= 14
+                        const float4 qi = pts[i];
+                        const float ei = fm_err(F[s], qi.x, qi.y, qi.z, qi.w);
+                        int less = 0, leq = 0;
+                        for (int j = 0; j < n; ++j) { const float4 q = pts[j]; const float ej = fm_err(F[s], q.x, q.y, q.z, q.w); less += ej < ei; leq += ej <= ei; }
+                        if (less <= k && k < leq) { med = ei; got = true; }
+                    }
+                s_cnt[tid * 3 + s] = got ? __float_as_int(med) : -1;      // errors are non-negative: their bit patterns are too
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int kept = -1, stop = 0;
+                double mm = s_minmed;
+                for (int j = 0; j < 256; ++j) {
+                    const int it = base + j;
+                    if (it >= niters || !s_ok[j]) { stop = 1; break; }        // `if (iter == 0) return false; break;`
+                    for (int sl = 0; sl < 3; ++sl) {
+                        const int c = s_cnt[j * 3 + sl];
+                        if (c >= 0 && (double)__int_as_float(c) < mm) { mm = (double)__int_as_float(c); kept = j * 3 + sl; }
+                    }
+                    iters = it + 1;
+                }
+                s_minmed = mm; s_ctl[0] = iters; s_ctl[1] = stop; s_ctl[2] = kept;
+            }
+            __syncthreads();
+            if (s_ctl[2] >= 0 && s_ctl[2] / 3 == tid) for (int e = 0; e < 9; ++e) bestF[e] = F[s_ctl[2] % 3][e];
+            have = have || s_ctl[2] >= 0;
+            base += RS_THREADS;
+            const bool more = !s_ctl[1] && base < niters;
+            __syncthreads();
+            if (!more) break;
+        }
+        iters = s_ctl[0];
+        if (!have) {
+            if (tid < 9) Fout[tid] = 0.0;
+            if (tid == 0) { info[0] = 0; info[1] = 0; info[2] = iters; info[3] = 1; }
+            return;
+        }
+        double Fb[9];
+        for (int e = 0; e < 9; ++e) Fb[e] = bestF[e];
+        const double sigma = fmax(2.5 * 1.4826 * (1.0 + 5.0 / (n - 7)) * sqrt(s_minmed), 0.001);
+        const float ts = (float)(sigma * sigma);
+        for (int i = tid; i < n; i += RS_THREADS) {
+            const float4 q = pts[i];
+            const int in = fm_err(Fb, q.x, q.y, q.z, q.w) <= ts;
+            mask[i] = (uint8_t)in;
+            if (in) atomicAdd(&s_good, 1);
+        }
+        __syncthreads();
+        const int good = s_good, found = good >= 7;
+        if (tid < 9) Fout[tid] = found ? Fb[tid] : 0.0;
+        if (tid == 0) { info[0] = found; info[1] = good; info[2] = iters; info[3] = 1; }
+        return;
+    }
     for (;;) {
-        if (tid == 0)
-            gen_round<7>(rng, n, s_idx, s_ok, alive, [&](const int* idx) {       // FMEstimatorCallback::checkSubset
-                double x1[14], x2[14];
-                for (int j = 0; j < 7; ++j) { const float4 q = pts[idx[j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
-                return !last_collinear<7>(x1) && !last_collinear<7>(x2);
-            });
+        if (tid == 0) gen_round<7>(rng, n, s_idx, s_ok, alive, check);
         __syncthreads();
         double x1[14], x2[14];
         for (int j = 0; j < 7; ++j) { const float4 q = pts[s_idx[tid * 7 + j]]; x1[2 * j] = q.x; x1[2 * j + 1] = q.y; x2[2 * j] = q.z; x2[2 * j + 1] = q.w; }
@@ -1222,10 +1302,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_fundamental(
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     FundArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, seed_dev, seed, prm->threshold, prm->confidence, prm->max_iters,
                out_f_dev, out_mask_dev, out_info_dev};
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->lds_attr_done & KPB_ATTR_FUNDAMENTAL)) {
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_fundamental), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_set = true;
+        ctx->lds_attr_done |= KPB_ATTR_FUNDAMENTAL;
     }
     KPB_LAUNCH(ctx, "ransac_fundamental", ransac_fundamental, dim3(batch), dim3(RS_THREADS), (size_t)max_k * sizeof(float4), ctx->stream, a);
     KPB_HIP(ctx, hipGetLastError());
@@ -1245,12 +1324,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_find_essential(
     if (lds > 128 * 1024)      // the matches live in LDS for the whole search (config_vo.yaml's top_k 2000 needs 64 KB)
         return kpb_fail(ctx, KPB_E_UNSUPPORTED, "kpb_find_essential: at most 4096 matches per pair (got %d)", max_k);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
-    if (lds > 48 * 1024) {
-        static bool raised = false;
-        if (!raised) {
-            KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_essential), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            raised = true;
-        }
+    if (lds > 48 * 1024 && !(ctx->lds_attr_done & KPB_ATTR_ESSENTIAL)) {
+        KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_essential), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ctx->lds_attr_done |= KPB_ATTR_ESSENTIAL;
     }
     EssArgs a{m0_dev, cols0, m1_dev, cols1, max_k, k_dev, scale_dev, cam_dev, cam_f32, thr_dev, seed_dev, seed, prob, max_iters, out_e_dev, out_mask_dev,
               out_info_dev, out_pts_dev};

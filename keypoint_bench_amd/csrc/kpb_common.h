@@ -24,7 +24,10 @@ __device__ __forceinline__ void kpb_halves32(float v, float& lo, float& hi)
     hi = __uint_as_float(r[1]);
 }
 // maximum of two NON-NEGATIVE floats (ReLU outputs, magnitudes) on the integer ALU: their bit patterns order like the values, and no
-// canonicalising `v_max_f32 x, x` is spent on operands the compiler cannot prove quiet (8 % of block 1's vector instructions)
+// canonicalising `v_max_f32 x, x` is spent on operands the compiler cannot prove quiet (8 % of block 1's vector instructions).
+// PRECONDITION: sign bit clear (callers pass fabsf(x) or a ReLU output: v_max_f32(-0, +0) = +0) -- a -0.0 or a negative value would
+// win against every positive one.  NaN and +inf order ABOVE every finite value (fmaxf would drop a NaN): where the result feeds a
+// split scale (cm_exp_of) the caller checks it for finiteness and takes the masked path (alike_block1_h) or skips it (amax_reduce).
 __device__ __forceinline__ float kpb_pmax(float a, float b) { return __uint_as_float(max(__float_as_uint(a), __float_as_uint(b))); }
 __device__ __forceinline__ float kpb_pmax32(float v) { float a, b; kpb_halves32(v, a, b); return kpb_pmax(a, b); }
 // likewise for lanes 16 apart (v_permlane16_swap: rows 1 / 3 of one operand against rows 0 / 2 of the other) and, for the quad
@@ -125,7 +128,11 @@ struct kpb_ctx {
     void* det_state = nullptr;
     void (*det_state_free)(void*) = nullptr;
     int det_pending = 0;
+    // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, device) pair: remembered per CONTEXT (= per device),
+    // not in a process-wide static that a second device would find already set
+    unsigned lds_attr_done = 0;
 };
+enum { KPB_ATTR_NMS = 1u, KPB_ATTR_HOMOGRAPHY = 2u, KPB_ATTR_ESSENTIAL = 4u, KPB_ATTR_FUNDAMENTAL = 8u };
 
 extern char g_kpb_err[512];
 

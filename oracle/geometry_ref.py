@@ -753,14 +753,70 @@ def fm_error(F, x1, x2):
         return np.maximum(d1 * d1 * s1, d2 * d2 * s2).astype(np.float32)
 
 
+LMEDS_OUTLIER_RATIO = 0.45     # LMeDSPointSetRegistrator::run
+LMEDS_MIN_POINTS = 15          # cv::findFundamentalMat: `(method & ~3) == FM_RANSAC && npoints >= 15` runs RANSAC, otherwise LMedS
+LMEDS_ATTEMPTS = 1000          # its getSubset call leaves maxAttempts at the default
+
+
+def find_fundamental_lmeds(x1, x2, seed=0, confidence=F_CONFIDENCE, max_iters=F_MAX_ITERS):
+    """What cv2.findFundamentalMat(.., FM_RANSAC) does with 8 <= n < 15 points: OpenCV 4.9's fundam.cpp hands fewer than
+    15 correspondences to the LEAST-MEDIAN registrator whatever method was asked for.  LMeDSPointSetRegistrator::run restated:
+    niters = max(RANSACUpdateNumIters(confidence, 0.45, 7, maxIters), 3) (= 300 at the defaults), the same cv::RNG / getSubset /
+    checkSubset stream, every model of every sample scored by the MEDIAN (element count / 2 of the sorted float32 errors), the
+    strictly smallest median kept; then sigma = 2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(median), at least 0.001, inliers =
+    error <= sigma^2, and the model stands if at least 7 points are inliers.  PARITY UNPINNED like everything in this module."""
+    x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
+    n = len(x1)
+    mask = np.zeros(n, np.uint8)
+    niters = max(update_iters(confidence, LMEDS_OUTLIER_RATIO, 7, max_iters), 3)
+    rng = CvRNG(rng_state(seed))
+    best_F, min_median, base, iters, stop = None, np.inf, 0, 0, False
+    while base < niters and not stop:
+        idx = np.zeros((ROUND, 7), np.int64)
+        ok = np.zeros(ROUND, bool)
+        for j in range(ROUND):
+            sub = get_subset(rng, n, 7, check_subset_fundamental, x1, x2, LMEDS_ATTEMPTS)
+            if sub is None:
+                break
+            idx[j], ok[j] = sub, True
+        F, valid = fundamental_7pt(x1[idx], x2[idx])
+        with np.errstate(invalid="ignore"):
+            err = fm_error(F, x1, x2)                                       # [ROUND, 3, n] float32
+        med = np.sort(err, axis=-1)[..., n // 2].astype(np.float64)         # std::nth_element(.., count / 2, ..)
+        for j in range(ROUND):
+            it = base + j
+            if it >= niters:
+                stop = True
+                break
+            if not ok[j]:                                                   # `if (iter == 0) return false; break;`
+                stop = True
+                break
+            for s_ in range(3):
+                if valid[j, s_] and med[j, s_] < min_median:
+                    min_median, best_F = med[j, s_], F[j, s_]
+            iters = it + 1
+        base += ROUND
+    if best_F is None:
+        return None, mask, dict(iters=iters, inliers=0)
+    sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * np.sqrt(min_median), 0.001)
+    mask[fm_error(best_F, x1, x2) <= np.float32(sigma * sigma)] = 1
+    good = int(mask.sum())
+    if good < 7:                                                            # `result = count >= modelPoints`
+        return None, mask, dict(iters=iters, inliers=good)
+    return best_F, mask, dict(iters=iters, inliers=good)
+
+
 def find_fundamental_ransac(x1, x2, seed=0, threshold=F_THRESHOLD, confidence=F_CONFIDENCE, max_iters=F_MAX_ITERS):
-    """cv2.findFundamentalMat(x1, x2, cv2.FM_RANSAC) restated for n >= 8 (utils/mvg.py:13 never calls it with fewer).
+    """cv2.findFundamentalMat(x1, x2, cv2.FM_RANSAC) restated for n >= 8 (utils/mvg.py:13 never calls it with fewer): the RANSAC
+    registrator from 15 points on, the least-median one below (find_fundamental_lmeds).
     x1, x2 [N, 2] pixel coordinates (float32 values).  Returns (F [3,3] or None, mask [N] uint8, info)."""
     x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
     n = len(x1)
     mask = np.zeros(n, np.uint8)
     if n < 8:
         return None, mask, dict(iters=0, inliers=0)
+    if n < LMEDS_MIN_POINTS:
+        return find_fundamental_lmeds(x1, x2, seed, confidence, max_iters)
     t2 = np.float32(threshold * threshold)
     rng = CvRNG(rng_state(seed))
     st = dict(niters=max(max_iters, 1), max_good=0, iters=0, stop=False, failed=False)

@@ -301,6 +301,90 @@ def test_batched_fundamental_equals_oracle_and_ground_truth():
                 assert mask[b, :n][inl].mean() > 0.85 and mask[b, :n][~inl].mean() < 0.2
 
 
+def test_fundamental_with_fewer_than_15_matches_takes_opencvs_least_median_branch():
+    """cv::findFundamentalMat hands fewer than 15 correspondences to the LMedS registrator even under FM_RANSAC (ADVICE r03): 300
+    least-median iterations, sigma-rule inliers.  Device = numpy restatement (oracle/geometry_ref.find_fundamental_lmeds) pair for
+    pair; 15 matches are back on the RANSAC branch.  info[3] tells which branch ran."""
+    from keypoint_bench_amd.utils.mvg import find_fundamental
+    from test_oracle_geometry import fscene
+    ns = [8, 9, 10, 11, 12, 13, 14, 15, 14, 9]
+    B, K = len(ns), 16
+    W, H = 640, 480
+    scale = np.array([W - 1, H - 1, W - 1, H - 1], np.float32)
+    m0, m1 = np.zeros((B, K, 2), np.float32), np.zeros((B, K, 2), np.float32)
+    for b, n in enumerate(ns):
+        p1, p2, _, _ = fscene(n, 1.0 if b < 8 else 0.8, 0.3, 900 + b)
+        m0[b, :n] = (p1 / scale[:2]).astype(np.float32)
+        m1[b, :n] = (p2 / scale[2:]).astype(np.float32)
+    kk = np.array(ns, np.int32)
+    seeds = np.arange(B) * 7919 + 1
+    seeds[0] = 0                                    # cv::RNG((uint64)-1): the state of a real call
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    F, mask, info = find_fundamental(t(m0), t(m1), scale, k_dev=t(kk), seeds=seeds)
+    F, mask, info = F.cpu().numpy(), mask.cpu().numpy(), info.cpu().numpy()
+    for b, n in enumerate(ns):
+        p0 = (m0[b, :n] * scale[:2]).astype(np.float64)
+        p1 = (m1[b, :n] * scale[2:]).astype(np.float64)
+        Fe, me, ie = g.find_fundamental_ransac(p0, p1, seed=int(seeds[b]))
+        assert info[b, 3] == (1 if n < 15 else 0), (b, n, info[b])
+        assert info[b, 0] == (Fe is not None) and info[b, 2] == ie["iters"], (b, n, info[b], ie)
+        if n < 15:
+            assert ie["iters"] == 300
+        if Fe is None:
+            continue
+        assert int(info[b, 1]) == ie["inliers"] and np.array_equal(mask[b, :n], me), (b, n, info[b], ie, mask[b, :n], me)
+        np.testing.assert_allclose(F[b], Fe, rtol=0, atol=1e-6 * np.abs(Fe).max(), err_msg=str((b, n)))
+
+
+def test_ransac_kernels_at_their_documented_match_limits():
+    """The matches of a pair live in LDS for the whole search: 8 192 for the homography and the fundamental matrix (16 bytes each),
+    4 096 for the essential matrix (32 bytes) -- 128 KB of dynamic LDS beside each kernel's static arrays.  One launch at each limit
+    (only 2 000 was exercised), one above it (KPB_E_UNSUPPORTED)."""
+    from keypoint_bench_amd._lib import KpbError
+    from keypoint_bench_amd.utils.mvg import estimate_pose, find_fundamental, find_homography
+    from test_oracle_geometry import fscene, scene
+    W, H = 640, 480
+    scale = np.array([W - 1, H - 1, W - 1, H - 1], np.float32)
+    t_ = lambda a: torch.from_numpy(a).to(DEV)
+    # homography: a known H on 8 192 points, 30 % outliers
+    rng = np.random.default_rng(5)
+    K = 8192
+    p0 = rng.uniform(0.02, 0.98, (K, 2))
+    Hm = np.array([[1.02, 0.03, 0.01], [-0.02, 0.98, 0.02], [0.01, -0.02, 1.0]])
+    q = np.c_[p0, np.ones(K)] @ Hm.T
+    p1 = q[:, :2] / q[:, 2:]
+    out = rng.random(K) < 0.3
+    p1[out] = rng.uniform(0, 1, (int(out.sum()), 2))
+    Hd, mask, info = find_homography(t_(p0.astype(np.float32))[None], t_(p1.astype(np.float32))[None], scale, seed=0)
+    info, mask = info.cpu().numpy(), mask.cpu().numpy()
+    assert info[0, 0] == 1 and mask[0][~out].mean() > 0.97 and mask[0][out].mean() < 0.05, info
+    S = np.diag([W - 1.0, H - 1.0, 1.0])
+    He = S @ Hm @ np.linalg.inv(S)
+    np.testing.assert_allclose(Hd[0].cpu().numpy() / Hd[0, 2, 2].item(), He / He[2, 2], rtol=0, atol=2e-3 * np.abs(He).max())
+    with pytest.raises(KpbError, match="at most"):
+        find_homography(t_(np.zeros((1, K + 1, 2), np.float32)), t_(np.zeros((1, K + 1, 2), np.float32)), scale)
+    # fundamental: 8 192 matches of one epipolar geometry
+    a, b, Ft, inl = fscene(K, 0.7, 0.3, 31)
+    Fd, fmask, finfo = find_fundamental(t_((a / scale[:2]).astype(np.float32))[None], t_((b / scale[2:]).astype(np.float32))[None], scale, seed=0)
+    fmask, finfo = fmask.cpu().numpy(), finfo.cpu().numpy()
+    assert finfo[0, 0] == 1 and fmask[0][inl].mean() > 0.85 and fmask[0][~inl].mean() < 0.2, finfo
+    # essential + recoverPose: 4 096 matches
+    K, f = 4096, 500.0
+    Kc = np.array([[f, 0, 319.5], [0, f, 239.5], [0, 0, 1.0]])
+    x1, x2, R, tt, inl = scene(K, 0.7, 0.4, 78)
+    m0 = ((x1 * f + [319.5, 239.5]) / [W - 1, H - 1]).astype(np.float32)
+    m1 = ((x2 * f + [319.5, 239.5]) / [W - 1, H - 1]).astype(np.float32)
+    rt, emask, good, einfo = estimate_pose(t_(m0)[None], t_(m1)[None], scale, Kc, Kc, thresh=1.0, seeds=[9])
+    rt, emask, einfo = rt.cpu().numpy(), emask.cpu().numpy(), einfo.cpu().numpy()
+    assert einfo[0, 0] == 1 and emask[0, 3000:].sum() > 300, einfo
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, tt
+    et, eR = g.compute_pose_error(T, rt[0, :9].reshape(3, 3), rt[0, 9:])
+    assert et < 6.0 and eR < 2.5, (et, eR)
+    with pytest.raises(KpbError, match="at most"):
+        estimate_pose(t_(np.zeros((1, K + 1, 2), np.float32)), t_(np.zeros((1, K + 1, 2), np.float32)), scale, Kc, Kc)
+
+
 def _fund_params(matcher="brute_force", top_k=300):
     EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=top_k, min_score=0.0, save_result=False)
     return {"model_type": "Alike", "task_type": "FundamentalMatrixRansac", "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64),

@@ -299,3 +299,29 @@ def test_ransac_fundamental_small_and_degenerate_inputs():
     assert a is None and len(b) == 7 and len(c) == 7
     with pytest.raises(AttributeError):
         g.fundamental_estimate(line, line + 2)
+
+
+def test_fundamental_below_15_points_takes_the_least_median_branch():
+    """cv::findFundamentalMat(FM_RANSAC) with 8 <= n < 15 points runs OpenCV's LMedS registrator (300 iterations at the defaults).
+    With 7-point samples on so few points the criterion is weak (the sample itself supplies 7 zero errors), so what is checked is the
+    rule itself: the iteration count, the kept model's median against every other hypothesis of the stream, and the sigma rule."""
+    assert g.update_iters(0.99, g.LMEDS_OUTLIER_RATIO, 7, 1000) == 300
+    for n in (9, 12, 14):
+        p1, p2, F, _ = fscene(n, 0.8, 0.5, 40 + n)
+        Fe, mask, info = g.find_fundamental_ransac(p1, p2, seed=0)
+        assert Fe is not None and info["iters"] == 300
+        err = g.fm_error(Fe, p1, p2)
+        med = float(np.sort(err)[n // 2])
+        sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * np.sqrt(med), 0.001)
+        assert np.array_equal(mask, (err <= np.float32(sigma * sigma)).astype(np.uint8)) and mask.sum() == info["inliers"] >= 7
+        # no hypothesis of the same stream has a smaller median
+        rng = g.CvRNG(g.rng_state(0))
+        for _ in range(300):
+            idx = g.get_subset(rng, n, 7, g.check_subset_fundamental, p1, p2, g.LMEDS_ATTEMPTS)
+            Fs, valid = g.fundamental_7pt(p1[idx][None], p2[idx][None])
+            for k in range(3):
+                if valid[0, k]:
+                    assert float(np.sort(g.fm_error(Fs[0, k], p1, p2))[n // 2]) >= med
+    p1, p2, F, _ = fscene(15, 1.0, 0.0, 77)
+    _, _, info = g.find_fundamental_ransac(p1, p2, seed=0)
+    assert info["iters"] < 300          # 15 points: RANSAC, which stops as soon as every point is an inlier
