@@ -764,7 +764,10 @@ def find_fundamental_lmeds(x1, x2, seed=0, confidence=F_CONFIDENCE, max_iters=F_
     niters = max(RANSACUpdateNumIters(confidence, 0.45, 7, maxIters), 3) (= 300 at the defaults), the same cv::RNG / getSubset /
     checkSubset stream, every model of every sample scored by the MEDIAN (element count / 2 of the sorted float32 errors), the
     strictly smallest median kept; then sigma = 2.5 * 1.4826 * (1 + 5 / (count - 7)) * sqrt(median), at least 0.001, inliers =
-    error <= sigma^2, and the model stands if at least 7 points are inliers.  PARITY UNPINNED like everything in this module."""
+    error <= sigma^2, and the model stands if at least 7 points are inliers.  PARITY UNPINNED like everything in this module.
+    Note for 8 <= n <= 13: element n / 2 of the sorted errors is then one of the SAMPLE's own seven residuals (zero up to rounding), so
+    the "strictly smallest median" is decided by rounding noise -- in OpenCV's float32 errors too: no implementation can promise
+    OpenCV's winner there, only a model that interpolates seven points and the sigma rule (tests/test_gpu_geometry.py)."""
     x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
     n = len(x1)
     mask = np.zeros(n, np.uint8)

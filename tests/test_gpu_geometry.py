@@ -332,8 +332,19 @@ def test_fundamental_with_fewer_than_15_matches_takes_opencvs_least_median_branc
             assert ie["iters"] == 300
         if Fe is None:
             continue
-        assert int(info[b, 1]) == ie["inliers"] and np.array_equal(mask[b, :n], me), (b, n, info[b], ie, mask[b, :n], me)
-        np.testing.assert_allclose(F[b], Fe, rtol=0, atol=1e-6 * np.abs(Fe).max(), err_msg=str((b, n)))
+        if n >= 14:     # element n / 2 of the sorted errors lies OUTSIDE the 7 sample points: a meaningful median, the same winner
+            assert int(info[b, 1]) == ie["inliers"] and np.array_equal(mask[b, :n], me), (b, n, info[b], ie, mask[b, :n], me)
+            np.testing.assert_allclose(F[b], Fe, rtol=0, atol=1e-6 * np.abs(Fe).max(), err_msg=str((b, n)))
+            continue
+        # 8 <= n <= 13: the median is one of the sample's own seven (rounding-level) residuals, so WHICH hypothesis has the strictly
+        # smallest one is decided by rounding noise -- in OpenCV's float32 errors as much as here.  Checked instead: the kept model
+        # interpolates seven of the points, and mask / count obey the sigma rule for ITS median.
+        err = g.fm_error(F[b], p0, p1)
+        srt = np.sort(err)
+        assert srt[6] < 1e-6 and srt[n // 2] < 1e-6, (b, n, srt)
+        sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * np.sqrt(float(srt[n // 2])), 0.001)
+        clear = np.abs(err - sigma * sigma) > 1e-7              # points not within rounding of the threshold
+        assert np.array_equal(mask[b, :n][clear], (err <= sigma * sigma)[clear]) and mask[b, :n].sum() == info[b, 1] >= 7, (b, n, err, mask[b, :n])
 
 
 def test_ransac_kernels_at_their_documented_match_limits():
