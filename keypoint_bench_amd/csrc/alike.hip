@@ -232,6 +232,7 @@ struct Block1HArgs {
     float inv_ws1, inv_ws2;     // reciprocals of the two power-of-two weight scales
     float l1_c1, bmax_c1;       // max over output channels of sum |w| of conv1, max |bias|: |conv1 output| <= amax(input) l1 + bmax
     float* wmax_x1;             // [B][workgroups][4 waves]: every wave's largest x1 value (x1 >= 0); amax_reduce folds them per image
+    int xcd_map;                // kpb_xcd_tile: neighbouring tiles on one XCD
 };
 
 constexpr int B1H_TH = 16;
@@ -249,8 +250,9 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
     constexpr int PLANE = MH * HW, REGION = 2 * PLANE, NIN = IH * IW;
     __shared__ __attribute__((aligned(16))) uint2 inh[2 * NIN + 2];        // [hi | lo][position] = (c0 c1 c2 0) halves; + a zero piece
     __shared__ __attribute__((aligned(16))) uint4 mid[2 * REGION];          // [hi | lo][parity][row][column / 2]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
-    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * B1_TW;
+    const kpb_tile3 tile = kpb_xcd_tile(ha.xcd_map);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = tile.z;
+    const int ty0 = tile.y * TH, tx0 = tile.x * B1_TW;
     const size_t P = (size_t)a.H * a.W;
     const float* img = a.img + (size_t)b * 3 * P;
     h8v c1hi[2], c1lo[2], bhi[3], blo[3];
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
             if (sN == 0 && py < H2 && pxl < W2) *reinterpret_cast<float4*>(a.p1 + (((size_t)b * H2 + py) * W2 + pxl) * 8 + c0) = m;
         }
     }
-    amax_commit(xmax, ha.wmax_x1, ((b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wv, lane);
+    amax_commit(xmax, ha.wmax_x1, ((b * gridDim.y + tile.y) * gridDim.x + tile.x) * 4 + wv, lane);
 }
 
 // conv1 of block 1, OIHW [8][3][3][3] -> alike_block1_h fragments [2 kb][hi / lo][64 lanes][8 halves]: lane (n = (s, cout), g),
@@ -601,6 +603,7 @@ struct Block2Args {
     float inv_ws1, inv_ws2, inv_wsa, l1_c1, bmax_c1, l1_c2, l1_ds, bmax_sum;
     const unsigned* amax_x1;    // [B] float bits: largest value of the image's x1 (= of p1, its 2 x 2 max-pool)
     float* wmax_a2;             // [B][workgroups][4 waves]: every wave's largest a2 value, folded per image by amax_reduce for the head
+    int xcd_map;                // kpb_xcd_tile: neighbouring tiles on one XCD
 };
 
 
@@ -615,8 +618,9 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
     __shared__ __attribute__((aligned(16))) uint4 mid[4 * NM];          // [hi | lo][octet][position]: conv1's output
     __shared__ __attribute__((aligned(16))) uint4 xs[4][2][2][16];      // per wave: [hi | lo][octet][pixel] of the x2 group in flight
     __shared__ __attribute__((aligned(16))) uint4 zslot;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
-    const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
+    const kpb_tile3 tile = kpb_xcd_tile(a.xcd_map);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = tile.z;
+    const int ty0 = tile.y * TH, tx0 = tile.x * TW;
     const size_t P = (size_t)a.H * a.W;
     h8v w1h[3], w1l[3], w2h[5], w2l[5];
 #pragma unroll
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         if ((px & 3) == 0 && gy < a.H && gx < a.W)
             *reinterpret_cast<float4*>(a.p2 + (size_t)b * (P / 16) * 16 + ((size_t)(gy >> 2) * (a.W >> 2) + (gx >> 2)) * 16 + 4 * g) = pm;
     }
-    amax_commit(amx, a.wmax_a2, ((b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wv, lane);
+    amax_commit(amx, a.wmax_a2, ((b * gridDim.y + tile.y) * gridDim.x + tile.x) * 4 + wv, lane);
 }
 
 // agg [16][16] (cout, cin) -> one k-block of fragments: piece g < 2 = channel octet g
@@ -1213,6 +1217,7 @@ __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
 // Operand range (r03): the fine features are scaled by the power of two that fits the image's bound (HybArgs), for free --
 // the scale rides on the agg1 weights staged in LDS and on the two y weights of the a2 interpolation; the projected coarse
 // rows are brought to the same units when the strips are built, and the accumulator is scaled back before the store.
+template <int WHOLE>
 __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
 {
     __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];         // [hi/lo][(kb, nh, h, n)]: one 16-byte fragment per lane and MFMA
@@ -1259,6 +1264,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
     const int ntile = live ? min(SEG_TILES, tiles_per_row - xs / 32) : 0;
     const int tb3 = (int)(sx8 * (float)xs), tb4 = (int)(sx32 * (float)xs);
     f32x16 pend = {0};                  // channels 32..63 of the previous tile, stored under the next tile's feature arithmetic
+    f32x16 pendB = {0};                 // WHOLE: pend = pixels R(r) of the previous tile, pendB = pixels R(r) + 4, all 64 channels each
     float* pend_d = nullptr;
     bool have = false;
     // A wave's vector-memory operations complete IN ORDER (loads and stores share one counter): a load issued behind a store
@@ -1295,7 +1301,8 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
     strip_store<NT3>(sr3, V3[wv], H8, sy8, y, lane, cacc);       // (a wave with no live row has y = 0: harmless)
     strip_store<NT4>(sr4, V4[wv], H32, sy32, y, lane, cacc);
     __syncthreads();
-    auto body = [&](const int t, const TileIn& cur, TileIn& nxt) {
+    auto body = [&](auto first_tag, const int t, const TileIn& cur, TileIn& nxt) {
+        constexpr bool FIRST = decltype(first_tag)::value;       // the segment's first tile has no predecessor whose stores are pending
         const int x0 = xs + 32 * t, x = x0 + p;
         const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
         if (t + 1 < ntile) fetch(t + 1, nxt);
@@ -1314,9 +1321,9 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
                 taps.t[4 * q + 2] = A2[(ry1 * A2C + rx0) * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 3] = A2[(ry1 * A2C + rx1) * 4 + ((2 * h + q) ^ s1)];
             }
         }
-        if (have) {
+        if constexpr (!FIRST) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(WHOLE ? pend[r] : pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
         }
         int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
         asm volatile("" : "+v"(z));
@@ -1391,8 +1398,11 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
         // (the lane-dependent part of a row's address, 4 h rows and channel p, sits in ONE base pointer: the 16 row offsets are
         // compile-time constants that fold into the store instructions instead of costing a 64-bit add each)
         float* dl = d + (4 * h) * 64 + p;
-#define ST0_2() { __builtin_nontemporal_store(acc0[r] * unacc, dl + ((r & 3) + 8 * (r >> 2)) * 64); ++r; \
-                  __builtin_nontemporal_store(acc0[r] * unacc, dl + ((r & 3) + 8 * (r >> 2)) * 64); ++r; }
+        // WHOLE (r04): the stores interleaved here are the previous tile's pixels R + 4 (pendB), 256 contiguous bytes each
+        float* pb = pend_d + 4 * 64;
+#define ST0_1() { if constexpr (WHOLE) { if constexpr (!FIRST) __builtin_nontemporal_store(pendB[r], pb + ((r & 3) + 8 * (r >> 2)) * 64); } \
+                  else __builtin_nontemporal_store(acc0[r] * unacc, dl + ((r & 3) + 8 * (r >> 2)) * 64); ++r; }
+#define ST0_2() { ST0_1() ST0_1() }
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); ST0_2()
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); ST0_2()
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); ST0_2()
@@ -1406,19 +1416,341 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], t4b[1], acc1, 0, 0, 0);
 #undef ST0_2
         // pin the interleaving (the scheduler otherwise gathers the stores into one burst behind the last MFMA)
-        __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+        if constexpr (!(WHOLE && FIRST)) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
 #pragma unroll
-        for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        pend = acc1; pend_d = dl + 32; have = true;
+            for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+        if constexpr (WHOLE) {
+            // One store instruction = one pixel = 256 contiguous bytes: v_permlane32_swap trades the upper half of acc0[r] (pixel
+            // R + 4, channels 0..31) for the lower half of acc1[r] (pixel R, channels 32..63).  The r03 form wrote two 128-byte half
+            // pixels per instruction and the other halves a tile later; the memory system takes whole pixels 5 % faster beside the
+            // head's loads (scripts/hbm_store_patterns.hip, profiles/r04_hbm_store_patterns.txt: 5.50 -> 5.77 TB/s).
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[q] * unacc), __float_as_uint(acc1[q] * unacc), false, false);
+                pend[q] = __uint_as_float(sw[0]); pendB[q] = __uint_as_float(sw[1]);
+            }
+            pend_d = d + lane;
+        } else {
+            pend = acc1; pend_d = dl + 32;
+        }
+        have = true;
     };
-    for (int t = 0; t < ntile; t += 2) {        // two tiles per trip: the two input sets swap roles, no register copies
-        body(t, tin[0], tin[1]);
-        if (t + 1 < ntile) body(t + 1, tin[1], tin[0]);
+    if (ntile > 0) body(std::true_type{}, 0, tin[0], tin[1]);
+    for (int t = 1; t < ntile; t += 2) {        // two tiles per trip: the two input sets swap roles, no register copies
+        body(std::false_type{}, t, tin[1], tin[0]);
+        if (t + 1 < ntile) body(std::false_type{}, t + 1, tin[0], tin[1]);
     }
     if (have) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(WHOLE ? pend[r] : pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
+        if (WHOLE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pendB[r], pend_d + ((r & 3) + 8 * (r >> 2) + 4) * 64);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ head, persistent form (r04)
+// r03's stamps (profiles/r03_head_stamps.txt): a workgroup of alike_head_f16 lives 45.5 k cycles, 18.6 k of them in a prologue that
+// stores nothing -- 27 loads per wave queued behind the other workgroups' stores, strips built, a barrier -- for four tiles per wave.
+// Here a workgroup is PERSISTENT down a 64-pixel column band: it walks `groups_per_wg` row groups (4 rows, one per wave, two 32-pixel
+// tiles each) and everything the NEXT groups need arrives while the current one computes:
+//   * the a2 rows live in an LDS ring of 8 rows (absolute row & 7); consecutive groups share half of their rows, so a group
+//     brings two new rows of 34 pixels (4.4 KB) instead of a 16.9 KB band;
+//   * the projected coarse rows E3 / E4 are kept RAW in rings of 4 rows (row & 3) and interpolated in y where they are used
+//     (hy, ly carry the accumulator's power-of-two scale: the values are bit for bit those of r03's per-wave strips), so nothing
+//     is rebuilt per row and a new E3 row (2.7 KB) is needed every other group;
+//   * the rows of group g + 2 are requested by LDS-DMA (global_load_lds_dwordx4: no registers) right after the barrier of group g;
+//     a wave's vector-memory operations complete in order, so `s_waitcnt vmcnt(63)` two groups (>= 68 operations) later proves
+//     its requests have landed without draining its stores.  The DMA is issued from inline assembly: the compiler's own LDS-DMA
+//     tracking would put a full wait in front of the first ring read after every request.
+// Ring capacities: a group g computes while rows up to group g + 2 arrive; those span at most floor(11 s) + 2 source rows for a
+// vertical scale s = (Hs - 1) / (H - 1) < 1/2, 1/8, 1/32: 7, 3, 2 -- inside 8, 4, 4, so a request never lands on a row in use.
+// LDS 42.6 KB (r03: 52.9), three workgroups per CU as before; whole-pixel stores (alike_head_f16<1>).
+constexpr int HP_TILES = 2, HP_BW = 32 * HP_TILES;
+constexpr int HP_A2C = 34, HP_A2R = 8, HP_A2S = HP_A2C * 4;                   // a2 ring: rows x 16-byte slots (136 per row)
+constexpr int HP_NT3 = 10, HP_NT4 = 5, HP_ER = 4;                             // raw E3 / E4 rings: rows x band columns x ESTRIDE
+constexpr int HP_E3S = HP_NT3 * (ESTRIDE / 4), HP_E4S = HP_NT4 * (ESTRIDE / 4);     // 16-byte slots per ring row: 170, 85
+constexpr int HP_LA = 2;                                                      // row groups of look-ahead
+
+// 16 bytes per active lane from global memory to LDS at lds_wave_base + 16 * lane (wave-uniform base), no VGPR in between.
+__device__ __forceinline__ void hp_dma16(const void* gsrc, const void* lds_wave_base)
+{
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_wave_base));   // low half of a shared-aperture address = LDS offset
+    unsigned keep;      // M0 is the compiler's (reserved register): saved and put back around the instruction that reads it
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(m0v), "v"(gsrc) : "memory");
+}
+
+__global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4* __restrict__ wh16, int groups_per_wg)
+{
+    __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];
+    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];
+    __shared__ __attribute__((aligned(16))) float Ws[2 * 16];
+    __shared__ __attribute__((aligned(16))) float4 A2r[HP_A2R * HP_A2S];
+    __shared__ __attribute__((aligned(16))) float E3r[HP_ER][HP_NT3 * ESTRIDE];
+    __shared__ __attribute__((aligned(16))) float E4r[HP_ER][HP_NT4 * ESTRIDE];
+    __shared__ __attribute__((aligned(16))) float4 X1r[4][2][64];     // per wave: the x1 pixels of two tiles in flight ([half][pixel] x 16 bytes)
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int ef = cm_exp_of(fmaxf(__uint_as_float(a.amax_x1[b]) * a.l1_agg1, __uint_as_float(a.amax_a2[b])));
+    // wave-uniform values the whole walk needs are pinned in scalar registers (uf / ui): computed on the vector ALU they would each
+    // hold a VGPR for the life of the workgroup (the first build of this kernel spilled 70)
+    auto uf = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+    auto ui = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    const float scf = uf(cm_scale_of(ef)), unf = cm_unscale_of(ef);
+    const float cacc = uf(scf * a.ws_h), unacc = uf(unf * a.inv_ws_h);
+    Bh[0][tid] = wh16[tid];
+    Bh[1][tid] = wh16[256 + tid];
+    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j] * scf; }
+    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)] * unf; }
+
+    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
+    const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
+    const float* E3 = a.E3 + (size_t)b * H8 * W8 * ESTRIDE;
+    const float* E4 = a.E4 + (size_t)b * H32 * W32 * ESTRIDE;
+    const float sy2 = uf((float)(H2 - 1) / (float)(a.H - 1)), sx2 = uf((float)(W2 - 1) / (float)(a.W - 1));
+    const float sy8 = uf((float)(H8 - 1) / (float)(a.H - 1)), sx8 = uf((float)(W8 - 1) / (float)(a.W - 1));
+    const float sy32 = uf((float)(H32 - 1) / (float)(a.H - 1)), sx32 = uf((float)(W32 - 1) / (float)(a.W - 1));
+    const int tiles_per_row = a.W / 32, bands = (tiles_per_row + HP_TILES - 1) / HP_TILES, ngroups = a.H / 4;
+    const int band = (int)blockIdx.x % bands, seg = (int)blockIdx.x / bands;
+    const int g0 = seg * groups_per_wg, g1 = min(g0 + groups_per_wg, ngroups);
+    const int xs = band * HP_BW;
+    const int ntile = min(HP_TILES, tiles_per_row - xs / 32);
+    const int c_lo = ui((int)(sx2 * (float)xs)), tb3 = ui((int)(sx8 * (float)xs)), tb4 = ui((int)(sx32 * (float)xs));
+
+    // rows [lo(G), hi(G)] of a source map that row group G reads (align_corners taps of its rows 4 G .. 4 G + 3)
+    auto hi_row = [&](float s, int G, int Hs) { const int r = ui((int)(s * (float)(4 * G + 3))); return r + (r < Hs - 1 ? 1 : 0); };
+    int a2next = ui((int)(sy2 * (float)(4 * g0))), e3next = ui((int)(sy8 * (float)(4 * g0))), e4next = ui((int)(sy32 * (float)(4 * g0)));
+    auto request = [&](const int G) {      // every row group G reads that has not been requested yet; 1 KB units dealt over the waves
+        int u = 0, ln = lane;
+        asm volatile("" : "+v"(ln));        // opaque: the per-lane source offsets are recomputed here, not hoisted out of the walk into ~25 registers
+        const int h2 = hi_row(sy2, G, H2), h3 = hi_row(sy8, G, H8), h4 = hi_row(sy32, G, H32);
+        for (int r = a2next; r <= h2; ++r)
+            for (int j = 0; j < (HP_A2S + 63) / 64; ++j, ++u)
+                if ((u & 3) == wv) {
+                    const int q = 64 * j + ln;
+                    if (q < HP_A2S) {       // LDS position q of the row holds slot (q & 3) ^ swizzle of pixel q >> 2 (bank spread, see alike_head_f16)
+                        const int col = q >> 2, sl = (q & 3) ^ ((col >> 2) & 3), gc = min(c_lo + col, W2 - 1);
+                        hp_dma16(a2 + ((size_t)r * W2 + gc) * 16 + 4 * sl, &A2r[(r & (HP_A2R - 1)) * HP_A2S + 64 * j]);
+                    }
+                }
+        a2next = max(a2next, h2 + 1);
+        for (int r = e3next; r <= h3; ++r)
+            for (int j = 0; j < (HP_E3S + 63) / 64; ++j, ++u)
+                if ((u & 3) == wv) {
+                    const int q = 64 * j + ln;
+                    if (q < HP_E3S) {
+                        const int t = q / (ESTRIDE / 4), quad = q - t * (ESTRIDE / 4);
+                        hp_dma16(E3 + ((size_t)r * W8 + min(tb3 + t, W8 - 1)) * ESTRIDE + 4 * quad, &E3r[r & (HP_ER - 1)][64 * j * 4]);
+                    }
+                }
+        e3next = max(e3next, h3 + 1);
+        for (int r = e4next; r <= h4; ++r)
+            for (int j = 0; j < (HP_E4S + 63) / 64; ++j, ++u)
+                if ((u & 3) == wv) {
+                    const int q = 64 * j + ln;
+                    if (q < HP_E4S) {
+                        const int t = q / (ESTRIDE / 4), quad = q - t * (ESTRIDE / 4);
+                        hp_dma16(E4 + ((size_t)r * W32 + min(tb4 + t, W32 - 1)) * ESTRIDE + 4 * quad, &E4r[r & (HP_ER - 1)][64 * j * 4]);
+                    }
+                }
+        e4next = max(e4next, h4 + 1);
+    };
+
+    f32x16 pend = {0}, pendB = {0};     // the previous tile, whole pixels: pend = pixels R(r), pendB = pixels R(r) + 4 (alike_head_f16<1>)
+    float* pend_d = nullptr;
+    // x1 arrives by LDS-DMA too, TWO tiles ahead, one 1 KB instruction per tile and wave: lane (p, h) brings half h of pixel p to
+    // slot 32 h + p.  With no load left that returns to registers, the only waits of the walk are `s_waitcnt vmcnt(63)` at tile
+    // starts: a wave keeps up to 63 vector-memory operations (two tiles of stores) in flight instead of the one tile the in-order
+    // return of a register load one tile ahead allowed.
+    auto fetch = [&](int y, int t, int slot) {
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + (xs + 32 * t + p);
+        hp_dma16(a.x1 + pix * 8 + 4 * h, &X1r[wv][slot][0]);
+    };
+    // tile k of this wave's walk = (group g0 + k / ntile, tile k % ntile)
+    if (g0 < g1) {
+        fetch(4 * g0 + wv, 0, 0);
+        if (ntile == 2) fetch(4 * g0 + wv, 1, 1);
+        else if (g0 + 1 < g1) fetch(4 * (g0 + 1) + wv, 0, 1);
+    }
+    for (int G = g0; G < min(g0 + HP_LA, g1); ++G) request(G);
+    int ktile = 0;
+
+    // per group and wave: the y taps of the raw coarse rows (strip_store's arithmetic, applied where the value is read)
+    int U3 = 0, D3 = 0, U4 = 0, D4 = 0;        // float offsets of the two tapped ring rows inside E3r / E4r (offsets, not pointers: the reads stay ds_read)
+    float hy3 = 0.f, ly3 = 0.f, hy4 = 0.f, ly4 = 0.f, hy3c = 0.f, ly3c = 0.f, hy4c = 0.f, ly4c = 0.f;
+
+    int xso = xs;       // the band's first column, made opaque once per group: everything derived from x is invariant along the walk, and
+                        // hoisted out of it the tap offsets and hat weights of both tiles held ~40 registers (spills)
+    auto body = [&](auto first_tag, const int y, const int t, const int ny, const int nt) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const int x0 = xso + 32 * t, x = x0 + p;
+        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
+        // this tile's x1 (requested two tiles = >= 65 operations ago) and every ring row of its group have landed once all but the
+        // youngest 63 operations of the wave have completed; the first tiles of a walk have fewer behind them and wait for all
+        if (ktile < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        const int slot = ktile & 1;
+        const float4 x1lo = X1r[wv][slot][p], x1hi = X1r[wv][slot][32 + p];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: the request for two tiles ahead may overwrite it
+        if (ny >= 0) fetch(ny, nt, slot);
+        ++ktile;
+        Up8Taps taps;
+        {
+            const float fy = sy2 * (float)y, fx = sx2 * (float)x;
+            const int gy0 = (int)fy, gx0 = (int)fx;
+            const int gy1 = gy0 + (gy0 < H2 - 1 ? 1 : 0);
+            const int rx0 = gx0 - c_lo, rx1 = rx0 + (gx0 < W2 - 1 ? 1 : 0);
+            taps.ly = fy - (float)gy0; taps.lx = fx - (float)gx0;
+            const float4* r0 = A2r + (gy0 & (HP_A2R - 1)) * HP_A2S;
+            const float4* r1 = A2r + (gy1 & (HP_A2R - 1)) * HP_A2S;
+            const int s0 = (rx0 >> 2) & 3, s1 = (rx1 >> 2) & 3;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                taps.t[4 * q + 0] = r0[rx0 * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 1] = r0[rx1 * 4 + ((2 * h + q) ^ s1)];
+                taps.t[4 * q + 2] = r1[rx0 * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 3] = r1[rx1 * 4 + ((2 * h + q) ^ s1)];
+            }
+        }
+        if constexpr (!FIRST) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
+        }
+        int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
+        asm volatile("" : "+v"(z));
+        const uint4* Bhz = &Bh[0][0] + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
+        float f[16];
+        {
+            const float v[8] = {x1lo.x, x1lo.y, x1lo.z, x1lo.w, x1hi.x, x1hi.y, x1hi.z, x1hi.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 w0 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8 + 4]);
+                f[0] = fmaf(v[c], w0.x, f[0]); f[1] = fmaf(v[c], w0.y, f[1]); f[2] = fmaf(v[c], w0.z, f[2]); f[3] = fmaf(v[c], w0.w, f[3]);
+                f[4] = fmaf(v[c], w1.x, f[4]); f[5] = fmaf(v[c], w1.y, f[5]); f[6] = fmaf(v[c], w1.z, f[6]); f[7] = fmaf(v[c], w1.w, f[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
+        }
+        up8ch_lerp(taps, f + 8, scf);
+
+        const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
+        const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;
+        const int t3 = (int)fx3 - tb3 - rb3, t4 = (int)fx4 - tb4 - rb4;
+        const float lx3 = fx3 - (float)(int)fx3, lx4 = fx4 - (float)(int)fx4;
+        const float *u3 = &E3r[0][0] + (U3 + rb3 * ESTRIDE + z), *d3 = &E3r[0][0] + (D3 + rb3 * ESTRIDE + z);
+        const float *u4 = &E4r[0][0] + (U4 + rb4 * ESTRIDE + z), *d4 = &E4r[0][0] + (D4 + rb4 * ESTRIDE + z);
+        // the y-interpolated coarse row at (strip row k, channel c), in the accumulator's units (channel 64: the score share, unscaled)
+        auto e3 = [&](int k, int c) { return hy3c * u3[k * ESTRIDE + c] + ly3c * d3[k * ESTRIDE + c]; };
+        auto e4 = [&](int k, int c) { return hy4c * u4[k * ESTRIDE + c] + ly4c * d4[k * ESTRIDE + c]; };
+
+        float sc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 w = *reinterpret_cast<const float4*>(&Wsz[h * 16 + 4 * q]);
+            sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
+        }
+        sc = kpb_sum32(sc);
+        sc += (1.0f - lx3) * (hy3 * u3[t3 * ESTRIDE + 64] + ly3 * d3[t3 * ESTRIDE + 64]) + lx3 * (hy3 * u3[(t3 + 1) * ESTRIDE + 64] + ly3 * d3[(t3 + 1) * ESTRIDE + 64]);
+        sc += (1.0f - lx4) * (hy4 * u4[t4 * ESTRIDE + 64] + ly4 * d4[t4 * ESTRIDE + 64]) + lx4 * (hy4 * u4[(t4 + 1) * ESTRIDE + 64] + ly4 * d4[(t4 + 1) * ESTRIDE + 64]);
+        if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));
+
+        float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
+        f32x16 acc0 = {0}, acc1 = {0};
+        h8v ahi[2], alo[2];
+        split8(f, ahi[0], alo[0]);
+        split8(f + 8, ahi[1], alo[1]);
+        float w3[3], w4[2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { const int k = 2 * s + h; w3[s] = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f); }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int k = 2 * s + h; w4[s] = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f); }
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[kb], b0h, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0l, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0h, acc0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], e3(2 * s + h, p), acc0, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], e4(2 * s + h, p), acc0, 0, 0, 0);
+        h8v b1h[2], b1l[2];
+        float t3b[3], t4b[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { b1h[kb] = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]); b1l[kb] = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]); }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) t3b[s] = e3(2 * s + h, 32 + p);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) t4b[s] = e4(2 * s + h, 32 + p);
+        int r = 0;
+        float* pb = pend_d + 4 * 64;
+#define HP_ST1() { if constexpr (!FIRST) __builtin_nontemporal_store(pendB[r], pb + ((r & 3) + 8 * (r >> 2)) * 64); ++r; }
+#define HP_ST2() { HP_ST1() HP_ST1() }
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], b1h[1], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1l[1], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1h[1], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[0], t3b[0], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[1], t3b[1], acc1, 0, 0, 0); HP_ST2()
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[2], t3b[2], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], t4b[0], acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], t4b[1], acc1, 0, 0, 0);
+#undef HP_ST2
+#undef HP_ST1
+        if constexpr (!FIRST) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[q] * unacc), __float_as_uint(acc1[q] * unacc), false, false);
+            pend[q] = __uint_as_float(sw[0]); pendB[q] = __uint_as_float(sw[1]);
+        }
+        pend_d = d + lane;
+    };
+
+    for (int g = g0; g < g1; ++g) {
+        // this wave's ring requests for group g (two groups = at least two tiles old) have landed: same rule as a tile's x1
+        if (ktile < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        __syncthreads();        // every wave has left group g - 1, every request for group g has landed
+        if (g + HP_LA < g1) request(g + HP_LA);
+        const int y = 4 * g + wv;
+        {
+            const float fy3 = sy8 * (float)y, fy4 = sy32 * (float)y;
+            const int y03 = (int)fy3, y04 = (int)fy4;
+            const int y13 = y03 + (y03 < H8 - 1 ? 1 : 0), y14 = y04 + (y04 < H32 - 1 ? 1 : 0);
+            ly3 = uf(fy3 - (float)y03); hy3 = uf(1.0f - ly3); ly4 = uf(fy4 - (float)y04); hy4 = uf(1.0f - ly4);
+            hy3c = uf(hy3 * cacc); ly3c = uf(ly3 * cacc); hy4c = uf(hy4 * cacc); ly4c = uf(ly4 * cacc);
+            U3 = ui((y03 & (HP_ER - 1)) * (HP_NT3 * ESTRIDE)); D3 = ui((y13 & (HP_ER - 1)) * (HP_NT3 * ESTRIDE));
+            U4 = ui((y04 & (HP_ER - 1)) * (HP_NT4 * ESTRIDE)); D4 = ui((y14 & (HP_ER - 1)) * (HP_NT4 * ESTRIDE));
+        }
+        asm volatile("" : "+s"(xso));
+        if (ntile == 2) {       // the tile two ahead is the same tile of the next group
+            const int ny = g + 1 < g1 ? y + 4 : -1;
+            if (g == g0) body(std::true_type{}, y, 0, ny, 0);
+            else body(std::false_type{}, y, 0, ny, 0);
+            body(std::false_type{}, y, 1, ny, 1);
+        } else {                // one-tile band: two groups ahead
+            const int ny = g + 2 < g1 ? y + 8 : -1;
+            if (g == g0) body(std::true_type{}, y, 0, ny, 0);
+            else body(std::false_type{}, y, 0, ny, 0);
+        }
+    }
+    if (g0 < g1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pendB[r], pend_d + ((r & 3) + 8 * (r >> 2) + 4) * 64);
     }
 }
 
@@ -1640,14 +1972,14 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     ConvArgs c;
     if (h16) {
         Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c1.pairs")), reinterpret_cast<const uint4*>(wp("b1c2.pairs")),
-                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), wmax_x1};
+                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), wmax_x1, kpb_env_int("KPB_XCD_MAP", 7) & 1};
         KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1H_TH), batch), dim3(256), 0, st, hb);
         KPB_LAUNCH(ctx, "amax_reduce", amax_reduce, dim3(batch), dim3(256), 0, st, wmax_x1, nw1, amax_x1);
         // block2 @ H/2 (ALike.py:139-140) + agg2, fused; it hands block 3 the 4 x 4 max-pool of its output (141)
         Block2Args b2{p1, x2, a2, S2, p2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
                       reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2,
                       k.at("b2c1.inv_ws"), k.at("b2c2.inv_ws"), k.at("agg2.inv_ws"), k.at("b2c1.l1"), k.at("b2c1.bmax"), k.at("b2c2.l1"), k.at("b2ds.l1"),
-                      k.at("b2c2.bsummax"), amax_x1, wmax_a2};
+                      k.at("b2c2.bsummax"), amax_x1, wmax_a2, (kpb_env_int("KPB_XCD_MAP", 7) >> 1) & 1};
         KPB_LAUNCH(ctx, "alike_block2", alike_block2, dim3(cdiv(W / 2, 32), cdiv(H / 2, 8), batch), dim3(256), 0, st, b2);
         KPB_LAUNCH(ctx, "amax_reduce", amax_reduce, dim3(batch), dim3(256), 0, st, wmax_a2, nw2, amax_a2);
         // blocks 3 and 4 @ H/8, H/32 (141-144) on conv_mfma_h: conv1 carries the identity branch ds(pooled input) as 32 / 64 more
@@ -1715,7 +2047,14 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         const int work4 = cdiv(H, 4) * cdiv(W / 32, SEG_TILES);     // four consecutive rows of one 128-pixel column band per workgroup
         if (h16) {
             hy.l1_agg1 = k.at("agg1.l1"); hy.inv_ws_h = k.at("head.inv_ws"); hy.ws_h = 1.0f / hy.inv_ws_h;
-            KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16, dim3(work4, batch), dim3(256), 0, st, hy, reinterpret_cast<const uint4*>(wp("head.wh16")));
+            const int hp = kpb_env_int("KPB_HEAD_PERSIST", 15);     // row groups per persistent workgroup (0: r03's one-group form)
+            if (hp > 0 && H % 4 == 0)
+                KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16p, dim3(cdiv(W / 32, HP_TILES) * cdiv(H / 4, hp), batch), dim3(256), 0, st, hy,
+                           reinterpret_cast<const uint4*>(wp("head.wh16")), hp);
+            else if (kpb_env_int("KPB_HEAD_WHOLE", 1))
+                KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16<1>, dim3(work4, batch), dim3(256), 0, st, hy, reinterpret_cast<const uint4*>(wp("head.wh16")));
+            else
+                KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16<0>, dim3(work4, batch), dim3(256), 0, st, hy, reinterpret_cast<const uint4*>(wp("head.wh16")));
         } else
             KPB_LAUNCH(ctx, "alike_head_dense", alike_head_hyb, dim3(work4, batch), dim3(256), 0, st, hy);
     } else {

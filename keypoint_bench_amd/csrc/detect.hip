@@ -37,6 +37,7 @@ struct NmsArgs {
     int ccap, border;
     float cmin;         // a confirmed maximum counts when its score is > cmin (threshold / min_score of the detection)
     int H, W, r, tiles_y, tiles_x, sweep, max_local;
+    int xcd_map;        // kpb_xcd_tile (nms_sweep_r)
 };
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_sweep(NmsArgs a)
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     __shared__ float clocal[CLOCAL];
     __shared__ int s_nc, s_cbase;
 
-    const int img = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const kpb_tile3 wg = kpb_xcd_tile(a.xcd_map);      // neighbouring tiles (they re-read each other's 2R halo) on one XCD's L2
+    const int img = wg.y, tile = wg.x, tid = threadIdx.x, lane = tid & 63;
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int ntiles = a.tiles_x * a.tiles_y;
     int* tcur = a.tchg_cur + (size_t)img * ntiles;
@@ -950,6 +952,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.clist = p.clist; a.ccount = p.ccount; a.ccap = p.ccap; a.border = p.border; a.cmin = p.cmin;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s;
+        a.xcd_map = (kpb_env_int("KPB_XCD_MAP", 7) >> 2) & 1;
         // with the sparse tail behind it, sweep 0 stops after three in-tile rounds (99.6 % of an ALIKE map is settled by
         // then; measured: 3 rounds 2.26 + 1.49 ms, 5 rounds 2.75 + 1.39 ms, 2 rounds 1.87 + 2.52 ms per 512 images)
         // with top-K pruning the tail is cheap and two rounds are the optimum (r02: 2 rounds 2.19 + <0.2 ms, 3 rounds 2.57 + <0.2 ms;

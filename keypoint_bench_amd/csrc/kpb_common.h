@@ -23,6 +23,23 @@ __device__ __forceinline__ void kpb_halves32(float v, float& lo, float& hi)
     lo = __uint_as_float(r[0]);
     hi = __uint_as_float(r[1]);
 }
+// XCD-aware tile map (r04).  Workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest, then y, then z), so the
+// linear ids L and L + 8 share an L2 and L, L + 1 never do: two tiles that are neighbours in the image -- and re-read each other's
+// halo lines -- meet in eight DIFFERENT L2s under the plain blockIdx map.  Here XCD k works through the k-th contiguous eighth of the
+// tile space in raster order, so a tile's neighbours run on the same XCD at about the same time and the halo lines are L2 hits.
+// Placement is speed only (HIP promises none): any bijection of the tile space is correct.  Identity when the tile count is not a
+// multiple of 8.
+struct kpb_tile3 { int x, y, z; };
+__device__ __forceinline__ kpb_tile3 kpb_xcd_tile(int enable)
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    unsigned L = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (enable && (total & 7u) == 0u) L = (L & 7u) * (total >> 3) + (L >> 3);
+    kpb_tile3 t;
+    t.x = (int)(L % gx); t.y = (int)((L / gx) % gy); t.z = (int)(L / (gx * gy));
+    return t;
+}
+
 // maximum of two NON-NEGATIVE floats (ReLU outputs, magnitudes) on the integer ALU: their bit patterns order like the values, and no
 // canonicalising `v_max_f32 x, x` is spent on operands the compiler cannot prove quiet (8 % of block 1's vector instructions).
 // PRECONDITION: sign bit clear (callers pass fabsf(x) or a ReLU output: v_max_f32(-0, +0) = +0) -- a -0.0 or a negative value would
