@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void conv3x3_k(ConvArgs a)
 //   agg2 (16 -> 16, no bias) + ReLU on x2 -> a2, and a2 . w_score -> S2 (the group's share of the score logit).
 // All three are implicit GEMMs on v_mfma_f32_16x16x32_f16 with every fp32 operand split into two half-precision terms (x = hi +
 // lo, hi = f16(x), lo = f16(x - hi), to nearest; three MFMAs per product, the lo.lo term dropped: relative 2^-22 per product, fp32
-// accumulation -- see alike_head_f16):
+// accumulation -- see alike_head_f16p):
 //   M = 16 consecutive pixels of an image row, N = the 16 output channels, K = 32 per MFMA = four 16-byte pieces, piece
 //   kidx = (tap, channel octet): lane (row i, group g) of k-block kb supplies piece 4 kb + g.  The input tile sits in LDS
 //   already split, as planes of 16-byte slots [hi | lo][octet][position]: a lane's operand is ONE ds_read_b128 per plane, 16
@@ -1209,252 +1209,20 @@ __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
     hi = __builtin_bit_cast(h8v, a); lo = __builtin_bit_cast(h8v, b);
 }
 
-// Pipelined stores: the 16 row stores of one half-tile are issued BETWEEN the matrix instructions of the other half (and the
-// second half's between the NEXT tile's loads and feature arithmetic), two per MFMA, instead of 32 in one burst at the end: a
-// wave that meets a full store queue then stalls for one queue slot while its MFMAs run, not for the drain of a whole 8 KB
-// burst with the SIMD's other waves doing the same.  (r02 measured the alternatives this replaced -- stores in one burst, four
-// waves per SIMD, no early line touch, plain instead of streaming line touch: all slower; they are gone from the source.)
-// Operand range (r03): the fine features are scaled by the power of two that fits the image's bound (HybArgs), for free --
-// the scale rides on the agg1 weights staged in LDS and on the two y weights of the a2 interpolation; the projected coarse
-// rows are brought to the same units when the strips are built, and the accumulator is scaled back before the store.
-template <int WHOLE>
-__global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4* __restrict__ wh16 /* [2 hi/lo][kb 2][nh 2][h 2][n 32] x 8 halves */)
-{
-    __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];         // [hi/lo][(kb, nh, h, n)]: one 16-byte fragment per lane and MFMA
-    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];      // [h][cin][j]:  agg1 weight of output 8h+j, times the feature scale
-    __shared__ __attribute__((aligned(16))) float Ws[2 * 16];         // [h][s]:       score weight of chan(s,h), divided by the feature scale
-    __shared__ __attribute__((aligned(16))) float V3[4][NT3 * ESTRIDE];
-    __shared__ __attribute__((aligned(16))) float V4[4][NT4 * ESTRIDE];
-    // the a2 pixels the workgroup's four rows x 128 pixels tap: <= 4 source rows x 66 columns x 16 channels, fetched ONCE (each
-    // output row used to fetch its two a2 rows itself).  A pixel's four 16-byte slots are XOR-swizzled by (column / 4) % 4 so
-    // that the 8 columns a ds_read_b128 lane group touches (columns 4 apart would share banks) fall on distinct banks.
-    constexpr int A2R = 4, A2C = 66;
-    __shared__ __attribute__((aligned(16))) float4 A2[A2R * A2C * 4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int p = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
-    // (r03 measured an XCD-contiguous workgroup map -- blockIdx.x % 8 shares an L2, so give each XCD a contiguous run of row
-    // groups: FETCH_SIZE fell from 1.73x to 1.05x of the algorithmic reads and the kernel took 2.5 % LONGER, as in r02: it is
-    // not bound by what it fetches.  Not kept.)
-    const int wmap = blockIdx.x;
-    const int ef = cm_exp_of(fmaxf(__uint_as_float(a.amax_x1[b]) * a.l1_agg1, __uint_as_float(a.amax_a2[b])));
-    const float scf = cm_scale_of(ef), unf = cm_unscale_of(ef);
-    const float cacc = scf * a.ws_h, unacc = unf * a.inv_ws_h;       // units of the accumulator, and back
-    Bh[0][tid] = wh16[tid];
-    Bh[1][tid] = wh16[256 + tid];
-    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j] * scf; }
-    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)] * unf; }
-
-    const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
-    const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
-    const float* E3 = a.E3 + (size_t)b * H8 * W8 * ESTRIDE;
-    const float* E4 = a.E4 + (size_t)b * H32 * W32 * ESTRIDE;
-    const float sy2 = (float)(H2 - 1) / (float)(a.H - 1), sx2 = (float)(W2 - 1) / (float)(a.W - 1);
-    const float sy8 = (float)(H8 - 1) / (float)(a.H - 1), sx8 = (float)(W8 - 1) / (float)(a.W - 1);
-    const float sy32 = (float)(H32 - 1) / (float)(a.H - 1), sx32 = (float)(W32 - 1) / (float)(a.W - 1);
-    const int tiles_per_row = a.W / 32, segs_per_row = (tiles_per_row + SEG_TILES - 1) / SEG_TILES;
-    int y, xs;
-    bool live;
-    {   // workgroup -> four consecutive rows of one 128-pixel column band (see alike_head_hyb)
-        const int w = wmap, band = w % segs_per_row, grp = w / segs_per_row;
-        y = 4 * grp + wv; xs = band * (32 * SEG_TILES);
-        live = y < a.H;
-        if (!live) { y = 0; xs = 0; }
-    }
-    const int ntile = live ? min(SEG_TILES, tiles_per_row - xs / 32) : 0;
-    const int tb3 = (int)(sx8 * (float)xs), tb4 = (int)(sx32 * (float)xs);
-    f32x16 pend = {0};                  // channels 32..63 of the previous tile, stored under the next tile's feature arithmetic
-    f32x16 pendB = {0};                 // WHOLE: pend = pixels R(r) of the previous tile, pendB = pixels R(r) + 4, all 64 channels each
-    float* pend_d = nullptr;
-    bool have = false;
-    // A wave's vector-memory operations complete IN ORDER (loads and stores share one counter): a load issued behind a store
-    // waits for that store's acknowledgement, which under 40 GB of streaming writes takes microseconds.  So every tile's ten
-    // 16-byte loads are issued a whole tile early -- before ANY store of the tile in front of it -- and are older than every
-    // store they could queue behind.
-    struct TileIn { float4 x1lo, x1hi; };
-    auto fetch = [&](int t, TileIn& in) {
-        const int x = xs + 32 * t + p;
-        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
-        in.x1lo = *reinterpret_cast<const float4*>(a.x1 + pix * 8); in.x1hi = *reinterpret_cast<const float4*>(a.x1 + pix * 8 + 4);
-    };
-    TileIn tin[2];
-    if (ntile > 0) fetch(0, tin[0]);
-    const int r_lo = (int)(sy2 * (float)(4 * (wmap / segs_per_row))), c_lo = (int)(sx2 * (float)((wmap % segs_per_row) * (32 * SEG_TILES)));
-    StripRegs<NT3> sr3;
-    StripRegs<NT4> sr4;
-    {   // every load of the prologue goes out before the first LDS store waits for one of them
-        float4 v[(A2R * A2C * 4 + 255) / 256];
-#pragma unroll
-        for (int k = 0; k < (A2R * A2C * 4 + 255) / 256; ++k) {
-            const int i = tid + 256 * k, slot = i & 3, pc = i >> 2, col = pc % A2C, row = pc / A2C;
-            const int gr = min(r_lo + row, H2 - 1), gc = min(c_lo + col, W2 - 1);
-            v[k] = i < A2R * A2C * 4 ? *reinterpret_cast<const float4*>(a2 + ((size_t)gr * W2 + gc) * 16 + 4 * slot) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        strip_load<NT3>(sr3, E3, H8, W8, sy8, y, tb3, lane);
-        strip_load<NT4>(sr4, E4, H32, W32, sy32, y, tb4, lane);
-#pragma unroll
-        for (int k = 0; k < (A2R * A2C * 4 + 255) / 256; ++k) {
-            const int i = tid + 256 * k, slot = i & 3, pc = i >> 2, col = pc % A2C;
-            if (i < A2R * A2C * 4) A2[pc * 4 + (slot ^ ((col >> 2) & 3))] = v[k];
-        }
-    }
-    strip_store<NT3>(sr3, V3[wv], H8, sy8, y, lane, cacc);       // (a wave with no live row has y = 0: harmless)
-    strip_store<NT4>(sr4, V4[wv], H32, sy32, y, lane, cacc);
-    __syncthreads();
-    auto body = [&](auto first_tag, const int t, const TileIn& cur, TileIn& nxt) {
-        constexpr bool FIRST = decltype(first_tag)::value;       // the segment's first tile has no predecessor whose stores are pending
-        const int x0 = xs + 32 * t, x = x0 + p;
-        const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
-        if (t + 1 < ntile) fetch(t + 1, nxt);
-        const float4 x1lo = cur.x1lo, x1hi = cur.x1hi;
-        Up8Taps taps;
-        {   // up8ch_load's arithmetic, the four taps read from the band in LDS
-            const float fy = sy2 * (float)y, fx = sx2 * (float)x;
-            const int gy0 = (int)fy, gx0 = (int)fx;
-            const int ry0 = gy0 - r_lo, rx0 = gx0 - c_lo;
-            const int ry1 = ry0 + (gy0 < H2 - 1 ? 1 : 0), rx1 = rx0 + (gx0 < W2 - 1 ? 1 : 0);
-            taps.ly = fy - (float)gy0; taps.lx = fx - (float)gx0;
-            const int s0 = (rx0 >> 2) & 3, s1 = (rx1 >> 2) & 3;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                taps.t[4 * q + 0] = A2[(ry0 * A2C + rx0) * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 1] = A2[(ry0 * A2C + rx1) * 4 + ((2 * h + q) ^ s1)];
-                taps.t[4 * q + 2] = A2[(ry1 * A2C + rx0) * 4 + ((2 * h + q) ^ s0)]; taps.t[4 * q + 3] = A2[(ry1 * A2C + rx1) * 4 + ((2 * h + q) ^ s1)];
-            }
-        }
-        if constexpr (!FIRST) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(WHOLE ? pend[r] : pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
-        }
-        int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
-        asm volatile("" : "+v"(z));
-        const uint4* Bhz = &Bh[0][0] + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
-        float f[16];                            // the fine features, times scf
-        {   // group 0: relu(agg1 . x1), outputs 8h..8h+7 (ALike.py:147)
-            const float v[8] = {x1lo.x, x1lo.y, x1lo.z, x1lo.w, x1hi.x, x1hi.y, x1hi.z, x1hi.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 w0 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8 + 4]);
-                f[0] = fmaf(v[c], w0.x, f[0]); f[1] = fmaf(v[c], w0.y, f[1]); f[2] = fmaf(v[c], w0.z, f[2]); f[3] = fmaf(v[c], w0.w, f[3]);
-                f[4] = fmaf(v[c], w1.x, f[4]); f[5] = fmaf(v[c], w1.y, f[5]); f[6] = fmaf(v[c], w1.z, f[6]); f[7] = fmaf(v[c], w1.w, f[7]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
-        }
-        up8ch_lerp(taps, f + 8, scf);      // ALike.py:151
-
-        const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
-        const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;     // tile's first strip row
-        const int t3 = (int)fx3 - tb3 - rb3, t4 = (int)fx4 - tb4 - rb4;
-        const float lx3 = fx3 - (float)(int)fx3, lx4 = fx4 - (float)(int)fx4;
-        const float* v3 = V3[wv] + rb3 * ESTRIDE;
-        const float* v4 = V4[wv] + rb4 * ESTRIDE;
-
-        float sc = 0.0f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 w = *reinterpret_cast<const float4*>(&Wsz[h * 16 + 4 * q]);
-            sc = fmaf(f[4 * q], w.x, sc); sc = fmaf(f[4 * q + 1], w.y, sc); sc = fmaf(f[4 * q + 2], w.z, sc); sc = fmaf(f[4 * q + 3], w.w, sc);
-        }
-        sc = kpb_sum32(sc);
-        sc += (1.0f - lx3) * v3[t3 * ESTRIDE + 64] + lx3 * v3[(t3 + 1) * ESTRIDE + 64];
-        sc += (1.0f - lx4) * v4[t4 * ESTRIDE + 64] + lx4 * v4[(t4 + 1) * ESTRIDE + 64];
-        if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
-
-        float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
-        f32x16 acc0 = {0}, acc1 = {0};
-        h8v ahi[2], alo[2];
-        split8(f, ahi[0], alo[0]);
-        split8(f + 8, ahi[1], alo[1]);
-        float w3[3], w4[2];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) { const int k = 2 * s + h; w3[s] = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f); }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) { const int k = 2 * s + h; w4[s] = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f); }
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {        // 16-deep block kb = fine group kb; lane (p, h) supplies channels 8h..8h+7 of it
-            const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[kb], b0h, acc0, 0, 0, 0);     // small terms first
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0l, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[kb], b0h, acc0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], v3[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], v4[(2 * s + h) * ESTRIDE + p], acc0, 0, 0, 0);
-        // operands of the second half first, so that nothing but MFMAs and stores remains to be interleaved
-        h8v b1h[2], b1l[2];
-        float t3b[3], t4b[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { b1h[kb] = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 1) * 2 + h) * 32 + p]); b1l[kb] = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 1) * 2 + h) * 32 + p]); }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) t3b[s] = v3[(2 * s + h) * ESTRIDE + 32 + p];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) t4b[s] = v4[(2 * s + h) * ESTRIDE + 32 + p];
-        // D[row = pixel][col = out channel]: lane holds channel p (+32), rows (r&3) + 8*(r>>2) + 4h.  Streaming stores: 40 GB
-        // per launch that nothing re-reads before they have left every cache
-        int r = 0;
-        // (the lane-dependent part of a row's address, 4 h rows and channel p, sits in ONE base pointer: the 16 row offsets are
-        // compile-time constants that fold into the store instructions instead of costing a 64-bit add each)
-        float* dl = d + (4 * h) * 64 + p;
-        // WHOLE (r04): the stores interleaved here are the previous tile's pixels R + 4 (pendB), 256 contiguous bytes each
-        float* pb = pend_d + 4 * 64;
-#define ST0_1() { if constexpr (WHOLE) { if constexpr (!FIRST) __builtin_nontemporal_store(pendB[r], pb + ((r & 3) + 8 * (r >> 2)) * 64); } \
-                  else __builtin_nontemporal_store(acc0[r] * unacc, dl + ((r & 3) + 8 * (r >> 2)) * 64); ++r; }
-#define ST0_2() { ST0_1() ST0_1() }
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[0], b1h[0], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1l[0], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[0], b1h[0], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[1], b1h[1], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1l[1], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[1], b1h[1], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[0], t3b[0], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[1], t3b[1], acc1, 0, 0, 0); ST0_2()
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[2], t3b[2], acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[0], t4b[0], acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[1], t4b[1], acc1, 0, 0, 0);
-#undef ST0_2
-        // pin the interleaving (the scheduler otherwise gathers the stores into one burst behind the last MFMA)
-        if constexpr (!(WHOLE && FIRST)) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-        }
-        if constexpr (WHOLE) {
-            // One store instruction = one pixel = 256 contiguous bytes: v_permlane32_swap trades the upper half of acc0[r] (pixel
-            // R + 4, channels 0..31) for the lower half of acc1[r] (pixel R, channels 32..63).  The r03 form wrote two 128-byte half
-            // pixels per instruction and the other halves a tile later; the memory system takes whole pixels 5 % faster beside the
-            // head's loads (scripts/hbm_store_patterns.hip, profiles/r04_hbm_store_patterns.txt: 5.50 -> 5.77 TB/s).
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[q] * unacc), __float_as_uint(acc1[q] * unacc), false, false);
-                pend[q] = __uint_as_float(sw[0]); pendB[q] = __uint_as_float(sw[1]);
-            }
-            pend_d = d + lane;
-        } else {
-            pend = acc1; pend_d = dl + 32;
-        }
-        have = true;
-    };
-    if (ntile > 0) body(std::true_type{}, 0, tin[0], tin[1]);
-    for (int t = 1; t < ntile; t += 2) {        // two tiles per trip: the two input sets swap roles, no register copies
-        body(std::false_type{}, t, tin[1], tin[0]);
-        if (t + 1 < ntile) body(std::false_type{}, t + 1, tin[0], tin[1]);
-    }
-    if (have) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(WHOLE ? pend[r] : pend[r] * unacc, pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
-        if (WHOLE) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pendB[r], pend_d + ((r & 3) + 8 * (r >> 2) + 4) * 64);
-        }
-    }
-}
-
+// How a tile's stores leave (alike_head_f16p below).  r02: the row stores are issued BETWEEN matrix instructions, two per MFMA, and
+// the rest under the NEXT tile's loads and feature arithmetic, instead of 32 in one burst at the end: a wave that meets a full store
+// queue then stalls for one queue slot while its MFMAs run, not for the drain of a whole 8 KB burst with the SIMD's other waves doing
+// the same (stores in one burst, four waves per SIMD, no early line touch, plain instead of streaming line touch: all measured
+// slower and gone).  r03: the fine features are scaled by the power of two that fits the image's bound (HybArgs), for free -- the
+// scale rides on the agg1 weights staged in LDS and on the two y weights of the a2 interpolation; the projected coarse rows carry the
+// same units, and the accumulator is scaled back before the store; the a2 pixels' four 16-byte slots are XOR-swizzled by
+// (column / 4) % 4 in LDS so that the 8 columns a ds_read_b128 lane group touches fall on distinct banks.  r04: one store instruction
+// = one whole pixel = 256 contiguous bytes -- v_permlane32_swap trades the upper half of acc0[r] (pixel R + 4, channels 0..31) for
+// the lower half of acc1[r] (pixel R, channels 32..63); r03 wrote two 128-byte half pixels per instruction and the other halves a
+// tile later.  Alone that is worth 5 % to the memory system beside loads (scripts/hbm_store_patterns.hip,
+// profiles/r04_hbm_store_patterns.txt: 5.50 -> 5.77 TB/s) and 0.4 % to r03's one-group kernel (profiles/r04_ab_knobs.txt).
 // ------------------------------------------------------------------------------------------------ head, persistent form (r04)
-// r03's stamps (profiles/r03_head_stamps.txt): a workgroup of alike_head_f16 lives 45.5 k cycles, 18.6 k of them in a prologue that
+// r03's stamps (profiles/r03_head_stamps.txt): a workgroup of r03's one-group kernel (alike_head_f16: four rows x 128 pixels, deleted) lived 45.5 k cycles, 18.6 k of them in a prologue that
 // stores nothing -- 27 loads per wave queued behind the other workgroups' stores, strips built, a barrier -- for four tiles per wave.
 // Here a workgroup is PERSISTENT down a 64-pixel column band: it walks `groups_per_wg` row groups (4 rows, one per wave, two 32-pixel
 // tiles each) and everything the NEXT groups need arrives while the current one computes:
@@ -1469,7 +1237,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16(HybArgs a, const uint4*
 //     tracking would put a full wait in front of the first ring read after every request.
 // Ring capacities: a group g computes while rows up to group g + 2 arrive; those span at most floor(11 s) + 2 source rows for a
 // vertical scale s = (Hs - 1) / (H - 1) < 1/2, 1/8, 1/32: 7, 3, 2 -- inside 8, 4, 4, so a request never lands on a row in use.
-// LDS 42.6 KB (r03: 52.9), three workgroups per CU as before; whole-pixel stores (alike_head_f16<1>).
+// LDS 50.8 KB with the x1 slots (r03: 52.9), three workgroups per CU as before; whole-pixel stores (see above).
 constexpr int HP_TILES = 2, HP_BW = 32 * HP_TILES;
 constexpr int HP_A2C = 34, HP_A2R = 8, HP_A2S = HP_A2C * 4;                   // a2 ring: rows x 16-byte slots (136 per row)
 constexpr int HP_NT3 = 10, HP_NT4 = 5, HP_ER = 4;                             // raw E3 / E4 rings: rows x band columns x ESTRIDE
@@ -1534,7 +1302,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
             for (int j = 0; j < (HP_A2S + 63) / 64; ++j, ++u)
                 if ((u & 3) == wv) {
                     const int q = 64 * j + ln;
-                    if (q < HP_A2S) {       // LDS position q of the row holds slot (q & 3) ^ swizzle of pixel q >> 2 (bank spread, see alike_head_f16)
+                    if (q < HP_A2S) {       // LDS position q of the row holds slot (q & 3) ^ swizzle of pixel q >> 2 (bank spread, see above)
                         const int col = q >> 2, sl = (q & 3) ^ ((col >> 2) & 3), gc = min(c_lo + col, W2 - 1);
                         hp_dma16(a2 + ((size_t)r * W2 + gc) * 16 + 4 * sl, &A2r[(r & (HP_A2R - 1)) * HP_A2S + 64 * j]);
                     }
@@ -1562,7 +1330,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         e4next = max(e4next, h4 + 1);
     };
 
-    f32x16 pend = {0}, pendB = {0};     // the previous tile, whole pixels: pend = pixels R(r), pendB = pixels R(r) + 4 (alike_head_f16<1>)
+    f32x16 pend = {0}, pendB = {0};     // the previous tile, whole pixels: pend = pixels R(r), pendB = pixels R(r) + 4
     float* pend_d = nullptr;
     // x1 arrives by LDS-DMA too, TWO tiles ahead, one 1 KB instruction per tile and wave: lane (p, h) brings half h of pixel p to
     // slot 32 h + p.  With no load left that returns to registers, the only waits of the walk are `s_waitcnt vmcnt(63)` at tile
@@ -1972,14 +1740,14 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     ConvArgs c;
     if (h16) {
         Block1HArgs hb{b1, reinterpret_cast<const uint4*>(wp("b1c1.pairs")), reinterpret_cast<const uint4*>(wp("b1c2.pairs")),
-                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), wmax_x1, kpb_env_int("KPB_XCD_MAP", 7) & 1};
+                       k.at("b1c1.inv_ws"), k.at("b1c2.inv_ws"), k.at("b1c1.l1"), k.at("b1c1.bmax"), wmax_x1, 0};       // XCD-aware map: +4 % on block 1 (not bound by its halo re-reads), off
         KPB_LAUNCH(ctx, "alike_block1", alike_block1_h, dim3(cdiv(W, B1_TW), cdiv(H, B1H_TH), batch), dim3(256), 0, st, hb);
         KPB_LAUNCH(ctx, "amax_reduce", amax_reduce, dim3(batch), dim3(256), 0, st, wmax_x1, nw1, amax_x1);
         // block2 @ H/2 (ALike.py:139-140) + agg2, fused; it hands block 3 the 4 x 4 max-pool of its output (141)
         Block2Args b2{p1, x2, a2, S2, p2, reinterpret_cast<const uint4*>(wp("b2c1.h16")), reinterpret_cast<const uint4*>(wp("b2c2.h16")),
                       reinterpret_cast<const uint4*>(wp("agg2.h16")), wp("b2c1.b"), wp("b2c2.bsum"), wp("head.ws") + 16, H / 2, W / 2,
                       k.at("b2c1.inv_ws"), k.at("b2c2.inv_ws"), k.at("agg2.inv_ws"), k.at("b2c1.l1"), k.at("b2c1.bmax"), k.at("b2c2.l1"), k.at("b2ds.l1"),
-                      k.at("b2c2.bsummax"), amax_x1, wmax_a2, (kpb_env_int("KPB_XCD_MAP", 7) >> 1) & 1};
+                      k.at("b2c2.bsummax"), amax_x1, wmax_a2, 1};     // XCD-aware map: -5 % (profiles/r04_ab_knobs.txt)
         KPB_LAUNCH(ctx, "alike_block2", alike_block2, dim3(cdiv(W / 2, 32), cdiv(H / 2, 8), batch), dim3(256), 0, st, b2);
         KPB_LAUNCH(ctx, "amax_reduce", amax_reduce, dim3(batch), dim3(256), 0, st, wmax_a2, nw2, amax_a2);
         // blocks 3 and 4 @ H/8, H/32 (141-144) on conv_mfma_h: conv1 carries the identity branch ds(pooled input) as 32 / 64 more
@@ -2047,14 +1815,11 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         const int work4 = cdiv(H, 4) * cdiv(W / 32, SEG_TILES);     // four consecutive rows of one 128-pixel column band per workgroup
         if (h16) {
             hy.l1_agg1 = k.at("agg1.l1"); hy.inv_ws_h = k.at("head.inv_ws"); hy.ws_h = 1.0f / hy.inv_ws_h;
-            const int hp = kpb_env_int("KPB_HEAD_PERSIST", 15);     // row groups per persistent workgroup (0: r03's one-group form)
-            if (hp > 0 && H % 4 == 0)
-                KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16p, dim3(cdiv(W / 32, HP_TILES) * cdiv(H / 4, hp), batch), dim3(256), 0, st, hy,
-                           reinterpret_cast<const uint4*>(wp("head.wh16")), hp);
-            else if (kpb_env_int("KPB_HEAD_WHOLE", 1))
-                KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16<1>, dim3(work4, batch), dim3(256), 0, st, hy, reinterpret_cast<const uint4*>(wp("head.wh16")));
-            else
-                KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16<0>, dim3(work4, batch), dim3(256), 0, st, hy, reinterpret_cast<const uint4*>(wp("head.wh16")));
+            // row groups per persistent workgroup: 30 (15: +1-2 %, 40 / 60: the same, 120: +1 %; profiles/r04_ab_knobs.txt); H is a
+            // multiple of 32 (kpb_net_forward checks), so every group has its four rows
+            const int hp = 30;
+            KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16p, dim3(cdiv(W / 32, HP_TILES) * cdiv(H / 4, hp), batch), dim3(256), 0, st, hy,
+                       reinterpret_cast<const uint4*>(wp("head.wh16")), hp);
         } else
             KPB_LAUNCH(ctx, "alike_head_dense", alike_head_hyb, dim3(work4, batch), dim3(256), 0, st, hy);
     } else {
@@ -2185,7 +1950,7 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         const float* hw = bl.get("head.w", {dim + 1, dim});
         transpose(hw, 64, 64, tmp); ws.put("head.wT", tmp);
         ws.put_raw("head.ws", hw + 64 * 64, 64);
-        // split-f16 fragments of the fine-group rows (alike_head_f16): [hi/lo][kb][nh][h][n][j] halves,
+        // split-f16 fragments of the fine-group rows (alike_head_f16p): [hi/lo][kb][nh][h][n][j] halves,
         // value = head.w[o = 32 nh + n][c = 16 kb + 8 h + j]; hi = f16(w), lo = f16(w - hi), to nearest
         // (rows 0..63 x channels 0..31: the part this pack carries sets its power-of-two scale)
         float hmax = 0.0f;

@@ -952,7 +952,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.clist = p.clist; a.ccount = p.ccount; a.ccap = p.ccap; a.border = p.border; a.cmin = p.cmin;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s;
-        a.xcd_map = (kpb_env_int("KPB_XCD_MAP", 7) >> 2) & 1;
+        a.xcd_map = 1;      // -1 % (profiles/r04_ab_knobs.txt)
         // with the sparse tail behind it, sweep 0 stops after three in-tile rounds (99.6 % of an ALIKE map is settled by
         // then; measured: 3 rounds 2.26 + 1.49 ms, 5 rounds 2.75 + 1.39 ms, 2 rounds 1.87 + 2.52 ms per 512 images)
         // with top-K pruning the tail is cheap and two rounds are the optimum (r02: 2 rounds 2.19 + <0.2 ms, 3 rounds 2.57 + <0.2 ms;

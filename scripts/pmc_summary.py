@@ -37,7 +37,7 @@ for k in names:
 # HBM traffic per launch for the kernels bench.py can name (MI355X_MICROARCH.md, "HBM": FETCH_SIZE and
 # WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes -> doubled; WRITE_SIZE exact).
 import json
-PROF = {"alike_head_hyb": "alike_head_dense", "alike_head_f16": "alike_head_dense", "alike_block1_h": "alike_block1", "alike_block2": "alike_block2",
+PROF = {"alike_head_hyb": "alike_head_dense", "alike_head_f16p": "alike_head_dense", "alike_block1_h": "alike_block1", "alike_block2": "alike_block2",
         "match_approx": "match_approx_min", "nms_tail<6>": "nms_tail", "alike_head<false>": "alike_head_score", "alike_score_lin": "alike_head_score",
         "alike_block1": "alike_block1", "nms_sweep_r<6>": "nms_sweep", "match_tile": "match_tile",
         "select_topk": "select_topk", "sample_bilinear": "sample_bilinear", "alike_desc_at": "alike_desc_at"}
