@@ -1817,7 +1817,9 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             hy.l1_agg1 = k.at("agg1.l1"); hy.inv_ws_h = k.at("head.inv_ws"); hy.ws_h = 1.0f / hy.inv_ws_h;
             // row groups per persistent workgroup: 30 (15: +1-2 %, 40 / 60: the same, 120: +1 %; profiles/r04_ab_knobs.txt); H is a
             // multiple of 32 (kpb_net_forward checks), so every group has its four rows
-            const int hp = 30;
+            // -- as long as that leaves about two rounds of workgroups for the chip's 768 slots: a single image walks 2 groups per workgroup
+            const int bands_ = cdiv(W / 32, HP_TILES), groups_ = H / 4;
+            const int hp = std::max(2, std::min(30, (int)(((long long)bands_ * groups_ * batch) / 1536)));
             KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16p, dim3(cdiv(W / 32, HP_TILES) * cdiv(H / 4, hp), batch), dim3(256), 0, st, hy,
                        reinterpret_cast<const uint4*>(wp("head.wh16")), hp);
         } else

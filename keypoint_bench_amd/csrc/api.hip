@@ -34,7 +34,7 @@ extern "C" __attribute__((visibility("default"))) void kpb_ctx_destroy(kpb_ctx* 
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (kpb_buf* b : {&ctx->ws_nms_state, &ctx->ws_nms_map, &ctx->ws_nms_list, &ctx->ws_cand, &ctx->ws_match, &ctx->ws_misc})
+    for (kpb_buf* b : {&ctx->ws_nms_state, &ctx->ws_nms_map, &ctx->ws_nms_list, &ctx->ws_cand, &ctx->ws_match, &ctx->ws_misc, &ctx->ws_sel})
         if (b->p) (void)hipFree(b->p);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->det_state && ctx->det_state_free) ctx->det_state_free(ctx->det_state);

@@ -699,6 +699,8 @@ struct SelArgs {
     int H, W, border, top_k, kpad;
     float threshold, min_score;
     int signed_map;              // the NMS working map keeps confirmed maxima negated
+    int* chunk_cnt;              // [B][nchunks] two-phase form (small batches): select_scan has left chunk c's candidates at
+    int nchunks;                 //   cand[c * SEL_CHUNK ...] and their number here; null: select_topk scans the map itself
 };
 
 __device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned long long* src, int n,
@@ -733,25 +735,19 @@ __device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned l
     if (threadIdx.x == 0) a.out_n[img] = base;
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
+constexpr int SEL_VPT = 16, SEL_CHUNK = SEL_THREADS * SEL_VPT;
+
+// Border mask and raster-order compaction of map > threshold over pixels [p_begin, p_end) of one image, by the whole workgroup:
+// candidates go to cand[out_base ...] as (key << 32) | ~index; returns their number.  Sixteen consecutive pixels per thread and
+// round (four 16-byte loads in flight before the first use): 19 rounds of load latency + block scan per 480x640 image where four
+// pixels per thread took 75.
+__device__ __forceinline__ int scan_chunks(const SelArgs& a, const float* map, unsigned long long* cand, int p_begin, int p_end, int out_base,
+                                           unsigned long long* wsum)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem);   // [kpad]
-    __shared__ unsigned long long wsum[SEL_WAVES];
-    __shared__ unsigned hist[256];
-    __shared__ unsigned s_prefix, s_krem;
-
-    const int img = blockIdx.x, tid = threadIdx.x;
-    const int P = a.H * a.W;
-    const float* map = a.map + (size_t)img * P;
-    unsigned long long* cand = a.cand + (size_t)img * P;
+    const int tid = threadIdx.x, P = a.H * a.W;
     const int bx = min(max(a.border, 0), a.W), by = min(max(a.border, 0), a.H);
-
-    // A2 + A3: border mask and raster-order compaction of map > threshold.  Sixteen consecutive pixels per thread and
-    // round (four 16-byte loads in flight before the first use): 19 rounds of load latency + block scan per 480x640 image
-    // where four pixels per thread took 75.
     int n = 0;
-    constexpr int VPT = 16;
+    constexpr int VPT = SEL_VPT;
     const bool vec = ((P & 3) == 0) && ((reinterpret_cast<uintptr_t>(map) & 15) == 0);
     float vn[VPT];                  // the next round's pixels are requested before this round's block scan (one load latency hidden per round)
     auto fetch = [&](int c0) {
@@ -768,13 +764,13 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
             }
         }
     };
-    fetch(0);
-    for (int c0 = 0; c0 < P; c0 += SEL_THREADS * VPT) {
+    fetch(p_begin);
+    for (int c0 = p_begin; c0 < p_end; c0 += SEL_THREADS * VPT) {
         const int i0 = c0 + tid * VPT;
         float v[VPT];
 #pragma unroll
         for (int j = 0; j < VPT; ++j) v[j] = vn[j];
-        if (c0 + SEL_THREADS * VPT < P) fetch(c0 + SEL_THREADS * VPT);
+        if (c0 + SEL_THREADS * VPT < p_end) fetch(c0 + SEL_THREADS * VPT);
         if (a.signed_map) {     // confirmed maxima are stored negated; at the fixed point nothing else is alive, and pixels the
                                 // top-K pruning of nms_tail left unresolved (positive) are by construction not among the top_k
 #pragma unroll
@@ -789,13 +785,64 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
             if (++col == a.W) { col = 0; ++row; }
         }
         unsigned long long tot;
-        int pos = n + (int)block_scan((unsigned long long)__popc(pred), wsum, tot);
+        int pos = out_base + n + (int)block_scan((unsigned long long)__popc(pred), wsum, tot);
 #pragma unroll
         for (int j = 0; j < VPT; ++j)
             if ((pred >> j) & 1u) cand[pos++] = ((unsigned long long)f2key(v[j]) << 32) | (0xFFFFFFFFu - (unsigned)(i0 + j));
         n += (int)tot;
     }
-    __syncthreads();
+    return n;
+}
+
+// Two-phase form, phase 1 (r04): one workgroup per SEL_CHUNK pixels and image.  select_topk is one workgroup per image -- right
+// when hundreds of images fill the chip, 129 us of one CU's latency (19 dependent rounds) for the single map `detection` hands
+// over on the drop-in path (profiles/r04_single_pair_latency.txt).
+__global__ __launch_bounds__(SEL_THREADS) void select_scan(SelArgs a)
+{
+    __shared__ unsigned long long wsum[SEL_WAVES];
+    const int img = blockIdx.y, c = blockIdx.x, P = a.H * a.W;
+    const int n = scan_chunks(a, a.map + (size_t)img * P, a.cand + (size_t)img * P, c * SEL_CHUNK, min((c + 1) * SEL_CHUNK, P), c * SEL_CHUNK, wsum);
+    if (threadIdx.x == 0) a.chunk_cnt[(size_t)img * a.nchunks + c] = n;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* sel = reinterpret_cast<unsigned long long*>(smem);   // [kpad]
+    __shared__ unsigned long long wsum[SEL_WAVES];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_krem;
+
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int P = a.H * a.W;
+    const float* map = a.map + (size_t)img * P;
+    unsigned long long* cand = a.cand + (size_t)img * P;
+
+    // A2 + A3: border mask and raster-order compaction of map > threshold
+    int n = 0;
+    if (a.chunk_cnt) {
+        // two-phase form: the scan ran as select_scan on (nchunks x batch) workgroups; here the chunks' lists are closed up into one
+        // raster-ordered list at the front of cand.  Every move goes LEFT (a chunk never holds more than its SEL_CHUNK pixels), so
+        // a block-wide step may read, synchronise, write: its destination ends where the next step's source begins at the latest.
+        const int* cc = a.chunk_cnt + (size_t)img * a.nchunks;
+        for (int c = 0; c < a.nchunks; ++c) {
+            const int cnt = cc[c];
+            const unsigned long long* src = cand + (size_t)c * SEL_CHUNK;
+            if (n != c * SEL_CHUNK)
+                for (int j0 = 0; j0 < cnt; j0 += SEL_THREADS) {
+                    const int j = j0 + tid;
+                    const unsigned long long v = j < cnt ? src[j] : 0ull;
+                    __syncthreads();
+                    if (j < cnt) cand[n + j] = v;
+                    __syncthreads();
+                }
+            n += cnt;
+        }
+        __syncthreads();
+    } else {
+        n = scan_chunks(a, map, cand, 0, P, 0, wsum);
+        __syncthreads();
+    }
 
     if (n <= a.top_k) {  // raster order kept (extracter.py:217)
         emit(a, img, cand, n, wsum);
@@ -1093,6 +1140,12 @@ int det_select(kpb_ctx* ctx, const DetState& d)
     s.kpad = d.prm.top_k >= d.H * d.W ? 0 : next_pow2(d.prm.top_k);
     s.threshold = d.prm.threshold; s.min_score = d.prm.min_score;
     s.signed_map = (d.prm.nms_dist >= 1 && d.prm.nms_dist <= 8) ? 1 : 0;
+    s.chunk_cnt = nullptr; s.nchunks = cdiv(d.H * d.W, SEL_CHUNK);
+    if (d.batch < 64 && s.nchunks > 1) {       // too few images to fill the chip with one workgroup each: scan in (chunks x batch) workgroups first
+        if (int rc = kpb_reserve(ctx, ctx->ws_sel, (size_t)d.batch * s.nchunks * sizeof(int))) return rc;
+        s.chunk_cnt = static_cast<int*>(ctx->ws_sel.p);
+        KPB_LAUNCH(ctx, "select_scan", select_scan, dim3(s.nchunks, d.batch), dim3(SEL_THREADS), 0, ctx->stream, s);
+    }
     KPB_LAUNCH(ctx, "select_topk", select_topk, dim3(d.batch), dim3(SEL_THREADS), (size_t)s.kpad * sizeof(unsigned long long),
                        ctx->stream, s);
     KPB_HIP(ctx, hipGetLastError());

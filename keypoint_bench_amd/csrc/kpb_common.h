@@ -140,6 +140,7 @@ struct kpb_ctx {
     kpb_buf ws_cand;        // [batch][H*W] uint64 candidate list (key<<32 | ~idx)
     kpb_buf ws_match;       // per-tile row/column minima
     kpb_buf ws_misc;
+    kpb_buf ws_sel;         // [batch][chunks] candidate counts of the two-phase selection (small batches)
     int* host_flags = nullptr;  // pinned, for status read-back
     // state of the last kpb_detect(sync=0), owned by detect.hip
     void* det_state = nullptr;

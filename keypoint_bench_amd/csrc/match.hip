@@ -597,7 +597,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
     int* ci = rj + nr;
     // prefilter on the matrix cores + exact refinement (see match_prep): C a multiple of 32 up to 256, at least two slots per row and column
     static const int prefilter = kpb_env_int("KPB_MATCH_PREFILTER", 1);
-    const bool pre = prefilter && (C % 32 == 0) && C <= 256 && tiles_i >= 2 && tiles_j >= 2 && (reinterpret_cast<uintptr_t>(d0_dev) % 16 == 0) &&
+    // ... and a batch that fills the chip (KPB_MATCH_PREFILTER: 0 never, 1 = default: from 8 pairs, 2 always -- the tests' way to the prefilter with one pair): for a handful of pairs the prefilter's five dependent launches are LATENCY (a single
+    // 1000 x 1000 pair: 0.30 ms with it, 0.175 ms on match_tile alone -- profiles/r04_single_pair_latency.txt); both give the same bits
+    const bool pre = prefilter && (batch >= 8 || prefilter == 2) && (C % 32 == 0) && C <= 256 && tiles_i >= 2 && tiles_j >= 2 && (reinterpret_cast<uintptr_t>(d0_dev) % 16 == 0) &&
                      (reinterpret_cast<uintptr_t>(d1_dev) % 16 == 0);
     const int* only = nullptr;
     if (pre) {

@@ -77,6 +77,30 @@ def test_detection_full_size_golden_and_batched():
         np.testing.assert_array_equal(kps[b, :nb, 2].cpu().numpy(), maps[b].ravel()[ii])
 
 
+@pytest.mark.parametrize("top_k,thr", [(1000, 0.0), (100000, 0.0), (50, 0.9)])
+def test_selection_forms_agree_one_workgroup_per_image_and_two_phase(top_k, thr):
+    """Below 64 images the raster-order candidate scan runs as (chunks x images) workgroups (select_scan) and one workgroup per image
+    only closes the chunk lists up and selects; from 64 images on that workgroup scans the map itself.  The same 72 maps through
+    both forms (one call of 72, calls of 9): identical rows, counts and flat indices; N <= top_k (raster order) and N > top_k."""
+    from keypoint_bench_amd.utils.extracter import detection_batch
+    H, W = 96, 416                                          # 39 936 pixels: three chunks of 16 384, the last one short
+    maps = np.stack([synthetic.score_uniform(700 + i, H, W) if i % 3 else synthetic.score_smooth(700 + i, H, W) for i in range(72)])
+    p = dict(nms_dist=3, threshold=thr, border_dist=5, top_k=top_k, min_score=0.0)
+    t = torch.from_numpy(maps)[:, None].to(_dev())
+    k1, i1, n1 = detection_batch(t, p)                      # >= 64 images: one workgroup per image
+    for b0 in range(0, 72, 9):
+        k2, i2, n2 = detection_batch(t[b0:b0 + 9], p)       # < 64: two-phase
+        assert torch.equal(n1[b0:b0 + 9], n2)
+        for b in range(9):
+            nb = int(n2[b])
+            assert nb > 0
+            assert torch.equal(k1[b0 + b, :nb], k2[b, :nb]) and torch.equal(i1[b0 + b, :nb], i2[b, :nb])
+    import oracle
+    for b in (0, 1, 71):
+        want, _ = oracle.detection(maps[b], p)
+        assert_kps_equal(k1[b, : int(n1[b])].cpu().numpy(), want, min(top_k, H * W), "image %d" % b)
+
+
 def test_detection_on_reference_alike_score_maps():
     from keypoint_bench_amd.utils.extracter import detection
     g = load_golden("alike_t.npz")

@@ -6,7 +6,10 @@ of this GPU-initialised process):
                          alike_head_hyb on v_mfma_f32_32x32x2_f32, lg_flash in fp32 -- instead of the split-f16 matrix forms.
                          The same goldens, the same tolerances: this is the companion figure's code path (bench.py variant_fp32).
   KPB_MATCH_PREFILTER=0  the exact float64 tile kernel on every pair (the path a pair with out-of-range or non-finite
-                         descriptors takes under the default).
+                         descriptors takes under the default, and -- r04 -- every call with fewer than 8 pairs: for them the
+                         prefilter's five dependent launches are latency, not throughput).
+  KPB_MATCH_PREFILTER=2  the MFMA prefilter + exact refinement for ANY number of pairs: the single-pair match goldens and the fuzz
+                         then run on the path the batched pipelines take from 8 pairs up.
 
 Experiment knobs of r02 (KPB_HEAD_MAP / PIPE / WPS / PF, KPB_*_MT1, KPB_GEMM_*, KPB_BLOCK*_H16, KPB_CONV_H16) lost their
 non-default branches: the measured choice is the code."""
@@ -49,6 +52,11 @@ def test_strict_fp32_kernels_pass_the_goldens():
 @pytest.mark.timeout(900)
 def test_exact_match_kernel_without_the_prefilter_passes_the_goldens():
     _child({"KPB_MATCH_PREFILTER": "0"}, ["tests/test_gpu_match.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_pipeline.py"])
+
+
+@pytest.mark.timeout(900)
+def test_prefilter_forced_on_single_pairs_passes_the_goldens():
+    _child({"KPB_MATCH_PREFILTER": "2"}, ["tests/test_gpu_match.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_range.py", "tests/test_gpu_pipeline.py"])
 
 
 def test_no_other_environment_knob_selects_a_kernel():
