@@ -102,6 +102,10 @@ int kpb_detect(kpb_ctx* ctx, const float* score_dev, int batch, int H, int W,
  * point within the enqueued sweeps, runs more sweeps and rewrites the outputs.  Returns 0 (outputs were
  * final), 1 (outputs were rewritten: redo whatever consumed them), or KPB_E_NEGATIVE. */
 int kpb_detect_check(kpb_ctx* ctx);
+/* Keypoint counts of the last COMPLETED kpb_detect (sync = 1, or sync = 0 + kpb_detect_check), as host integers: the kernels leave
+ * them in pinned host memory, so the `N` of the reference's `detection(...) -> Tensor[N, 3]` (utils/extracter.py:217-221) costs no
+ * second device read-back.  out_n_host [batch] is host memory; batch must be the batch of that call. */
+int kpb_detect_counts(kpb_ctx* ctx, int32_t* out_n_host, int batch);
 
 /* ---- M1: utils/matcher.py:221-226 descriptor sampling (grid_sample, align_corners=True) -----
  * desc_dev: [batch] maps of C channels, Hd x Wd, element strides (sb, sc, sh, sw) so both NCHW and
@@ -119,6 +123,11 @@ int kpb_sample(kpb_ctx* ctx, const float* desc_dev, int batch, int C, int Hd, in
 int kpb_match(kpb_ctx* ctx, const float* d0_dev, const float* d1_dev, int batch, int C, int max_n,
               int max_m, const int32_t* n_dev, const int32_t* m_dev, const kpb_match_params* params,
               int32_t* out_pairs_dev, double* out_dist_dev, int32_t* out_k_dev);
+
+/* Match counts of the last kpb_match as host integers: waits for the context's stream, then hands over what match_finalize left in
+ * pinned host memory -- the `K` of skimage's `matches` array [K, 2] (utils/matcher.py:227-230) without a device read-back of its own.
+ * out_k_host [batch] is host memory; batch must be the batch of that call. */
+int kpb_match_counts(kpb_ctx* ctx, int32_t* out_k_host, int batch);
 
 /* ---- M3: utils/matcher.py:231-233 row gather ---------------------------------------------------
  * out[b][i][:] = src[b][idx[b][i*idx_stride + idx_col]][:] for i < k[b].  cols floats per row. */

@@ -46,6 +46,8 @@ SIGNATURES = {
     "kpb_detect": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, ctypes.POINTER(DetectParams), c_void_p, c_void_p,
                            c_void_p, c_int]),
     "kpb_detect_check": (c_int, [c_void_p]),
+    "kpb_detect_counts": (c_int, [c_void_p, c_void_p, c_int]),
+    "kpb_match_counts": (c_int, [c_void_p, c_void_p, c_int]),
     "kpb_sample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64,
                            c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "kpb_match": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

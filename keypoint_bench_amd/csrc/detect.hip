@@ -699,6 +699,8 @@ struct SelArgs {
     int H, W, border, top_k, kpad;
     float threshold, min_score;
     int signed_map;              // the NMS working map keeps confirmed maxima negated
+    const int* lastchg; const int* negflag;      // NMS status words of the image (null without NMS) ...
+    int* host_status;            // ... copied with the count to pinned host memory: [B][3] = (lastchg, negflag, n), or null
     int* chunk_cnt;              // [B][nchunks] two-phase form (small batches): select_scan has left chunk c's candidates at
     int nchunks;                 //   cand[c * SEL_CHUNK ...] and their number here; null: select_topk scans the map itself
 };
@@ -732,7 +734,14 @@ __device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned l
         }
         base += (int)tot;
     }
-    if (threadIdx.x == 0) a.out_n[img] = base;
+    if (threadIdx.x == 0) {
+        a.out_n[img] = base;
+        if (a.host_status) {
+            a.host_status[3 * img + 0] = a.lastchg ? a.lastchg[img] : 0;
+            a.host_status[3 * img + 1] = a.negflag ? a.negflag[img] : 0;
+            a.host_status[3 * img + 2] = base;
+        }
+    }
 }
 
 constexpr int SEL_VPT = 16, SEL_CHUNK = SEL_THREADS * SEL_VPT;
@@ -861,15 +870,29 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
             if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned krem = s_krem, cum = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (cum + hist[d] >= krem) break;
-                cum += hist[d];
+        // the digit d whose bin holds the krem-th largest key: the largest d with  sum(hist[d..255]) >= krem  (digit 0 if none).
+        // Suffix sums by 256 threads (a wave scan and four wave totals); r03 let thread 0 walk the bins one LDS read at a time --
+        // up to 256 dependent reads in each of the four passes, most of select_topk's 60 us on a single map.
+        {
+            const unsigned krem = s_krem;
+            unsigned suf = 0, own = 0;
+            if (tid < 256) {
+                own = hist[255 - tid];                      // thread t looks at digit 255 - t: prefix sums over t = suffix sums over d
+                suf = own;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(suf, o, 64); if ((tid & 63) >= o) suf += v; }
+                if ((tid & 63) == 63) wsum[tid >> 6] = suf;
             }
-            s_krem = krem - cum;
-            s_prefix = prefix | ((unsigned)d << shift);
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = 0; w < (tid >> 6); ++w) suf += (unsigned)wsum[w];
+                const unsigned before = suf - own;          // keys in the bins above this digit
+                const int d = 255 - tid;
+                if ((before < krem && suf >= krem) || (d == 0 && suf < krem)) {
+                    s_krem = krem - before;
+                    s_prefix = prefix | ((unsigned)d << shift);
+                }
+            }
         }
         __syncthreads();
     }
@@ -1140,6 +1163,14 @@ int det_select(kpb_ctx* ctx, const DetState& d)
     s.kpad = d.prm.top_k >= d.H * d.W ? 0 : next_pow2(d.prm.top_k);
     s.threshold = d.prm.threshold; s.min_score = d.prm.min_score;
     s.signed_map = (d.prm.nms_dist >= 1 && d.prm.nms_dist <= 8) ? 1 : 0;
+    s.lastchg = d.prm.nms_dist > 0 ? d.plan.lastchg : nullptr; s.negflag = d.prm.nms_dist > 0 ? d.plan.negflag : nullptr;
+    if (ctx->host_det_cap < 3 * d.batch) {
+        if (ctx->host_det) KPB_HIP(ctx, hipHostFree(ctx->host_det));
+        ctx->host_det = nullptr; ctx->host_det_cap = 0;
+        KPB_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_det), (size_t)3 * d.batch * sizeof(int), hipHostMallocDefault));
+        ctx->host_det_cap = 3 * d.batch;
+    }
+    s.host_status = ctx->host_det;
     s.chunk_cnt = nullptr; s.nchunks = cdiv(d.H * d.W, SEL_CHUNK);
     if (d.batch < 64 && s.nchunks > 1) {       // too few images to fill the chip with one workgroup each: scan in (chunks x batch) workgroups first
         if (int rc = kpb_reserve(ctx, ctx->ws_sel, (size_t)d.batch * s.nchunks * sizeof(int))) return rc;
@@ -1211,7 +1242,11 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
     int rerun = 0;
     for (;;) {
         int pending = 0, neg = 0;
-        if (int rc = nms_status(ctx, d.plan, d.batch, d.sweeps_run, pending, neg)) return rc;
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // select_topk has written every image's status to pinned host memory
+        for (int b = 0; b < d.batch; ++b) {
+            pending += (ctx->host_det[3 * b] >= d.sweeps_run);
+            neg |= ctx->host_det[3 * b + 1];
+        }
         if (neg) {
             ctx->det_pending = 0;
             return kpb_fail(ctx, KPB_E_NEGATIVE, "kpb_detect: negative scores are outside this path's contract "
@@ -1228,6 +1263,17 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
         if (int rc = det_select(ctx, d)) return rc;
     }
     ctx->det_pending = 0;
-    if (rerun) KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return rerun;   // 1: the outputs were rewritten after extra sweeps
+    return rerun;   // 1: the outputs were rewritten after extra sweeps (the loop's last synchronisation covers them)
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_detect_counts(kpb_ctx* ctx, int32_t* out_n_host, int batch)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_detect_counts: null context");
+    if (!out_n_host || batch <= 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: bad argument");
+    if (ctx->det_pending) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: the last kpb_detect has not been completed (kpb_detect_check)");
+    if (!ctx->det_state || !ctx->host_det) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: no detection has run");
+    const DetState& d = det_state(ctx);
+    if (batch != d.batch) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: the last kpb_detect had %d images, not %d", d.batch, batch);
+    for (int b = 0; b < batch; ++b) out_n_host[b] = ctx->host_det[3 * b + 2];
+    return KPB_OK;
 }

@@ -142,6 +142,12 @@ struct kpb_ctx {
     kpb_buf ws_misc;
     kpb_buf ws_sel;         // [batch][chunks] candidate counts of the two-phase selection (small batches)
     int* host_flags = nullptr;  // pinned, for status read-back
+    // kpb_detect: select_topk leaves (last sweep that changed, negative flag, keypoint count) of every image HERE -- pinned host
+    // memory the kernel writes directly -- so that completing a detection is one stream synchronisation, not two copies back
+    int* host_det = nullptr;
+    int host_det_cap = 0;
+    int* host_match = nullptr;  // likewise: match_finalize leaves every pair's match count here (kpb_match_counts)
+    int host_match_cap = 0, host_match_n = 0;
     // state of the last kpb_detect(sync=0), owned by detect.hip
     void* det_state = nullptr;
     void (*det_state_free)(void*) = nullptr;

@@ -220,6 +220,7 @@ struct FinArgs {
     const double* rpart_s; const int* rpart_j; const double* cpart_s; const int* cpart_i;
     const int* n; const int* m;
     int* out_pairs; double* out_dist; int* out_k;
+    int* host_k;        // pinned host mirror of out_k (kpb_match_counts), written by the kernel
     int max_n, max_m, tiles_i, tiles_j, cross_check;
     double max_distance;
 };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(FIN_THREADS) void match_finalize(FinArgs a)
         }
         base += tot;
     }
-    if (tid == 0) a.out_k[b] = base;
+    if (tid == 0) { a.out_k[b] = base; a.host_k[b] = base; }
 }
 
 // ------------------------------------------------------------------------------------------------ M2, prefilter
@@ -581,8 +582,17 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
     if (!prm || !out_k_dev || batch <= 0 || C <= 0 || max_n < 0 || max_m < 0)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->host_match_cap < batch) {
+        if (ctx->host_match) KPB_HIP(ctx, hipHostFree(ctx->host_match));
+        ctx->host_match = nullptr; ctx->host_match_cap = 0;
+        KPB_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_match), (size_t)batch * sizeof(int), hipHostMallocDefault));
+        ctx->host_match_cap = batch;
+    }
+    ctx->host_match_n = batch;
     if (max_n == 0 || max_m == 0) {   // nothing can match; mirror the empty result
         KPB_HIP(ctx, hipMemsetAsync(out_k_dev, 0, (size_t)batch * sizeof(int), ctx->stream));
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // (a kernel of an earlier call may still be writing the mirror)
+        for (int b = 0; b < batch; ++b) ctx->host_match[b] = 0;
         return KPB_OK;
     }
     if (!d0_dev || !d1_dev || !out_pairs_dev) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: null buffer");
@@ -641,10 +651,22 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
     }
     MatchArgs a{only, d0_dev, d1_dev, n_dev, m_dev, rs, rj, cs, ci, C, max_n, max_m, tiles_i, tiles_j};
     KPB_LAUNCH(ctx, "match_tile", match_tile, dim3(tiles_j, tiles_i, batch), dim3(MATCH_THREADS), 0, ctx->stream, a);
-    FinArgs f{rs, rj, cs, ci, n_dev, m_dev, out_pairs_dev, out_dist_dev, out_k_dev,
+    FinArgs f{rs, rj, cs, ci, n_dev, m_dev, out_pairs_dev, out_dist_dev, out_k_dev, ctx->host_match,
               max_n, max_m, tiles_i, tiles_j, prm->cross_check, prm->max_distance};
     KPB_LAUNCH(ctx, "match_finalize", match_finalize, dim3(batch), dim3(FIN_THREADS), (size_t)max_m * sizeof(int), ctx->stream, f);
     KPB_HIP(ctx, hipGetLastError());
+    return KPB_OK;
+}
+
+extern "C" __attribute__((visibility("default"))) int kpb_match_counts(kpb_ctx* ctx, int32_t* out_k_host, int batch)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_match_counts: null context");
+    if (!out_k_host || batch <= 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match_counts: bad argument");
+    if (!ctx->host_match || batch != ctx->host_match_n)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_match_counts: the last kpb_match had %d pairs, not %d", ctx->host_match_n, batch);
+    KPB_HIP(ctx, hipSetDevice(ctx->device));
+    KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < batch; ++b) out_k_host[b] = ctx->host_match[b];
     return KPB_OK;
 }
 

@@ -55,5 +55,8 @@ def detection_batch(score_map: torch.Tensor, params: dict = None, sync: bool = T
 
 def detection(score_map: torch.Tensor, params: dict = None):
     """utils/extracter.py:193-221.  score_map Bx1xHxW -> Nx3 (x, y, prob) of batch element 0."""
-    kps, _, n = detection_batch(score_map[:1], params, sync=True)
-    return kps[0, : int(n[0].item())].clone()
+    kps, _, _ = detection_batch(score_map[:1], params, sync=True)
+    ctx = Context.get(kps.device)
+    n = (ctypes.c_int32 * 1)()
+    ctx.check(ctx.lib.kpb_detect_counts(ctx.handle, n, 1))      # host integer left by the kernels: no second read-back (n[0].item())
+    return kps[0, : int(n[0])].clone()
