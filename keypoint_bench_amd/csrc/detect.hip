@@ -1217,7 +1217,10 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
     if (prm->nms_dist > 0) {
         if (int rc = kpb_reserve(ctx, ctx->ws_nms_map, (size_t)batch * P * sizeof(float))) return rc;
         d.cur = static_cast<float*>(ctx->ws_nms_map.p);
-        const int chunk = 6;
+        // tiled sweeps enqueued before the first look at the status: an ALIKE map is at its fixed point after 3-4 of them; a sweep
+        // with nothing to do still costs its launch (5 us each on the single map of the drop-in path), an early look costs a
+        // synchronisation -- 6 for batches (amortised), 4 when a few images are all there is
+        const int chunk = batch >= 16 ? 6 : 4;
         if (int rc = nms_open(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, chunk, d.sweeps_run)) return rc;
     }
     if (int rc = det_select(ctx, d)) return rc;

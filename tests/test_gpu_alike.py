@@ -48,6 +48,28 @@ def test_forward_full_size_against_reference_golden_and_oracle():
     np.testing.assert_allclose(desc[0].cpu().numpy(), do[0].numpy(), rtol=0, atol=ATOL_DESC)
 
 
+@pytest.mark.parametrize("dense", [True, False])
+def test_a_batch_that_fills_the_chip_and_a_single_image_take_different_launch_shapes_to_the_same_maps(dense):
+    """From 16 images on, block 4 runs on 16 x 16 tiles with two n-tiles per workgroup, the head walks up to 30 row groups per
+    persistent workgroup; a single image (the drop-in path) gets 8-row tiles with one n-tile and 2 groups per workgroup so that its
+    few workgroups spread over the chip.  Same arithmetic per output: the maps must agree to the last bit, and with the oracle."""
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.utils.matcher import sample_descriptors
+    imgs = np.stack([synthetic.image_pair(60 + i, 96, 160)[i & 1] for i in range(18)])
+    net = alike_t(dense_descriptors=dense).eval()
+    sb, db = net(torch.from_numpy(imgs).to(DEV))
+    pts = torch.rand((64, 2), device=DEV)
+    for i in (0, 7, 17):
+        s1, d1 = net(torch.from_numpy(imgs[i:i + 1]).to(DEV))
+        assert torch.equal(s1[0], sb[i])
+        if dense:
+            assert torch.equal(d1[0], db[i])
+        so, do = _oracle_forward(imgs[i])
+        np.testing.assert_allclose(sb[i, 0].cpu().numpy(), so[0, 0].numpy(), rtol=0, atol=ATOL_SCORE)
+        if dense:
+            np.testing.assert_allclose(db[i].cpu().numpy(), do[0].numpy(), rtol=0, atol=ATOL_DESC)
+
+
 @pytest.mark.parametrize("shape", [(512, 512), (480, 608), (96, 32), (32, 160), (224, 736)])
 @pytest.mark.parametrize("dense", [True, False])
 def test_forward_other_shapes_against_oracle(shape, dense):
