@@ -1245,12 +1245,17 @@ constexpr int HP_E3S = HP_NT3 * (ESTRIDE / 4), HP_E4S = HP_NT4 * (ESTRIDE / 4); 
 constexpr int HP_LA = 2;                                                      // row groups of look-ahead
 
 // 16 bytes per active lane from global memory to LDS at lds_wave_base + 16 * lane (wave-uniform base), no VGPR in between.
+template <bool NT = false>
 __device__ __forceinline__ void hp_dma16(const void* gsrc, const void* lds_wave_base)
 {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_wave_base));   // low half of a shared-aperture address = LDS offset
     unsigned keep;      // M0 is the compiler's (reserved register): saved and put back around the instruction that reads it
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(m0v), "v"(gsrc) : "memory");
+    if (NT)     // once-read stream: non-temporal (MI355X_MICROARCH.md, nt-weights: issued -> landed -18 %)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(m0v), "v"(gsrc) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(m0v), "v"(gsrc) : "memory");
 }
 
 __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4* __restrict__ wh16, int groups_per_wg)
@@ -1338,7 +1343,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
     // return of a register load one tile ahead allowed.
     auto fetch = [&](int y, int t, int slot) {
         const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + (xs + 32 * t + p);
-        hp_dma16(a.x1 + pix * 8 + 4 * h, &X1r[wv][slot][0]);
+        hp_dma16<true>(a.x1 + pix * 8 + 4 * h, &X1r[wv][slot][0]);        // read once: non-temporal (-0.4 %, profiles/r04_ab_knobs.txt)
     };
     // tile k of this wave's walk = (group g0 + k / ntile, tile k % ntile)
     if (g0 < g1) {
@@ -1361,6 +1366,8 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         const size_t pix = (size_t)b * a.H * a.W + (size_t)y * a.W + x;
         // this tile's x1 (requested two tiles = >= 65 operations ago) and every ring row of its group have landed once all but the
         // youngest 63 operations of the wave have completed; the first tiles of a walk have fewer behind them and wait for all
+        // (vmcnt(40) and vmcnt(24) here cost nothing either -- profiles/r04_ab_knobs.txt: the stores of the tile before are acknowledged
+        // within a tile's time, the walk is not waiting for the memory system)
         if (ktile < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
         const int slot = ktile & 1;
         const float4 x1lo = X1r[wv][slot][p], x1hi = X1r[wv][slot][32 + p];
