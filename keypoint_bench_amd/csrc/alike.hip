@@ -1358,6 +1358,21 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
     int U3 = 0, D3 = 0, U4 = 0, D4 = 0;        // float offsets of the two tapped ring rows inside E3r / E4r (offsets, not pointers: the reads stay ds_read)
     float hy3 = 0.f, ly3 = 0.f, hy4 = 0.f, ly4 = 0.f, hy3c = 0.f, ly3c = 0.f, hy4c = 0.f, ly4c = 0.f;
 
+    // The x taps of the coarse maps depend on the tile position only, not on the row group: the hat weights and their fractions are
+    // taken once per walk for both tiles (14 registers; the a2 tap offsets and the rest stay per tile -- hoisting everything spilled)
+    float w3t[HP_TILES][3], w4t[HP_TILES][2], lx3t[HP_TILES], lx4t[HP_TILES];
+#pragma unroll
+    for (int t = 0; t < HP_TILES; ++t) {
+        const int x0 = xs + 32 * t, x = x0 + p;
+        const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
+        const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;
+        const int t3 = (int)fx3 - tb3 - rb3, t4 = (int)fx4 - tb4 - rb4;
+        lx3t[t] = fx3 - (float)(int)fx3; lx4t[t] = fx4 - (float)(int)fx4;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) { const int kk = 2 * s + h; w3t[t][s] = kk == t3 ? 1.0f - lx3t[t] : (kk == t3 + 1 ? lx3t[t] : 0.0f); }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { const int kk = 2 * s + h; w4t[t][s] = kk == t4 ? 1.0f - lx4t[t] : (kk == t4 + 1 ? lx4t[t] : 0.0f); }
+    }
     int xso = xs;       // the band's first column, made opaque once per group: everything derived from x is invariant along the walk, and
                         // hoisted out of it the tap offsets and hat weights of both tiles held ~40 registers (spills)
     auto body = [&](auto first_tag, const int y, const int t, const int ny, const int nt) {
@@ -1416,7 +1431,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
         const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;
         const int t3 = (int)fx3 - tb3 - rb3, t4 = (int)fx4 - tb4 - rb4;
-        const float lx3 = fx3 - (float)(int)fx3, lx4 = fx4 - (float)(int)fx4;
+        const float lx3 = t == 0 ? lx3t[0] : lx3t[1], lx4 = t == 0 ? lx4t[0] : lx4t[1];
         const float *u3 = &E3r[0][0] + (U3 + rb3 * ESTRIDE + z), *d3 = &E3r[0][0] + (D3 + rb3 * ESTRIDE + z);
         const float *u4 = &E4r[0][0] + (U4 + rb4 * ESTRIDE + z), *d4 = &E4r[0][0] + (D4 + rb4 * ESTRIDE + z);
         // the y-interpolated coarse row at (strip row k, channel c), in the accumulator's units (channel 64: the score share, unscaled)
@@ -1441,9 +1456,9 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         split8(f + 8, ahi[1], alo[1]);
         float w3[3], w4[2];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) { const int k = 2 * s + h; w3[s] = k == t3 ? 1.0f - lx3 : (k == t3 + 1 ? lx3 : 0.0f); }
+        for (int s = 0; s < 3; ++s) w3[s] = t == 0 ? w3t[0][s] : w3t[1][s];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) { const int k = 2 * s + h; w4[s] = k == t4 ? 1.0f - lx4 : (k == t4 + 1 ? lx4 : 0.0f); }
+        for (int s = 0; s < 2; ++s) w4[s] = t == 0 ? w4t[0][s] : w4t[1][s];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const h8v b0h = __builtin_bit_cast(h8v, Bhz[((kb * 2 + 0) * 2 + h) * 32 + p]), b0l = __builtin_bit_cast(h8v, Bhz[256 + ((kb * 2 + 0) * 2 + h) * 32 + p]);
