@@ -144,7 +144,7 @@ def kernel_costs(B2, B, K, C, dense, sweeps):
     """Algorithmic (compulsory) FLOPs and HBM bytes PER LAUNCH of each kernel."""
     P = H * W
     c = {}
-    c["alike_block1"] = (2 * P * (27 * 8 + 72 * 8) * B2, P * (12 + 32) * B2)
+    c["alike_block1"] = (2 * P * (27 * 8 + 72 * 8) * B2, P * (12 + 32 + 8) * B2)      # image in, x1 out, and its 2 x 2 max-pool (P / 4 x 32 B) block 2 reads: DESIGN.md section 5
     c["conv3x3_b2c1"] = (2 * (P // 4) * 9 * 8 * 16 * B2, (P * 32 + (P // 4) * 64) * B2)
     c["conv3x3_b2c2"] = (2 * (P // 4) * (9 * 16 * 16 + 8 * 16) * B2, ((P // 4) * 64 + P * 32 + (P // 4) * 64) * B2)
     c["conv3x3_b3c1"] = (2 * (P // 64) * 9 * 16 * 32 * B2, ((P // 4) * 64 + (P // 64) * 128) * B2)
@@ -234,8 +234,8 @@ def workload_label(model, matcher):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (SURVEY 8d: at least 200 timed batches)")
+    ap.add_argument("--warmup", type=int, default=20, help="untimed steps before them (SURVEY 8d: 20)")
     ap.add_argument("--pairs-per-step", type=int, default=None, help="pairs per GPU per step (default: 256 ALIKE and XFeat [SURVEY 8d], 16 SuperPoint and DISK)")
     ap.add_argument("--sparse", action="store_true", help="keypoint-only descriptors (no dense 78.6 MB/img map)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
