@@ -36,6 +36,7 @@ extern "C" __attribute__((visibility("default"))) void kpb_ctx_destroy(kpb_ctx* 
     (void)hipStreamSynchronize(ctx->stream);
     for (kpb_buf* b : {&ctx->ws_nms_state, &ctx->ws_nms_map, &ctx->ws_nms_list, &ctx->ws_cand, &ctx->ws_match, &ctx->ws_misc, &ctx->ws_sel})
         if (b->p) (void)hipFree(b->p);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     if (ctx->host_det) (void)hipHostFree(ctx->host_det);
     if (ctx->host_match) (void)hipHostFree(ctx->host_match);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

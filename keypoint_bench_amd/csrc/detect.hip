@@ -1237,7 +1237,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
     DetState& d = det_state(ctx);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     if (d.prm.nms_dist == 0) {
-        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        KPB_HIP(ctx, kpb_wait_stream(ctx, d.batch < 16));
         ctx->det_pending = 0;
         return KPB_OK;
     }
@@ -1245,7 +1245,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
     int rerun = 0;
     for (;;) {
         int pending = 0, neg = 0;
-        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // select_topk has written every image's status to pinned host memory
+        KPB_HIP(ctx, kpb_wait_stream(ctx, d.batch < 16));        // select_topk has written every image's status to pinned host memory
         for (int b = 0; b < d.batch; ++b) {
             pending += (ctx->host_det[3 * b] >= d.sweeps_run);
             neg |= ctx->host_det[3 * b + 1];

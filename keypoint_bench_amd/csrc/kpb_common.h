@@ -146,6 +146,7 @@ struct kpb_ctx {
     // memory the kernel writes directly -- so that completing a detection is one stream synchronisation, not two copies back
     int* host_det = nullptr;
     int host_det_cap = 0;
+    hipEvent_t wait_ev = nullptr;   // kpb_wait_stream's completion marker
     int* host_match = nullptr;  // likewise: match_finalize leaves every pair's match count here (kpb_match_counts)
     int host_match_cap = 0, host_match_n = 0;
     // state of the last kpb_detect(sync=0), owned by detect.hip
@@ -177,6 +178,24 @@ inline int kpb_fail(kpb_ctx* ctx, int code, const char* fmt, ...)
             return kpb_fail(ctx, KPB_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
                             __FILE__, __LINE__);                                                       \
     } while (0)
+
+// Waits for everything enqueued on the context's stream.  small = the caller waits for a handful of images / one pair (the drop-in path):
+// a completion event is POLLED -- hipStreamSynchronize parks the thread and is woken tens of microseconds late, which is 5 % of a
+// single pair (0.73 -> 0.70 ms).  Batches keep hipStreamSynchronize: measured on one box (scripts/ab_lib.sh, three interleaved runs
+// each, profiles/r04_ab_knobs.txt), polling at the end of every 256-pair step held the chip at 18.00 ms per step where the parked
+// wait gives 17.7 -- with no gap at all between steps the chip sits at its sustained clock (the head 10.17 ms instead of 9.86).
+inline hipError_t kpb_wait_stream(kpb_ctx* ctx, bool small)
+{
+    if (!small) return hipStreamSynchronize(ctx->stream);
+    if (!ctx->wait_ev) {
+        const hipError_t e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipEventRecord(ctx->wait_ev, ctx->stream);
+    if (e != hipSuccess) return e;
+    while ((e = hipEventQuery(ctx->wait_ev)) == hipErrorNotReady) {}
+    return e;
+}
 
 inline int kpb_reserve(kpb_ctx* ctx, kpb_buf& b, size_t bytes)
 {

@@ -665,7 +665,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match_counts(kpb_ctx* 
     if (!ctx->host_match || batch != ctx->host_match_n)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_match_counts: the last kpb_match had %d pairs, not %d", ctx->host_match_n, batch);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
-    KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KPB_HIP(ctx, kpb_wait_stream(ctx, batch < 8));
     for (int b = 0; b < batch; ++b) out_k_host[b] = ctx->host_match[b];
     return KPB_OK;
 }
