@@ -136,6 +136,73 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
     }
 }
 
+// XFeat block1.0 (1 -> 4, 3x3) + block1.1 (4 -> 8, 3x3, stride 2) in one kernel (r04; XFeat.py:30-31): the 4-channel full-resolution map
+// (4.9 MB per image written by one kernel and read back by the next: 0.89 + 0.84 ms per 512 images) stays in LDS.  A workgroup owns
+// 8 x 32 outputs of block1.1 = 16 x 64 pixels (22.7 KB of LDS: seven workgroups per CU; 16 x 32 outputs, 43.7 KB, three per CU: 1.21 ms): it stages the 19 x 67 grey pixels they depend on, evaluates block1.0 + ReLU on the
+// 17 x 65 positions block1.1 taps (8 % more than it owns; positions outside the image are block1.1's zero padding, not block1.0 of
+// zero-padded grey), then block1.1 + ReLU, two outputs per thread.  Every output is accumulated in conv_valu_t's order -- bias, then
+// taps in (ky, kx, cin) order, an fma each, zero for a tap outside -- so the maps are bit for bit those of the two-kernel form.
+constexpr int XB_TH = 8, XB_TW = 32, XB_AH = 2 * XB_TH + 1, XB_AW = 2 * XB_TW + 1, XB_GH = XB_AH + 2, XB_GW = XB_AW + 2;
+__global__ __launch_bounds__(256) void xfeat_block1_01(const float* __restrict__ gray, float* __restrict__ out, const float* __restrict__ w0,
+                                                       const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       int H, int W)
+{
+    __shared__ float g[XB_GH * XB_GW];
+    __shared__ __attribute__((aligned(16))) float4 a1[XB_AH * XB_AW];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int H2 = H / 2, W2 = W / 2;
+    const int oy0 = blockIdx.y * XB_TH, ox0 = blockIdx.x * XB_TW;        // first output of the tile (half resolution)
+    const int ay0 = 2 * oy0 - 1, ax0 = 2 * ox0 - 1;                      // first block1.0 position block1.1 taps
+    const int gy0 = ay0 - 1, gx0 = ax0 - 1;                              // first grey pixel block1.0 taps
+    const float* gi = gray + (size_t)b * H * W;
+    for (int i = tid; i < XB_GH * XB_GW; i += 256) {
+        const int y = i / XB_GW, x = i - y * XB_GW, gy = gy0 + y, gx = gx0 + x;
+        g[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gi[(size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < XB_AH * XB_AW; i += 256) {
+        const int y = i / XB_AW, x = i - y * XB_AW, py = ay0 + y, px = ax0 + x;
+        float acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = b0[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float v = g[(y + ky) * XB_GW + x + kx];           // zero outside the image: block1.0's padding
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, w0[(ky * 3 + kx) * 8 + j], acc[j]);
+            }
+        const bool inside = py >= 0 && py < H && px >= 0 && px < W;
+        a1[i] = inside ? make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3])) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < XB_TH * XB_TW / 256; ++k) {
+        const int o = tid + 256 * k, ly = o / XB_TW, lx = o - ly * XB_TW;
+        const int oy = oy0 + ly, ox = ox0 + lx;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = b1[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 f = a1[(2 * ly + ky) * XB_AW + 2 * lx + kx];
+                const float v[4] = {f.x, f.y, f.z, f.w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(v[c], w1[((ky * 3 + kx) * 4 + c) * 8 + j], acc[j]);
+            }
+        if (oy < H2 && ox < W2) {
+            float* q = out + (((size_t)b * H2 + oy) * W2 + ox) * 8;
+            *reinterpret_cast<float4*>(q) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
+            *reinterpret_cast<float4*>(q + 4) = make_float4(relu(acc[4]), relu(acc[5]), relu(acc[6]), relu(acc[7]));
+        }
+    }
+}
+
 // SuperPoint conv1a (1 -> 64, 3x3, ReLU; SuperPoint.py:44): 16 lanes share a pixel, each lane keeps the 9 taps of its
 // 4 output channels in registers and walks down a column of pixels, so a wave store is 4 whole 256-byte pixels.
 __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block)
@@ -594,8 +661,15 @@ struct XFeatNet : kpb_net {
         KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P / 4 + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
         int rc;
         // block1 (XFeat.py:30-35) and the skip connection (27-28, 127)
-        if ((rc = conv("block1.0", gray, a1, batch, H, W))) return rc;
-        if ((rc = conv("block1.1", a1, b1, batch, H, W))) return rc;
+        {   // block1.0 + block1.1 fused: the 4-channel full-resolution map never reaches HBM (r04)
+            const Layer &l0 = L.at("block1.0"), &l1 = L.at("block1.1");
+            if (l0.mfma || l1.mfma || l0.cin != 1 || l0.cout != 4 || l0.ks != 3 || l0.stride != 1 || l1.cin != 4 || l1.cout != 8 || l1.ks != 3 || l1.stride != 2 ||
+                !relu_of.at("block1.0") || !relu_of.at("block1.1"))
+                return kpb_fail(ctx, KPB_E_INVALID, "XFeat block1.0 / block1.1: unexpected layer plan");
+            KPB_LAUNCH(ctx, "xf_block1.01", xfeat_block1_01, dim3(cdiv(W2, XB_TW), cdiv(H2, XB_TH), batch), dim3(256), 0, st, gray, b1,
+                       wp("block1.0.w"), wp("block1.0.b"), wp("block1.1.w"), wp("block1.1.b"), H, W);
+            (void)a1;
+        }
         if ((rc = conv("block1.2", b1, c1, batch, H2, W2))) return rc;
         // block1's last layer with the skip connection (AvgPool2d(4) -> Conv2d(1, 24, 1), XFeat.py:27-28, 127) added in its epilogue:
         // as a kernel of its own (r02: xf_skip_add, 1.12 ms per 512 images) it read x1 back and wrote it again
