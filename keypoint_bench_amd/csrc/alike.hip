@@ -1258,6 +1258,36 @@ __device__ __forceinline__ void hp_dma16(const void* gsrc, const void* lds_wave_
                      : "=&s"(keep) : "s"(m0v), "v"(gsrc) : "memory");
 }
 
+// The same with a wave-uniform base pointer (scalar registers) and a 32-bit per-lane BYTE offset: no 64-bit vector address arithmetic.
+__device__ __forceinline__ void hp_dma16s(const void* sbase, unsigned voff_bytes, const void* lds_wave_base)
+{
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_wave_base));
+    const unsigned long long sb = (unsigned long long)reinterpret_cast<uintptr_t>(sbase);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+    const unsigned long long sbu = ((unsigned long long)hi << 32) | lo;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(m0v), "v"(voff_bytes), "s"(sbu) : "memory");
+}
+
+#ifdef KPB_STAMPS
+// One-off instrumentation (scripts/head_stamps.sh builds with -DKPB_STAMPS; never in the product build): lane 0 of sampled waves leaves
+// s_memtime at phase boundaries of ONE row group in the middle of its walk.  [wave slot][32] shader-clock stamps.
+__device__ unsigned long long kpb_stamp_buf[256 * 32];
+__device__ unsigned kpb_stamp_slots;
+#define KPB_STAMP(i) do { if (stamp_on) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                          if (lane == 0) kpb_stamp_buf[stamp_slot * 32 + (i)] = t_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int kpb_debug_head_stamps(unsigned long long* out_host, unsigned* slots_host)
+{
+    if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(kpb_stamp_buf), sizeof(unsigned long long) * 256 * 32) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(slots_host, HIP_SYMBOL(kpb_stamp_slots), sizeof(unsigned)) != hipSuccess) return -1;
+    const unsigned zero = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(kpb_stamp_slots), &zero, sizeof(unsigned)) == hipSuccess ? 0 : -1;
+}
+#else
+#define KPB_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4* __restrict__ wh16, int groups_per_wg)
 {
     __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];
@@ -1299,39 +1329,48 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
     // rows [lo(G), hi(G)] of a source map that row group G reads (align_corners taps of its rows 4 G .. 4 G + 3)
     auto hi_row = [&](float s, int G, int Hs) { const int r = ui((int)(s * (float)(4 * G + 3))); return r + (r < Hs - 1 ? 1 : 0); };
     int a2next = ui((int)(sy2 * (float)(4 * g0))), e3next = ui((int)(sy8 * (float)(4 * g0))), e4next = ui((int)(sy32 * (float)(4 * g0)));
+    // per-lane byte offsets of the 1 KB request units inside a source row, once per walk (8 registers): LDS position q = 64 j + lane of
+    // an a2 ring row holds slot (q & 3) ^ swizzle of pixel q >> 2 (bank spread, see above); of an E ring row, 16-byte piece q % 17 of
+    // band column q / 17 (clamped to the map's last column)
+    unsigned offA[(HP_A2S + 63) / 64], off3[(HP_E3S + 63) / 64], off4[(HP_E4S + 63) / 64];
+#pragma unroll
+    for (int j = 0; j < (HP_A2S + 63) / 64; ++j) {
+        const int q = min(64 * j + lane, HP_A2S - 1), col = q >> 2, sl = (q & 3) ^ ((col >> 2) & 3), gc = min(c_lo + col, W2 - 1);
+        offA[j] = (unsigned)(gc * 16 + 4 * sl) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < (HP_E3S + 63) / 64; ++j) {
+        const int q = min(64 * j + lane, HP_E3S - 1), t = q / (ESTRIDE / 4), quad = q - t * (ESTRIDE / 4);
+        off3[j] = (unsigned)(min(tb3 + t, W8 - 1) * ESTRIDE + 4 * quad) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < (HP_E4S + 63) / 64; ++j) {
+        const int q = min(64 * j + lane, HP_E4S - 1), t = q / (ESTRIDE / 4), quad = q - t * (ESTRIDE / 4);
+        off4[j] = (unsigned)(min(tb4 + t, W32 - 1) * ESTRIDE + 4 * quad) * 4u;
+    }
     auto request = [&](const int G) {      // every row group G reads that has not been requested yet; 1 KB units dealt over the waves
-        int u = 0, ln = lane;
-        asm volatile("" : "+v"(ln));        // opaque: the per-lane source offsets are recomputed here, not hoisted out of the walk into ~25 registers
+        int u = 0;                          // (r04 stamps: with per-unit 64-bit vector addresses this took 2.6 k of a group's 27.8 k cycles)
         const int h2 = hi_row(sy2, G, H2), h3 = hi_row(sy8, G, H8), h4 = hi_row(sy32, G, H32);
-        for (int r = a2next; r <= h2; ++r)
+        for (int r = a2next; r <= h2; ++r) {
+            const float* row = a2 + (size_t)r * W2 * 16;
+#pragma unroll
             for (int j = 0; j < (HP_A2S + 63) / 64; ++j, ++u)
-                if ((u & 3) == wv) {
-                    const int q = 64 * j + ln;
-                    if (q < HP_A2S) {       // LDS position q of the row holds slot (q & 3) ^ swizzle of pixel q >> 2 (bank spread, see above)
-                        const int col = q >> 2, sl = (q & 3) ^ ((col >> 2) & 3), gc = min(c_lo + col, W2 - 1);
-                        hp_dma16(a2 + ((size_t)r * W2 + gc) * 16 + 4 * sl, &A2r[(r & (HP_A2R - 1)) * HP_A2S + 64 * j]);
-                    }
-                }
+                if ((u & 3) == wv && 64 * j + lane < HP_A2S) hp_dma16s(row, offA[j], &A2r[(r & (HP_A2R - 1)) * HP_A2S + 64 * j]);
+        }
         a2next = max(a2next, h2 + 1);
-        for (int r = e3next; r <= h3; ++r)
+        for (int r = e3next; r <= h3; ++r) {
+            const float* row = E3 + (size_t)r * W8 * ESTRIDE;
+#pragma unroll
             for (int j = 0; j < (HP_E3S + 63) / 64; ++j, ++u)
-                if ((u & 3) == wv) {
-                    const int q = 64 * j + ln;
-                    if (q < HP_E3S) {
-                        const int t = q / (ESTRIDE / 4), quad = q - t * (ESTRIDE / 4);
-                        hp_dma16(E3 + ((size_t)r * W8 + min(tb3 + t, W8 - 1)) * ESTRIDE + 4 * quad, &E3r[r & (HP_ER - 1)][64 * j * 4]);
-                    }
-                }
+                if ((u & 3) == wv && 64 * j + lane < HP_E3S) hp_dma16s(row, off3[j], &E3r[r & (HP_ER - 1)][64 * j * 4]);
+        }
         e3next = max(e3next, h3 + 1);
-        for (int r = e4next; r <= h4; ++r)
+        for (int r = e4next; r <= h4; ++r) {
+            const float* row = E4 + (size_t)r * W32 * ESTRIDE;
+#pragma unroll
             for (int j = 0; j < (HP_E4S + 63) / 64; ++j, ++u)
-                if ((u & 3) == wv) {
-                    const int q = 64 * j + ln;
-                    if (q < HP_E4S) {
-                        const int t = q / (ESTRIDE / 4), quad = q - t * (ESTRIDE / 4);
-                        hp_dma16(E4 + ((size_t)r * W32 + min(tb4 + t, W32 - 1)) * ESTRIDE + 4 * quad, &E4r[r & (HP_ER - 1)][64 * j * 4]);
-                    }
-                }
+                if ((u & 3) == wv && 64 * j + lane < HP_E4S) hp_dma16s(row, off4[j], &E4r[r & (HP_ER - 1)][64 * j * 4]);
+        }
         e4next = max(e4next, h4 + 1);
     };
 
@@ -1353,6 +1392,11 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
     }
     for (int G = g0; G < min(g0 + HP_LA, g1); ++G) request(G);
     int ktile = 0;
+#ifdef KPB_STAMPS
+    bool stamp_on = false;
+    unsigned stamp_slot = 0;
+    const bool stamp_wg = (blockIdx.x % 61) == 7 && (blockIdx.y % 16) == 3 && ntile == 2;
+#endif
 
     // per group and wave: the y taps of the raw coarse rows (strip_store's arithmetic, applied where the value is read)
     int U3 = 0, D3 = 0, U4 = 0, D4 = 0;        // float offsets of the two tapped ring rows inside E3r / E4r (offsets, not pointers: the reads stay ds_read)
@@ -1384,11 +1428,13 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         // (vmcnt(40) and vmcnt(24) here cost nothing either -- profiles/r04_ab_knobs.txt: the stores of the tile before are acknowledged
         // within a tile's time, the walk is not waiting for the memory system)
         if (ktile < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        KPB_STAMP(4 + 8 * t);
         const int slot = ktile & 1;
         const float4 x1lo = X1r[wv][slot][p], x1hi = X1r[wv][slot][32 + p];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: the request for two tiles ahead may overwrite it
         if (ny >= 0) fetch(ny, nt, slot);
         ++ktile;
+        KPB_STAMP(5 + 8 * t);
         Up8Taps taps;
         {
             const float fy = sy2 * (float)y, fx = sx2 * (float)x;
@@ -1409,6 +1455,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
 #pragma unroll
             for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(pend[r], pend_d + ((r & 3) + 8 * (r >> 2)) * 64);
         }
+        KPB_STAMP(6 + 8 * t);                   // taps read, first 16 stores of the previous tile issued
         int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
         asm volatile("" : "+v"(z));
         const uint4* Bhz = &Bh[0][0] + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
@@ -1448,6 +1495,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         sc += (1.0f - lx3) * (hy3 * u3[t3 * ESTRIDE + 64] + ly3 * d3[t3 * ESTRIDE + 64]) + lx3 * (hy3 * u3[(t3 + 1) * ESTRIDE + 64] + ly3 * d3[(t3 + 1) * ESTRIDE + 64]);
         sc += (1.0f - lx4) * (hy4 * u4[t4 * ESTRIDE + 64] + ly4 * d4[t4 * ESTRIDE + 64]) + lx4 * (hy4 * u4[(t4 + 1) * ESTRIDE + 64] + ly4 * d4[(t4 + 1) * ESTRIDE + 64]);
         if (h == 0) a.score[pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));
+        KPB_STAMP(7 + 8 * t);                   // features, score
 
         float* d = a.desc + ((size_t)b * a.H * a.W + (size_t)y * a.W + x0) * 64;
         f32x16 acc0 = {0}, acc1 = {0};
@@ -1470,6 +1518,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         for (int s = 0; s < 3; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w3[s], e3(2 * s + h, p), acc0, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], e4(2 * s + h, p), acc0, 0, 0, 0);
+        KPB_STAMP(8 + 8 * t);                   // split, first MFMA chain issued
         h8v b1h[2], b1l[2];
         float t3b[3], t4b[2];
 #pragma unroll
@@ -1501,19 +1550,34 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
             for (int g = 0; g < 8; ++g) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x040, 2, 0); }
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         }
+        KPB_STAMP(9 + 8 * t);                   // second MFMA chain + 16 interleaved stores issued
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc0[q] * unacc), __float_as_uint(acc1[q] * unacc), false, false);
             pend[q] = __uint_as_float(sw[0]); pendB[q] = __uint_as_float(sw[1]);
         }
         pend_d = d + lane;
+        KPB_STAMP(10 + 8 * t);                  // accumulators read, scaled, swapped
     };
 
     for (int g = g0; g < g1; ++g) {
+#ifdef KPB_STAMPS
+        stamp_on = false;
+        if (stamp_wg && g == g0 + 10) {       // one group in the middle of the walk
+            unsigned sl = 0;
+            if (lane == 0) sl = atomicAdd(&kpb_stamp_slots, 1u);
+            stamp_slot = __builtin_amdgcn_readfirstlane(sl);
+            stamp_on = stamp_slot < 256;
+        }
+#endif
+        KPB_STAMP(0);
         // this wave's ring requests for group g (two groups = at least two tiles old) have landed: same rule as a tile's x1
         if (ktile < 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        KPB_STAMP(1);
         __syncthreads();        // every wave has left group g - 1, every request for group g has landed
+        KPB_STAMP(2);
         if (g + HP_LA < g1) request(g + HP_LA);
+        KPB_STAMP(3);
         const int y = 4 * g + wv;
         {
             const float fy3 = sy8 * (float)y, fy4 = sy32 * (float)y;
@@ -1535,6 +1599,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
             if (g == g0) body(std::true_type{}, y, 0, ny, 0);
             else body(std::false_type{}, y, 0, ny, 0);
         }
+        KPB_STAMP(20);
     }
     if (g0 < g1) {
 #pragma unroll
