@@ -1002,6 +1002,8 @@ struct HybArgs {
     const unsigned* amax_x1; const unsigned* amax_a2;     // [B] float bits, written by blocks 1 and 2
     float l1_agg1;     // max over agg1's output channels of sum |w|
     float ws_h, inv_ws_h;      // power-of-two scale the head's weight fragments were packed with, and its reciprocal
+    const uint4* a1h16;        // alike_head_f16p: agg1's weights as MFMA A-operand fragments [hi / lo][64 lanes], scaled by 1 / inv_wa
+    float inv_wa;
 };
 
 constexpr int SEG_TILES = 4;            // a wave owns one 128-pixel row segment
@@ -1291,7 +1293,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_debug_head_stamps(unsi
 __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4* __restrict__ wh16, int groups_per_wg)
 {
     __shared__ __attribute__((aligned(16))) uint4 Bh[2][256];
-    __shared__ __attribute__((aligned(16))) float A1[2 * 8 * 8];
+    __shared__ __attribute__((aligned(16))) uint4 A1h[2][64];         // agg1 as MFMA A fragments [hi / lo][lane] (HybArgs::a1h16)
     __shared__ __attribute__((aligned(16))) float Ws[2 * 16];
     __shared__ __attribute__((aligned(16))) float4 A2r[HP_A2R * HP_A2S];
     __shared__ __attribute__((aligned(16))) float E3r[HP_ER][HP_NT3 * ESTRIDE];
@@ -1309,8 +1311,12 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
     const float cacc = uf(scf * a.ws_h), unacc = uf(unf * a.inv_ws_h);
     Bh[0][tid] = wh16[tid];
     Bh[1][tid] = wh16[256 + tid];
-    if (tid < 128) { const int j = tid & 7, c = (tid >> 3) & 7, hh = tid >> 6; A1[tid] = a.agg1[c * 16 + 8 * hh + j] * scf; }
-    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[16 * (s >> 3) + 8 * hh + (s & 7)] * unf; }
+    if (tid < 128) A1h[tid >> 6][tid & 63] = a.a1h16[tid];
+    // score weights in the lane's k order: group 0 = the agg1 accumulator's channels {0..3, 8..11} + 4 h, group 1 = 16 + 8 h + (s & 7)
+    if (tid < 32) { const int s = tid & 15, hh = tid >> 4; Ws[tid] = a.wsc[s < 8 ? (s < 4 ? s : s + 4) + 4 * hh : 16 + 8 * hh + (s & 7)] * unf; }
+    // x1 >= 0 is split at the image's own scale (amax_x1), the product is brought to the features' units on the accumulator
+    const int ex1 = cm_exp_of(__uint_as_float(a.amax_x1[b]));
+    const float sx1 = uf(cm_scale_of(ex1)), una1 = uf((cm_unscale_of(ex1) * scf) * a.inv_wa);      // (the two data-dependent powers of two first: their product is moderate)
 
     const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
     const float* a2 = a.a2 + (size_t)b * H2 * W2 * 16;
@@ -1458,20 +1464,21 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         KPB_STAMP(6 + 8 * t);                   // taps read, first 16 stores of the previous tile issued
         int z = 0;                              // opaque zero: keeps the tile-invariant LDS reads inside the loop
         asm volatile("" : "+v"(z));
-        const uint4* Bhz = &Bh[0][0] + z; const float* A1z = A1 + z; const float* Wsz = Ws + z;
+        const uint4* Bhz = &Bh[0][0] + z; const uint4* A1z = &A1h[0][0] + z; const float* Wsz = Ws + z;
         float f[16];
-        {
-            const float v[8] = {x1lo.x, x1lo.y, x1lo.z, x1lo.w, x1hi.x, x1hi.y, x1hi.z, x1hi.w};
+        {   // group 0: relu(agg1 . x1) (ALike.py:147) on the matrix pipe (r04): D[o][pixel] = A1[o][c] x1[pixel][c] as three split-f16 MFMAs
+            // (K = 16, the upper eight are zero weights); lane (p, h) finds channels {0..3, 8..11} + 4 h of ITS pixel in registers 0..7.
+            // r03 / early r04: 64 FMAs per lane against 16 weight reads from LDS -- 3.3 k of a tile's 11 k cycles were this phase.
+            const float xs[8] = {x1lo.x * sx1, x1lo.y * sx1, x1lo.z * sx1, x1lo.w * sx1, x1hi.x * sx1, x1hi.y * sx1, x1hi.z * sx1, x1hi.w * sx1};
+            h8v xh, xl;
+            split8(xs, xh, xl);
+            const h8v wh = __builtin_bit_cast(h8v, A1z[lane]), wl = __builtin_bit_cast(h8v, A1z[64 + lane]);
+            f32x16 aa = {0};
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh, aa, 0, 0, 0);
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl, aa, 0, 0, 0);
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, aa, 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = 0.0f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 w0 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8]), w1 = *reinterpret_cast<const float4*>(&A1z[(h * 8 + c) * 8 + 4]);
-                f[0] = fmaf(v[c], w0.x, f[0]); f[1] = fmaf(v[c], w0.y, f[1]); f[2] = fmaf(v[c], w0.z, f[2]); f[3] = fmaf(v[c], w0.w, f[3]);
-                f[4] = fmaf(v[c], w1.x, f[4]); f[5] = fmaf(v[c], w1.y, f[5]); f[6] = fmaf(v[c], w1.z, f[6]); f[7] = fmaf(v[c], w1.w, f[7]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = relu(f[j]);
+            for (int j = 0; j < 8; ++j) f[j] = relu(aa[j] * una1);
         }
         up8ch_lerp(taps, f + 8, scf);
 
@@ -1907,10 +1914,11 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
     // upsample + concat + head (151-162)
     if (desc_out_dev) {
-        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W, amax_x1, amax_a2, 0.f, 1.f, 1.f};
+        HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W, amax_x1, amax_a2, 0.f, 1.f, 1.f, nullptr, 1.f};
         const int work4 = cdiv(H, 4) * cdiv(W / 32, SEG_TILES);     // four consecutive rows of one 128-pixel column band per workgroup
         if (h16) {
             hy.l1_agg1 = k.at("agg1.l1"); hy.inv_ws_h = k.at("head.inv_ws"); hy.ws_h = 1.0f / hy.inv_ws_h;
+            hy.a1h16 = reinterpret_cast<const uint4*>(wp("agg1.h16")); hy.inv_wa = k.at("agg1.inv_wa");
             // row groups per persistent workgroup: 30 (15: +1-2 %, 40 / 60: the same, 120: +1 %; profiles/r04_ab_knobs.txt); H is a
             // multiple of 32 (kpb_net_forward checks), so every group has its four rows
             // -- as long as that leaves about two rounds of workgroups for the chip's 768 slots: a single image walks 2 groups per workgroup
@@ -2057,7 +2065,10 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         net->k["head.inv_ws"] = 1.0f / sh;
         std::vector<uint16_t> hl(2 * 2 * 2 * 2 * 32 * 8);
         for (int kb = 0; kb < 2; ++kb) for (int nh = 0; nh < 2; ++nh) for (int hh = 0; hh < 2; ++hh) for (int n = 0; n < 32; ++n) for (int j = 0; j < 8; ++j) {
-            const float w = hw[(32 * nh + n) * 64 + 16 * kb + 8 * hh + j] * sh;
+            // k slot (hh, j) of block kb: group 1 (up2 a2) keeps channel 8 hh + j; group 0 (agg1) is produced by an MFMA whose accumulator
+            // leaves lane half hh with channels {0..3, 8..11} + 4 hh (rows (r & 3) + 8 (r >> 2) + 4 hh of a 32 x 32 tile), so its k order is that
+            const int cch = kb == 0 ? (j < 4 ? j : j + 4) + 4 * hh : 16 + 8 * hh + j;
+            const float w = hw[(32 * nh + n) * 64 + cch] * sh;
             const _Float16 hi = (_Float16)w;
             const _Float16 lo = (_Float16)(w - (float)hi);
             const size_t at = ((((size_t)kb * 2 + nh) * 2 + hh) * 32 + n) * 8 + j;
@@ -2067,6 +2078,24 @@ int alike_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         tmp.assign(2048, 0.f);
         memcpy(tmp.data(), hl.data(), 8192);
         ws.put("head.wh16", tmp);
+        // agg1 (8 -> 16, 1x1) as the A operand of v_mfma_f32_32x32x16_f16 (r04): rows = output channels (16 of 32 used), k = input
+        // channel (8 of 16 used): lane (row o, k half) holds agg1[o][c = 0..7] in its eight halves for o < 16 and k half 0, zeros elsewhere
+        {
+            const float* a1w = bl.get("agg1.w", {dim / 4, c1});            // [16][8]
+            const float sa1 = weight_scale_h(a1w, 16 * 8);
+            net->k["agg1.inv_wa"] = 1.0f / sa1;
+            std::vector<uint16_t> fr(2 * 64 * 8, 0);
+            for (int o = 0; o < 16; ++o) for (int c = 0; c < 8; ++c) {
+                const float w = a1w[o * 8 + c] * sa1;
+                const _Float16 hi = (_Float16)w;
+                const _Float16 lo = (_Float16)(w - (float)hi);
+                memcpy(&fr[(size_t)o * 8 + c], &hi, 2);
+                memcpy(&fr[(size_t)(64 + o) * 8 + c], &lo, 2);
+            }
+            tmp.assign(512, 0.f);
+            memcpy(tmp.data(), fr.data(), 2048);
+            ws.put("agg1.h16", tmp);
+        }
     }
     if (int rc = ws.upload(net)) { delete net; return rc; }
     *out = net;
