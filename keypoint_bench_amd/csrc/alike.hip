@@ -961,17 +961,20 @@ __device__ __forceinline__ void up8ch(const float* m, int Hs, int Ws, float sy, 
 
 // the same for taps already in registers (the head reads them from the a2 band it keeps in LDS)
 struct Up8Taps { float4 t[8]; float ly, lx; };
-// `sc` (a power of two) scales the result exactly: it rides on the two y weights
-__device__ __forceinline__ void up8ch_lerp(const Up8Taps& u, float* f, float sc = 1.0f)
+// The bilinear interpolation of up8ch from taps already in registers, as four weighted taps: the four weights once per pixel, then a
+// multiply and three FMAs per channel (36 vector instructions per pixel; r03's hy (hx a + lx b) + ly (hx c + lx d), unfused, took 56 and
+// differs in the last bit).  `sc` (a power of two) scales the result exactly: it rides on the two y weights.
+__device__ __forceinline__ void up8ch_lerp4(const Up8Taps& u, float* f, float sc)
 {
     const float lx = u.lx, hx = 1.0f - lx, hy = (1.0f - u.ly) * sc, ly = u.ly * sc;
+    const float w00 = hy * hx, w01 = hy * lx, w10 = ly * hx, w11 = ly * lx;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const float4 a = u.t[4 * q], b = u.t[4 * q + 1], c = u.t[4 * q + 2], d = u.t[4 * q + 3];
-        f[4 * q + 0] = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
-        f[4 * q + 1] = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
-        f[4 * q + 2] = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
-        f[4 * q + 3] = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+        f[4 * q + 0] = fmaf(w11, d.x, fmaf(w10, c.x, fmaf(w01, b.x, w00 * a.x)));
+        f[4 * q + 1] = fmaf(w11, d.y, fmaf(w10, c.y, fmaf(w01, b.y, w00 * a.y)));
+        f[4 * q + 2] = fmaf(w11, d.z, fmaf(w10, c.z, fmaf(w01, b.z, w00 * a.z)));
+        f[4 * q + 3] = fmaf(w11, d.w, fmaf(w10, c.w, fmaf(w01, b.w, w00 * a.w)));
     }
 }
 
@@ -1480,7 +1483,7 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = relu(aa[j] * una1);
         }
-        up8ch_lerp(taps, f + 8, scf);
+        up8ch_lerp4(taps, f + 8, scf);
 
         const float fx3 = sx8 * (float)x, fx4 = sx32 * (float)x;
         const int rb3 = (int)(sx8 * (float)x0) - tb3, rb4 = (int)(sx32 * (float)x0) - tb4;
@@ -1489,8 +1492,8 @@ __global__ __launch_bounds__(256, 3) void alike_head_f16p(HybArgs a, const uint4
         const float *u3 = &E3r[0][0] + (U3 + rb3 * ESTRIDE + z), *d3 = &E3r[0][0] + (D3 + rb3 * ESTRIDE + z);
         const float *u4 = &E4r[0][0] + (U4 + rb4 * ESTRIDE + z), *d4 = &E4r[0][0] + (D4 + rb4 * ESTRIDE + z);
         // the y-interpolated coarse row at (strip row k, channel c), in the accumulator's units (channel 64: the score share, unscaled)
-        auto e3 = [&](int k, int c) { return hy3c * u3[k * ESTRIDE + c] + ly3c * d3[k * ESTRIDE + c]; };
-        auto e4 = [&](int k, int c) { return hy4c * u4[k * ESTRIDE + c] + ly4c * d4[k * ESTRIDE + c]; };
+        auto e3 = [&](int k, int c) { return fmaf(ly3c, d3[k * ESTRIDE + c], hy3c * u3[k * ESTRIDE + c]); };     // (one fused step: r04)
+        auto e4 = [&](int k, int c) { return fmaf(ly4c, d4[k * ESTRIDE + c], hy4c * u4[k * ESTRIDE + c]); };
 
         float sc = 0.0f;
 #pragma unroll
