@@ -1165,6 +1165,7 @@ int det_select(kpb_ctx* ctx, const DetState& d)
     s.signed_map = (d.prm.nms_dist >= 1 && d.prm.nms_dist <= 8) ? 1 : 0;
     s.lastchg = d.prm.nms_dist > 0 ? d.plan.lastchg : nullptr; s.negflag = d.prm.nms_dist > 0 ? d.plan.negflag : nullptr;
     if (ctx->host_det_cap < 3 * d.batch) {
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // an earlier call's select_topk may still be writing the old mirror
         if (ctx->host_det) KPB_HIP(ctx, hipHostFree(ctx->host_det));
         ctx->host_det = nullptr; ctx->host_det_cap = 0;
         KPB_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_det), (size_t)3 * d.batch * sizeof(int), hipHostMallocDefault));

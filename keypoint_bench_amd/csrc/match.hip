@@ -583,6 +583,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->host_match_cap < batch) {
+        KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // an earlier call's match_finalize may still be writing the old mirror
         if (ctx->host_match) KPB_HIP(ctx, hipHostFree(ctx->host_match));
         ctx->host_match = nullptr; ctx->host_match_cap = 0;
         KPB_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->host_match), (size_t)batch * sizeof(int), hipHostMallocDefault));
