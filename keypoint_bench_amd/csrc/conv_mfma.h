@@ -30,7 +30,21 @@ struct ConvM {
     const float* xw = nullptr;    // conv_mfma_h<XC>: [tap][CIN] fp32 weights of ONE extra output channel (index xco) taken on the VALU
     float xb = 0.0f;              // its bias
     int xco = 0;
+    // gemm_h only (the LightGlue linears): rows >= rowcnt[b] are staged as zeros and never written -- what a padded row holds cannot
+    // reach a valid row's operand scale; aux0 / aux1 / out1 / out2 belong to the epilogue forms GE_* below
+    const int* rowcnt = nullptr;
+    const float* aux0 = nullptr;
+    const float* aux1 = nullptr;
+    float* out1 = nullptr;
+    float* out2 = nullptr;
 };
+
+// gemm_h epilogues.  GE_RESIDUAL: out = res + (W x + b), rows of `res` rstride floats apart (lightglue.py:185 / 242, x + ffn(...)).
+// GE_ROTARY: the 768 columns of Wqkv arrive permuted (lg_pack_qkv_rows): workgroup nb = 3 head + which (q, k, v) owns the 32 even
+// elements of that head in its first tile and the 32 odd ones in its second, so a lane holds one rotary pair; q and k are rotated by
+// (aux0, aux1) = (cos, sin) [row][32] and all three go out head-major as float2 (lightglue.py:71-78, 179-183).
+// GE_SPLIT2: output tiles from column 256 on go to out1 (two Linears over the same input as one product).
+enum { GE_PLAIN = 0, GE_RESIDUAL = 1, GE_ROTARY = 2, GE_SPLIT2 = 3 };
 
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2>
 __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
@@ -495,8 +509,8 @@ __global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) v
 // of slab c) and go into the OTHER of two LDS buffers behind them, so there is one barrier per slab and the loads fly
 // under the matrix work.  Workgroup = 256 rows x 32 NTB columns; wave = 64 rows (two M tiles); weights in pack_mfma_h's
 // KS = 1 order; LDS rows as in conv_mfma_h (hi | lo | pad, 144 bytes: nine 16-byte slots, conflict-free).
-template <int NTB, int MT = 2>
-__global__ __launch_bounds__(256) void gemm_h(ConvM a)
+template <int NTB, int MT = 2, int EPI = GE_PLAIN>
+__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
 {
     // r03: a wave stages exactly the 32 MT rows it multiplies, so its slice of the LDS buffers is private to it (a wave's LDS
     // operations execute in order: no barrier anywhere in the kernel) and the activation scale is chosen PER WAVE from the
@@ -507,8 +521,11 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
     const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
     if (a.active && !a.active[b]) return;
-    const int nrows = a.H * a.W, r0 = blockIdx.x * ROWS + WROWS * wv;          // this wave's first row
-    const float* in = a.in + (size_t)b * nrows * a.istride;
+    const int nrows_all = a.H * a.W, r0 = blockIdx.x * ROWS + WROWS * wv;      // this wave's first row
+    const int nrows = a.rowcnt ? min(nrows_all, a.rowcnt[b]) : nrows_all;
+    if (r0 >= nrows) return;                                     // wave-level: the kernel has no barrier
+    if (EPI != GE_PLAIN && blockIdx.x * ROWS + ROWS > nrows_all) return;     // the fused forms read whole row tiles (LightGlue pads to 128 rows)
+    const float* in = a.in + (size_t)b * nrows_all * a.istride;
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)a.NCH * NKB * 4 * 32;
     unsigned char* wt = tile + wv * WBUF;
@@ -564,9 +581,40 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
     fetch(0);
     stage(0, true);
     // (Also requesting the next slab's weight fragments a slab ahead costs 94 more VGPRs and the second wave per SIMD: 1.7x slower.)
-    for (int ch = 0; ch < a.NCH; ++ch) {
-        const bool more = ch + 1 < a.NCH;
-        if (more) fetch(ch + 1);
+    // what the fused epilogues read per output element is requested ahead of the LAST slab's products (in the epilogue each load
+    // was an exposed round trip: ffn3 + residual 0.83 -> 1.10 ms per 18 launches)
+    constexpr int NX = EPI == GE_RESIDUAL ? NTB : (EPI == GE_ROTARY ? 2 : 0);
+    float xv[MT][NX ? NX : 1][16];
+    auto fetch_epilogue = [&]() {
+        if constexpr (EPI == GE_RESIDUAL) {
+            const float* res = a.res + (size_t)b * nrows_all * a.rstride;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = r0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;        // < nrows_all: see the check at the top
+                        xv[m][n][r] = res[(size_t)row * a.rstride + (nt0 + n) * 32 + p];
+                    }
+        } else if constexpr (EPI == GE_ROTARY) {
+            const float* cs = a.aux0 + (size_t)b * nrows_all * 32 + p;
+            const float* sn = a.aux1 + (size_t)b * nrows_all * 32 + p;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = r0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    xv[m][0][r] = cs[(size_t)row * 32];
+                    xv[m][1][r] = sn[(size_t)row * 32];
+                }
+        }
+    };
+    // the last slab is peeled off the loop: it has nothing to fetch ahead, so the registers of `buf` carry the epilogue's operands
+    auto slab = [&](int ch, auto more_t) {
+        constexpr bool more = decltype(more_t)::value;
+        if constexpr (more) fetch(ch + 1);
+        else fetch_epilogue();
         const uint4* bp = wq + (((size_t)nt0 * a.NCH + ch) * NKB * 4 + h) * 32 + p;
         cm_h8 Bh[NTB][NKB], Bl[NTB][NKB], Ah[MT][NKB], Al[MT][NKB];
 #pragma unroll
@@ -596,24 +644,52 @@ __global__ __launch_bounds__(256) void gemm_h(ConvM a)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bl[n][kb], acc[m][n], 0, 0, 0);
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Bh[n][kb], acc[m][n], 0, 0, 0);
                 }
-        if (more) stage((ch + 1) & 1, false);      // the wave's other buffer
-    }
+        if constexpr (more) stage((ch + 1) & 1, false);      // the wave's other buffer
+    };
+    for (int ch = 0; ch + 1 < a.NCH; ++ch) slab(ch, std::true_type{});
+    slab(a.NCH - 1, std::false_type{});
 
     const float unscale = a.unscale * cm_unscale_of(e_cur);
-    float* out = a.out + (size_t)b * nrows * a.ostride + a.ooff;
+    if constexpr (EPI == GE_ROTARY) {
+        static_assert(EPI != GE_ROTARY || NTB == 2, "gemm_h: the rotary epilogue pairs the workgroup's two tiles");
+        const int head = nb / 3, which = nb - 3 * head;
+        float* dst = (which == 0 ? a.out : which == 1 ? a.out1 : a.out2) + (size_t)b * nrows_all * 256 + head * 64 + 2 * p;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (row >= nrows) continue;
+                const float ev = fmaf(acc[m][0][r], unscale, biasv[0]), od = fmaf(acc[m][1][r], unscale, biasv[1]);
+                float2 o = make_float2(ev, od);
+                if (which < 2) {
+                    const float c = xv[m][0][r], s = xv[m][1][r];
+                    o.x = __fadd_rn(__fmul_rn(ev, c), __fmul_rn(-od, s));
+                    o.y = __fadd_rn(__fmul_rn(od, c), __fmul_rn(ev, s));
+                }
+                *reinterpret_cast<float2*>(dst + (size_t)row * 256) = o;
+            }
+        return;
+    }
+    float* out = a.out + (size_t)b * nrows_all * a.ostride + a.ooff;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
-            const int co = (nt0 + n) * 32 + p;
+            int co = (nt0 + n) * 32 + p;
             const float bias = biasv[n];
             if (co >= a.COUT) continue;
+            float* o = out;
+            if (EPI == GE_SPLIT2 && co >= 256) { o = a.out1 + (size_t)b * nrows_all * a.ostride; co -= 256; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = r0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float v = fmaf(acc[m][n][r], unscale, bias);
                 if (a.relu) v = relu(v);
-                if (row < nrows) out[(size_t)row * a.ostride + co] = v;
+                if (row < nrows) {
+                    if constexpr (EPI == GE_RESIDUAL) v = xv[m][n][r] + v;
+                    o[(size_t)row * a.ostride + co] = v;
+                }
             }
         }
 }

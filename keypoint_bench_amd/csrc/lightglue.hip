@@ -307,12 +307,16 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
     cm_h8 Qh[4], Ql[4];
     float qscale;           // a.scale / (the tile's Q scale): with the key block's K scale, what turns the accumulator into scores
     {
-        const float* qp = a.q + ((size_t)s * a.MP + q0 + p) * D + head * HD + 8 * h;       // rows past nq stay inside the padded buffer
+        // rows past nq are inside the padded buffer but hold whatever an earlier call left there: they enter as zeros, so the
+        // tile's operand scale depends on its own queries only
+        const float* qp = a.q + ((size_t)s * a.MP + q0 + p) * D + head * HD + 8 * h;
+        const bool qvalid = q0 + p < nq;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float4 t0[4], t1[4];
         float am = 0.0f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            t0[kb] = *reinterpret_cast<const float4*>(qp + 16 * kb); t1[kb] = *reinterpret_cast<const float4*>(qp + 16 * kb + 4);
+            t0[kb] = qvalid ? *reinterpret_cast<const float4*>(qp + 16 * kb) : z4; t1[kb] = qvalid ? *reinterpret_cast<const float4*>(qp + 16 * kb + 4) : z4;
             am = cm_amax4(cm_amax4(am, t0[kb]), t1[kb]);
         }
         const int eq = cm_exp_of(cm_wave_max(am));
@@ -730,8 +734,16 @@ struct LgNetShim : kpb_net {     // WeightStage::upload wants a kpb_net; only ct
     int forward(const float*, int, int, int, float*, float*) override { return KPB_E_INVALID; }
 };
 
+// One Linear over the tokens of every sequence.  Split-f16 form: gemm_h, rows past cnt[s] neither read nor written; `epi` selects
+// the fused epilogue (conv_mfma.h GE_*) and `x` carries its operands.  Strict fp32 form: conv_mfma<1,...>, plain epilogue only.
+struct LgEpi {
+    int epi = GE_PLAIN;
+    const float* res = nullptr; int rstride = 0;          // GE_RESIDUAL
+    const float* cosb = nullptr; const float* sinb = nullptr; float* out1 = nullptr; float* out2 = nullptr;   // GE_ROTARY (out1 also GE_SPLIT2)
+};
+
 int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name, int cin, int cout, const float* in, int istride,
-              float* out, int ostride, int ooff, int S, int MP, const int* active)
+              float* out, int ostride, int ooff, int S, int MP, const int* active, const int* cnt, const LgEpi& x = LgEpi())
 {
     ConvM a;
     a.in = in; a.out = out; a.wp = lg->wp(name + ".w"); a.bias = lg->wp(name + ".b"); a.xf = nullptr; a.res = nullptr; a.active = active;
@@ -740,11 +752,26 @@ int lg_linear(kpb_ctx* ctx, kpb_lg* lg, const char* tag, const std::string& name
     a.istride = istride; a.ostride = ostride; a.ooff = ooff;
     if (conv_mfma_use_h16()) {
         a.unscale = 1.0f / (lg->wscale.at(name + ".w"));
+        a.rowcnt = cnt; a.res = x.res; a.rstride = x.rstride; a.aux0 = x.cosb; a.aux1 = x.sinb; a.out1 = x.out1; a.out2 = x.out2;
         // 128-row tiles: four workgroups per CU (8-15 % faster than 256-row tiles, r02)
-        KPB_LAUNCH(ctx, tag, (gemm_h<2, 1>), dim3(cdiv(MP, 128), 1, S * a.nblk), dim3(256), 0, ctx->stream, a);
-    } else
+        const dim3 grid(cdiv(MP, 128), 1, S * a.nblk);
+        if (x.epi == GE_RESIDUAL) KPB_LAUNCH(ctx, tag, (gemm_h<2, 1, GE_RESIDUAL>), grid, dim3(256), 0, ctx->stream, a);
+        else if (x.epi == GE_ROTARY) KPB_LAUNCH(ctx, tag, (gemm_h<2, 1, GE_ROTARY>), grid, dim3(256), 0, ctx->stream, a);
+        else if (x.epi == GE_SPLIT2) KPB_LAUNCH(ctx, tag, (gemm_h<2, 1, GE_SPLIT2>), grid, dim3(256), 0, ctx->stream, a);
+        else KPB_LAUNCH(ctx, tag, (gemm_h<2, 1>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+        if (x.epi != GE_PLAIN) return kpb_fail(ctx, KPB_E_INVALID, "lg_linear: fused epilogues exist in the split-f16 form only");
         KPB_LAUNCH(ctx, tag, (conv_mfma<1, 1, 32, false, false, false, 2>), dim3(1, MP / 128, S * a.nblk), dim3(256), 0, ctx->stream, a);
+    }
     return KPB_OK;
+}
+
+// Row order of the fused Wqkv product (GE_ROTARY): packed row (2 nb + par) 32 + f, nb = 3 head + which, is the reference's row
+// head 192 + (2 f + par) 3 + which of qkv.unflatten(-1, (heads, -1, 3)) (lightglue.py:179-180).
+inline int lg_qkv_row(int o)
+{
+    const int nb = o / 64, par = (o % 64) / 32, f = o % 32, head = nb / 3, which = nb % 3;
+    return head * 192 + (2 * f + par) * 3 + which;
 }
 
 }  // namespace
@@ -775,6 +802,28 @@ KPB_API int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc
         ws.put(name + ".b", pad_bias(b, (int)cout, 64));
         return true;
     };
+    // split-f16 form only: the rows of `key` in the order `perm` (GE_ROTARY), or `key` and `key2` stacked (GE_SPLIT2)
+    auto linear_rows = [&](const std::string& key, const std::string& key2, const std::string& name, uint32_t cout, uint32_t cin, bool permute) -> bool {
+        const uint32_t c1 = key2.empty() ? cout : cout / 2;
+        const float* w = bl.get((key + ".weight").c_str(), {c1, cin});
+        const float* b = bl.get((key + ".bias").c_str(), {c1});
+        const float* w2 = key2.empty() ? nullptr : bl.get((key2 + ".weight").c_str(), {c1, cin});
+        const float* b2 = key2.empty() ? nullptr : bl.get((key2 + ".bias").c_str(), {c1});
+        if (!w || !b || (!key2.empty() && (!w2 || !b2))) return false;
+        std::vector<float> wr((size_t)cout * cin), br(cout);
+        for (uint32_t o = 0; o < cout; ++o) {
+            const float* srcw = o < c1 ? w : w2;
+            const float* srcb = o < c1 ? b : b2;
+            const uint32_t r = o < c1 ? (permute ? (uint32_t)lg_qkv_row((int)o) : o) : o - c1;
+            std::memcpy(&wr[(size_t)o * cin], srcw + (size_t)r * cin, cin * sizeof(float));
+            br[o] = srcb[r];
+        }
+        const float sc = weight_scale_h(wr.data(), wr.size());
+        ws.put(name + ".w", pack_mfma_h(wr.data(), (int)cout, (int)cin, 1, 32, 2, sc));
+        ws.wscale[name + ".w"] = sc;
+        ws.put(name + ".b", pad_bias(br.data(), (int)cout, 64));
+        return true;
+    };
     auto vec = [&](const std::string& key, const std::string& name, std::vector<uint32_t> dims) -> bool {
         const float* v = bl.get(key.c_str(), dims);
         if (!v) return false;
@@ -793,10 +842,16 @@ KPB_API int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc
     for (int i = 0; i < NL; ++i) {
         const std::string sa = "transformers." + std::to_string(i) + ".self_attn", ca = "transformers." + std::to_string(i) + ".cross_attn";
         const std::string L = "L" + std::to_string(i);
-        if (!linear(sa + ".Wqkv", L + ".Wqkv", 768, 256) || !linear(sa + ".out_proj", L + ".sout", 256, 256) ||
+        // the self-attention q/k/v product and the cross-attention qk / v products: fused forms for split-f16 (see lg_linear)
+        if (conv_mfma_use_h16() ? (!linear_rows(sa + ".Wqkv", "", L + ".Wqkv_r", 768, 256, true) ||
+                                   !linear_rows(ca + ".to_qk", ca + ".to_v", L + ".toqkv", 512, 256, false))
+                                : (!linear(sa + ".Wqkv", L + ".Wqkv", 768, 256) || !linear(ca + ".to_qk", L + ".toqk", 256, 256) ||
+                                   !linear(ca + ".to_v", L + ".tov", 256, 256)))
+            return fail(L);
+        if (!linear(sa + ".out_proj", L + ".sout", 256, 256) ||
             !linear(sa + ".ffn.0", L + ".sffn0", 512, 512) || !linear(sa + ".ffn.3", L + ".sffn3", 256, 512) ||
             !vec(sa + ".ffn.1.weight", L + ".sln.g", {512}) || !vec(sa + ".ffn.1.bias", L + ".sln.b", {512}) ||
-            !linear(ca + ".to_qk", L + ".toqk", 256, 256) || !linear(ca + ".to_v", L + ".tov", 256, 256) || !linear(ca + ".to_out", L + ".toout", 256, 256) ||
+            !linear(ca + ".to_out", L + ".toout", 256, 256) ||
             !linear(ca + ".ffn.0", L + ".cffn0", 512, 512) || !linear(ca + ".ffn.3", L + ".cffn3", 256, 512) ||
             !vec(ca + ".ffn.1.weight", L + ".cln.g", {512}) || !vec(ca + ".ffn.1.bias", L + ".cln.b", {512}))
             return fail(L);
@@ -877,17 +932,22 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
     KPB_LAUNCH(ctx, "lg_sample", lg_sample, dim3(cdiv(max_k, 4), S), dim3(256), 0, st, sa);
     int rc;
     if (lg->off.count("input_proj.w")) {
-        if ((rc = lg_linear(ctx, lg, "lg_input_proj", "input_proj", C, 256, din, C, cat[0], 512, 0, S, MP, active_seq))) return rc;
+        if ((rc = lg_linear(ctx, lg, "lg_input_proj", "input_proj", C, 256, din, C, cat[0], 512, 0, S, MP, active_seq, cnt))) return rc;
     } else {
         KPB_HIP(ctx, hipMemcpy2DAsync(cat[0], 512 * sizeof(float), din, 256 * sizeof(float), 256 * sizeof(float), T, hipMemcpyDeviceToDevice, st));
     }
     const dim3 tokgrid4(cdiv(max_k, 4), S), tokgrid64(cdiv(max_k * 64, 256), S);
+    const bool h16 = conv_mfma_use_h16();
     auto ffn = [&](const std::string& L, const char* pfx, float* c) -> int {     // x + ffn(cat([x, msg])), lightglue.py:185 / 241-242
         int r;
-        if ((r = lg_linear(ctx, lg, "lg_ffn0", L + pfx + "ffn0", 512, 512, c, 512, h1, 512, 0, S, MP, active_seq))) return r;
+        if ((r = lg_linear(ctx, lg, "lg_ffn0", L + pfx + "ffn0", 512, 512, c, 512, h1, 512, 0, S, MP, active_seq, cnt))) return r;
         KPB_LAUNCH(ctx, "lg_ln_gelu", lg_ln_gelu, tokgrid4, dim3(256), 0, st, h1, lg->wp(L + (pfx[1] == 's' ? ".sln.g" : ".cln.g")),
                    lg->wp(L + (pfx[1] == 's' ? ".sln.b" : ".cln.b")), cnt, active_seq, MP);
-        if ((r = lg_linear(ctx, lg, "lg_ffn3", L + pfx + "ffn3", 512, 256, h1, 512, y, 256, 0, S, MP, active_seq))) return r;
+        if (h16) {          // the residual sum rides in the product's epilogue: c[:, :256] = c[:, :256] + ffn3(h1)
+            LgEpi x; x.epi = GE_RESIDUAL; x.res = c; x.rstride = 512;
+            return lg_linear(ctx, lg, "lg_ffn3", L + pfx + "ffn3", 512, 256, h1, 512, c, 512, 0, S, MP, active_seq, cnt, x);
+        }
+        if ((r = lg_linear(ctx, lg, "lg_ffn3", L + pfx + "ffn3", 512, 256, h1, 512, y, 256, 0, S, MP, active_seq, cnt))) return r;
         KPB_LAUNCH(ctx, "lg_residual", lg_residual, tokgrid64, dim3(256), 0, st, c, y, cnt, active_seq, MP);
         return KPB_OK;
     };
@@ -896,9 +956,14 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
         float* c = cat[i & 1];
         float *cs = cosb[i & 1], *sn = sinb[i & 1];
         // self attention (lightglue.py:173-185)
-        if ((rc = lg_linear(ctx, lg, "lg_Wqkv", L + ".Wqkv", 256, 768, c, 512, qkv, 768, 0, S, MP, active_seq))) return rc;
-        KPB_LAUNCH(ctx, "lg_rotary", lg_rotary, dim3(cdiv(max_k * 128, 256), S), dim3(256), 0, st, qkv, cs, sn, q, k, v, cnt, active_seq, MP);
-        if (conv_mfma_use_h16()) {
+        if (h16) {          // q, k rotated and all three laid out head-major by the product's own epilogue
+            LgEpi x; x.epi = GE_ROTARY; x.cosb = cs; x.sinb = sn; x.out1 = k; x.out2 = v;
+            if ((rc = lg_linear(ctx, lg, "lg_Wqkv", L + ".Wqkv_r", 256, 768, c, 512, q, 256, 0, S, MP, active_seq, cnt, x))) return rc;
+        } else {
+            if ((rc = lg_linear(ctx, lg, "lg_Wqkv", L + ".Wqkv", 256, 768, c, 512, qkv, 768, 0, S, MP, active_seq, cnt))) return rc;
+            KPB_LAUNCH(ctx, "lg_rotary", lg_rotary, dim3(cdiv(max_k * 128, 256), S), dim3(256), 0, st, qkv, cs, sn, q, k, v, cnt, active_seq, MP);
+        }
+        if (h16) {
             FragArgs fr{k, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 0};
             KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
             FlashHArgs fa{q, kfrag, vfrag, kvexp, cx, cnt, active_seq, MP, 0, 0.125f};
@@ -907,12 +972,17 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
             FlashArgs fa{q, k, v, cx, cnt, active_seq, MP, 0, 0.125f};
             KPB_LAUNCH(ctx, "lg_flash_self", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
         }
-        if ((rc = lg_linear(ctx, lg, "lg_out_proj", L + ".sout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq))) return rc;
+        if ((rc = lg_linear(ctx, lg, "lg_out_proj", L + ".sout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq, cnt))) return rc;
         if ((rc = ffn(L, ".s", c))) return rc;
         // cross attention (lightglue.py:216-243)
-        if ((rc = lg_linear(ctx, lg, "lg_to_qk", L + ".toqk", 256, 256, c, 512, q, 256, 0, S, MP, active_seq))) return rc;
-        if ((rc = lg_linear(ctx, lg, "lg_to_v", L + ".tov", 256, 256, c, 512, v, 256, 0, S, MP, active_seq))) return rc;
-        if (conv_mfma_use_h16()) {
+        if (h16) {
+            LgEpi x; x.epi = GE_SPLIT2; x.out1 = v;
+            if ((rc = lg_linear(ctx, lg, "lg_to_qkv", L + ".toqkv", 256, 512, c, 512, q, 256, 0, S, MP, active_seq, cnt, x))) return rc;
+        } else {
+            if ((rc = lg_linear(ctx, lg, "lg_to_qk", L + ".toqk", 256, 256, c, 512, q, 256, 0, S, MP, active_seq, cnt))) return rc;
+            if ((rc = lg_linear(ctx, lg, "lg_to_v", L + ".tov", 256, 256, c, 512, v, 256, 0, S, MP, active_seq, cnt))) return rc;
+        }
+        if (h16) {
             FragArgs fr{q, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 1};
             KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
             FlashHArgs fc{q, kfrag, vfrag, kvexp, cx, cnt, active_seq, MP, 1, 0.125f};
@@ -921,7 +991,7 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
             FlashArgs fc{q, q, v, cx, cnt, active_seq, MP, 1, 0.125f};
             KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
         }
-        if ((rc = lg_linear(ctx, lg, "lg_to_out", L + ".toout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq))) return rc;
+        if ((rc = lg_linear(ctx, lg, "lg_to_out", L + ".toout", 256, 256, cx, 256, c, 512, 256, S, MP, active_seq, cnt))) return rc;
         if ((rc = ffn(L, ".c", c))) return rc;
         // confidences, stop / prune decision (lightglue.py:557-579)
         const bool last = i == NL - 1;
@@ -933,7 +1003,7 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
                       prm->width_confidence > 0 ? 1 : 0};
         KPB_LAUNCH(ctx, "lg_decide", lg_decide, dim3(B), dim3(256), 0, st, da);
         // assignment for the pairs that finish at this layer (lightglue.py:606-614)
-        if ((rc = lg_linear(ctx, lg, "lg_final_proj", L + ".fproj", 256, 256, c, 512, md, 256, 0, S, MP, fin_seq))) return rc;
+        if ((rc = lg_linear(ctx, lg, "lg_final_proj", L + ".fproj", 256, 256, c, 512, md, 256, 0, S, MP, fin_seq, cnt))) return rc;
         KPB_LAUNCH(ctx, "lg_sim", lg_sim, dim3(cdiv(max_k, 128), cdiv(max_k, 32), B), dim3(256), 0, st, md, sim, cnt, fin_pair, MP);
         KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, cnt, fin_pair, MP, 0);
         KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, cnt, fin_pair, MP, 1);
