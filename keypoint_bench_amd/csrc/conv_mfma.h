@@ -279,6 +279,9 @@ __device__ __forceinline__ float cm_wave_max(float v)
 // weight round trip is not what keeps the matrix pipe at 46 %.  Nor is the slab staging: a persistent form that fetches the next
 // slab (or the next tile's first slab) into registers before the taps of the current one ran 2 % faster on conv1b at two
 // waves per SIMD and 20 % slower on DISK's up_3 (the 44 registers of the slab in flight cost the third wave).)
+// (Tried, r04: the workgroups sharing a CU start together and take the same time per phase, so their load / split / store phases
+// might coincide and idle the matrix pipe together; delaying the first generation's slot k by k x 8-48 k cycles changed no layer of
+// SuperPoint by more than 1 % -- the phases are not in lockstep.)
 // PF: with POOL_IN the input is max-pooled PF x PF (2 or 4) while it is staged (ALike.py:139-143).
 // waves per SIMD the register allocation is held to: what r02's code reached without being told (accumulators 16 MT NTB) --
 // left alone, the allocator keeps a second copy of the accumulators in VGPRs for the rare rescale below (+64 registers, a wave
