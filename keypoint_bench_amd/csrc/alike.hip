@@ -833,13 +833,14 @@ constexpr int ESTRIDE = 68;             // channels of a projected map: 64 descr
 // out = relu(w . in) (ALike.py:147-150); smap = this group's share of the score logit; with E != null also the group's
 // share of every head row, E[p][o] = sum_c wproj[c][o] out[p][c] (see alike_head: the head commutes with upsampling)
 template <int CIN>
-__global__ __launch_bounds__(256) void conv1x1_relu(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ w /*[CIN][16]*/,
-                                                    const float* __restrict__ wsg /*[16]*/, float* __restrict__ smap, size_t npix,
-                                                    const float* __restrict__ wproj /*[16][64]*/, float* __restrict__ E /*[npix][ESTRIDE]*/)
+__device__ __forceinline__ void conv1x1_relu_body(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ w /*[CIN][16]*/,
+                                                  const float* __restrict__ wsg /*[16]*/, float* __restrict__ smap, size_t npix,
+                                                  const float* __restrict__ wproj /*[16][64]*/, float* __restrict__ E /*[npix][ESTRIDE]*/,
+                                                  const unsigned bx /* workgroup index within this layer */)
 // (__restrict__ matters: the projection weights are read AFTER the stores of out / smap; without it the compiler could not prove them
 //  unclobbered and fetched all 1 024 of them with per-lane vector loads, 256 serialised round trips per wave -- 0.46 ms for agg3)
 {
-    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t p = (size_t)bx * 256 + threadIdx.x;
     const bool live = p < npix;        // (dead lanes of the last workgroup still help to copy the projected rows out)
     // One LDS region per wave, used twice: first to turn the wave's 64 pixels x CIN floats -- contiguous in memory, read with
     // consecutive lanes on consecutive 16-byte pieces -- into one pixel per lane (a lane reading its own pixel straight from global
@@ -856,7 +857,7 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* __restrict__ in
     const float* x = in + (live ? p : 0) * CIN;
     if (STAGE_IN) {
         const int ln = threadIdx.x & 63;
-        const size_t pw = (size_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 64;     // first pixel of this wave
+        const size_t pw = (size_t)bx * 256 + (threadIdx.x >> 6) * 64;     // first pixel of this wave
         float4 ld[CIN / 4];
 #pragma unroll
         for (int i = 0; i < CIN / 4; ++i) {
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* __restrict__ in
         // consecutive lanes on consecutive float4s (a wave's LDS operations execute in order: no barrier)
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         float* st = wreg;
-        const size_t p0 = (size_t)blockIdx.x * 256 + wv * 64;          // first pixel of this wave
+        const size_t p0 = (size_t)bx * 256 + wv * 64;          // first pixel of this wave
         float4 r[17];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -920,6 +921,23 @@ __global__ __launch_bounds__(256) void conv1x1_relu(const float* __restrict__ in
                     *reinterpret_cast<float4*>(E + base * ESTRIDE + 4 * j) = *reinterpret_cast<const float4*>(st + 4 * j);
         }
     }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv1x1_relu(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ w,
+                                                    const float* __restrict__ wsg, float* __restrict__ smap, size_t npix,
+                                                    const float* __restrict__ wproj, float* __restrict__ E)
+{
+    conv1x1_relu_body<CIN>(in, out, w, wsg, smap, npix, wproj, E, blockIdx.x);
+}
+
+// agg3 and agg4 as ONE launch: workgroups [0, nb3) are agg3's, the rest agg4's.  For a handful of images only (every launch of the
+// drop-in path's single image is 5-6 us of dispatch for microseconds of work); a batch keeps the two kernels, whose LDS adds up here.
+struct AggArgs { const float* in; float* out; const float* w; const float* wsg; float* smap; size_t npix; const float* wproj; float* E; };
+__global__ __launch_bounds__(256) void conv1x1_relu_34(AggArgs a3, AggArgs a4, unsigned nb3)
+{
+    if (blockIdx.x < nb3) conv1x1_relu_body<32>(a3.in, a3.out, a3.w, a3.wsg, a3.smap, a3.npix, a3.wproj, a3.E, blockIdx.x);
+    else conv1x1_relu_body<64>(a4.in, a4.out, a4.w, a4.wsg, a4.smap, a4.npix, a4.wproj, a4.E, blockIdx.x - nb3);
 }
 
 // ------------------------------------------------------------------------------------------------ head
@@ -1860,12 +1878,13 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             m.unscale = 1.0f / wscale.at(k1);
             const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
             // small layers are bound by per-workgroup latency: 8-row tiles (r02: b3c1 0.36 -> 0.32 ms, b3c2 0.58 -> 0.49 ms)
-            if (prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+            if (prepooled && batch < 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1, false, 2, true>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+            else if (prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
             else if (batch >= 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 2, 2, false, 4>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk), dim3(256), 0, st, m);
             else {      // a handful of images (the drop-in path runs ONE): a 15 x 20 map in 16 x 16 tiles with two n-tiles each is 4 workgroups of
                         // pure latency (41 us); 8-row tiles with one n-tile each are 16 (same weights, same arithmetic per output)
                 m.nblk = 2 * cout / 32;
-                KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 1, 1, false, 4>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+                KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 1, 1, false, 4, true>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
             }
             ConvM c2;
             c2.in = tr; c2.out = xo; c2.wp = wp(k2.c_str()); c2.bias = wp((std::string(n2) + ".bp").c_str()); c2.xf = nullptr; c2.active = nullptr;
@@ -1873,11 +1892,12 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             c2.Hi = Hi / 4; c2.Wi = Wi / 4; c2.H = Hi / 4; c2.W = Wi / 4; c2.CIN = cout; c2.COUT = cout; c2.NCH = cout / 32; c2.relu = 0; c2.nblk = 1;
             c2.istride = 2 * cout; c2.ostride = cout; c2.ooff = 0;
             c2.unscale = 1.0f / wscale.at(k2);
-            if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch), dim3(256), 0, st, c2);
+            if (cout == 32 && batch < 16) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1, false, 2, true>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch), dim3(256), 0, st, c2);
+            else if (cout == 32) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch), dim3(256), 0, st, c2);
             else if (batch >= 16) KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 16), batch), dim3(256), 0, st, c2);
             else {
                 c2.nblk = cout / 32;
-                KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch * c2.nblk), dim3(256), 0, st, c2);
+                KPB_LAUNCH(ctx, tag2.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 1, false, 2, true>), dim3(cdiv(c2.W, 16), cdiv(c2.H, 8), batch * c2.nblk), dim3(256), 0, st, c2);
             }
         };
         block_h("b3c1", "b3c2", p2, t3r3, x3, 16, 32, H / 2, W / 2, true);
@@ -1913,8 +1933,15 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         KPB_LAUNCH(ctx, "conv1x1_agg2", conv1x1_relu<16>, dim3((unsigned)((B * P / 4 + 255) / 256)), dim3(256), 0, st, x2, a2, wp("agg2.w"), wp("head.ws") + 16, S2, B * P / 4, nullptr, nullptr);
     }
     // aggregation 1x1 + ReLU (149-150), each with its share of the score logit and -- dense mode -- of every head row
-    KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64, wp("head.wT") + 32 * 64, E3);
-    KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
+    if (batch < 16) {
+        const AggArgs g3{x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64, wp("head.wT") + 32 * 64, E3};
+        const AggArgs g4{x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4};
+        const unsigned nb3 = (unsigned)((B * P / 64 + 255) / 256), nb4 = (unsigned)((B * P / 1024 + 255) / 256);
+        KPB_LAUNCH(ctx, "conv1x1_agg34", conv1x1_relu_34, dim3(nb3 + nb4), dim3(256), 0, st, g3, g4, nb3);
+    } else {
+        KPB_LAUNCH(ctx, "conv1x1_agg3", conv1x1_relu<32>, dim3((unsigned)((B * P / 64 + 255) / 256)), dim3(256), 0, st, x3, a3, wp("agg3.w"), wp("head.ws") + 32, S3, B * P / 64, wp("head.wT") + 32 * 64, E3);
+        KPB_LAUNCH(ctx, "conv1x1_agg4", conv1x1_relu<64>, dim3((unsigned)((B * P / 1024 + 255) / 256)), dim3(256), 0, st, x4, a4, wp("agg4.w"), wp("head.ws") + 48, S4, B * P / 1024, wp("head.wT") + 48 * 64, E4);
+    }
     // upsample + concat + head (151-162)
     if (desc_out_dev) {
         HybArgs hy{x1, a2, E3, E4, wp("agg1.w"), wp("head.wT"), wp("head.ws"), score_out_dev, desc_out_dev, H, W, amax_x1, amax_a2, 0.f, 1.f, 1.f, nullptr, 1.f};

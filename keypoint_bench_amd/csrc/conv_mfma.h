@@ -291,8 +291,13 @@ constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
     return MT * NTB >= 4 ? ((KS == 5 && CC == 32) || POOL_IN ? 2 : 3) : (MT * NTB == 2 ? (KS == 3 && CC == 16 ? 3 : 4) : 5);
 }
 
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2>
-__global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
+// WPRE (r04): the latency form for grids that cannot fill the chip (one image on the drop-in path: 2-16 workgroups per layer, each a
+// chain of dependent round trips -- per tap a weight fetch, then LDS reads, then the products).  The weight fragments of ALL taps of a
+// slab are requested before the slab's input is even loaded and land while it is staged: one round trip per slab instead of ten.
+// Costs T x 4 NTB NKB registers (144 for a 3 x 3 kernel, one n-tile), irrelevant at one wave per SIMD; the arithmetic and its order
+// are those of the throughput form.
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false>
+__global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
@@ -329,6 +334,20 @@ __global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) v
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
     for (int ch = 0; ch < a.NCH; ++ch) {
+        cm_h8 Wh[WPRE ? T : 1][NTB][NKB], Wl[WPRE ? T : 1][NTB][NKB];
+        if constexpr (WPRE) {
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const uint4* bp = wq + ((((size_t)nt0 * T + tap) * a.NCH + ch) * NKB * 4 + h) * 32 + p;
+#pragma unroll
+                for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        Wh[tap][n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 0) * 32]);
+                        Wl[tap][n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 2) * 32]);
+                    }
+            }
+        }
         float4 buf[NLD];
         float amax = 0.0f;
 #pragma unroll
@@ -400,6 +419,34 @@ __global__ __launch_bounds__(256, conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) v
         }
         __syncthreads();
         float xpart = 0.0f;      // XC: this slab's share of the extra channel, in the slab's activation scale
+        static_assert(!WPRE || !XC, "conv_mfma_h: no latency form of the extra-channel layers");
+        if constexpr (WPRE) {
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const int ky = tap / KS, kx = tap - ky * KS;
+                cm_h8 Ah[MT][NKB], Al[MT][NKB];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int orow = 2 * (wv * MT + m) + (p >> 4);
+                    const unsigned char* ap = &tile[(orow * S + ky) * ROWP + (ocol * S + kx) * PITCH + h * KC * 2];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
+                        Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + LO + 16 * kb));
+                    }
+                }
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NTB; ++n) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[m][kb], Wh[tap][n][kb], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Wl[tap][n][kb], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Wh[tap][n][kb], acc[m][n], 0, 0, 0);
+                        }
+            }
+        } else
 #pragma unroll 1
         for (int tap = 0; tap < T; ++tap) {
             const int ky = tap / KS, kx = tap - ky * KS;

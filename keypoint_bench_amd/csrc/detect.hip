@@ -703,6 +703,7 @@ struct SelArgs {
     int* host_status;            // ... copied with the count to pinned host memory: [B][3] = (lastchg, negflag, n), or null
     int* chunk_cnt;              // [B][nchunks] two-phase form (small batches): select_scan has left chunk c's candidates at
     int nchunks;                 //   cand[c * SEL_CHUNK ...] and their number here; null: select_topk scans the map itself
+    int lcap;                    // two-phase form: candidates that fit in LDS behind the kpad selection slots
 };
 
 __device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned long long* src, int n,
@@ -829,23 +830,54 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
 
     // A2 + A3: border mask and raster-order compaction of map > threshold
     int n = 0;
+    const unsigned long long* cl = cand;        // the raster-ordered candidate list the selection below reads
     if (a.chunk_cnt) {
-        // two-phase form: the scan ran as select_scan on (nchunks x batch) workgroups; here the chunks' lists are closed up into one
-        // raster-ordered list at the front of cand.  Every move goes LEFT (a chunk never holds more than its SEL_CHUNK pixels), so
-        // a block-wide step may read, synchronise, write: its destination ends where the next step's source begins at the latest.
+        // two-phase form: the scan ran as select_scan on (nchunks x batch) workgroups and left chunk c's list at cand[c * SEL_CHUNK].
         const int* cc = a.chunk_cnt + (size_t)img * a.nchunks;
-        for (int c = 0; c < a.nchunks; ++c) {
-            const int cnt = cc[c];
-            const unsigned long long* src = cand + (size_t)c * SEL_CHUNK;
-            if (n != c * SEL_CHUNK)
-                for (int j0 = 0; j0 < cnt; j0 += SEL_THREADS) {
-                    const int j = j0 + tid;
-                    const unsigned long long v = j < cnt ? src[j] : 0ull;
-                    __syncthreads();
-                    if (j < cnt) cand[n + j] = v;
-                    __syncthreads();
-                }
-            n += cnt;
+        __shared__ int s_off[65];
+        bool local = a.nchunks <= 64 && a.lcap > 0;
+        if (local) {
+            if (tid < 64) {
+                const int c = tid < a.nchunks ? cc[tid] : 0;
+                int inc = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (tid >= o) inc += v; }
+                s_off[tid + 1] = inc;
+                if (tid == 0) s_off[0] = 0;
+            }
+            __syncthreads();
+            n = s_off[a.nchunks];
+            local = n <= a.lcap;
+        }
+        if (local) {
+            // The lists are gathered into LDS behind `sel` by all threads at once (independent loads: a few round trips).  Closing
+            // them up in place, chunk after chunk, was 19 dependent read-synchronise-write steps: 28 of select_topk's 40 us on the
+            // single map of the drop-in path; the radix passes below then read LDS instead of global memory.
+            unsigned long long* lc = sel + a.kpad;
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                int lo = 0, hi = a.nchunks - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid - 1; }
+                lc[i] = cand[(size_t)lo * SEL_CHUNK + (i - s_off[lo])];
+            }
+            cl = lc;
+        } else {
+            // too many candidates (or chunks) for LDS: the lists are closed up into one at the front of cand.  Every move goes LEFT
+            // (a chunk never holds more than its SEL_CHUNK pixels), so a block-wide step may read, synchronise, write: its
+            // destination ends where the next step's source begins at the latest.
+            n = 0;
+            for (int c = 0; c < a.nchunks; ++c) {
+                const int cnt = cc[c];
+                const unsigned long long* src = cand + (size_t)c * SEL_CHUNK;
+                if (n != c * SEL_CHUNK)
+                    for (int j0 = 0; j0 < cnt; j0 += SEL_THREADS) {
+                        const int j = j0 + tid;
+                        const unsigned long long v = j < cnt ? src[j] : 0ull;
+                        __syncthreads();
+                        if (j < cnt) cand[n + j] = v;
+                        __syncthreads();
+                    }
+                n += cnt;
+            }
         }
         __syncthreads();
     } else {
@@ -854,7 +886,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
     }
 
     if (n <= a.top_k) {  // raster order kept (extracter.py:217)
-        emit(a, img, cand, n, wsum);
+        emit(a, img, cl, n, wsum);
         return;
     }
 
@@ -866,7 +898,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
         const unsigned prefix = s_prefix;
         const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
         for (int i = tid; i < n; i += SEL_THREADS) {
-            const unsigned k = (unsigned)(cand[i] >> 32);
+            const unsigned k = (unsigned)(cl[i] >> 32);
             if ((k & himask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
         }
         __syncthreads();
@@ -906,7 +938,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
         unsigned long long ent = 0;
         bool gt = false, eq = false;
         if (i < n) {
-            ent = cand[i];
+            ent = cl[i];
             const unsigned k = (unsigned)(ent >> 32);
             gt = k > T;
             eq = k == T;
@@ -1172,14 +1204,16 @@ int det_select(kpb_ctx* ctx, const DetState& d)
         ctx->host_det_cap = 3 * d.batch;
     }
     s.host_status = ctx->host_det;
-    s.chunk_cnt = nullptr; s.nchunks = cdiv(d.H * d.W, SEL_CHUNK);
+    s.chunk_cnt = nullptr; s.nchunks = cdiv(d.H * d.W, SEL_CHUNK); s.lcap = 0;
+    size_t lds = (size_t)s.kpad * sizeof(unsigned long long);
     if (d.batch < 64 && s.nchunks > 1) {       // too few images to fill the chip with one workgroup each: scan in (chunks x batch) workgroups first
         if (int rc = kpb_reserve(ctx, ctx->ws_sel, (size_t)d.batch * s.nchunks * sizeof(int))) return rc;
         s.chunk_cnt = static_cast<int*>(ctx->ws_sel.p);
+        s.lcap = (int)((64 * 1024 - lds) / sizeof(unsigned long long));        // (the attribute set in nms_plan allows 64 KB)
+        lds = 64 * 1024;
         KPB_LAUNCH(ctx, "select_scan", select_scan, dim3(s.nchunks, d.batch), dim3(SEL_THREADS), 0, ctx->stream, s);
     }
-    KPB_LAUNCH(ctx, "select_topk", select_topk, dim3(d.batch), dim3(SEL_THREADS), (size_t)s.kpad * sizeof(unsigned long long),
-                       ctx->stream, s);
+    KPB_LAUNCH(ctx, "select_topk", select_topk, dim3(d.batch), dim3(SEL_THREADS), lds, ctx->stream, s);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }
@@ -1221,6 +1255,8 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
         // tiled sweeps enqueued before the first look at the status: an ALIKE map is at its fixed point after 3-4 of them; a sweep
         // with nothing to do still costs its launch (5 us each on the single map of the drop-in path), an early look costs a
         // synchronisation -- 6 for batches (amortised), 4 when a few images are all there is
+        // (r04, 96 single maps -- synthetic pairs and warped views: none is confirmed at its fixed point by three sweeps, 86 are by
+        //  four, the other 10 take a second chunk)
         const int chunk = batch >= 16 ? 6 : 4;
         if (int rc = nms_open(ctx, d.plan, score_dev, d.cur, batch, H, W, prm->nms_dist, chunk, d.sweeps_run)) return rc;
     }
