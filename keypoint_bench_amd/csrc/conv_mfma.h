@@ -37,6 +37,8 @@ struct ConvM {
     const float* aux1 = nullptr;
     float* out1 = nullptr;
     float* out2 = nullptr;
+    int unfold_w = 0;             // gemm_h<.., UNFOLD>: `in` is a single-channel [B][8 H][unfold_w] image and row r, channel c stand for pixel
+                                  // (8 (r / W) + c / 8, 8 (r % W) + c % 8): XFeat's _unfold2d(x, 8) read in place (XFeat.py:96-103, 138)
 };
 
 // gemm_h epilogues.  GE_RESIDUAL: out = res + (W x + b), rows of `res` rstride floats apart (lightglue.py:185 / 242, x + ffn(...)).
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
 // of slab c) and go into the OTHER of two LDS buffers behind them, so there is one barrier per slab and the loads fly
 // under the matrix work.  Workgroup = 256 rows x 32 NTB columns; wave = 64 rows (two M tiles); weights in pack_mfma_h's
 // KS = 1 order; LDS rows as in conv_mfma_h (hi | lo | pad, 144 bytes: nine 16-byte slots, conflict-free).
-template <int NTB, int MT = 2, int EPI = GE_PLAIN>
+template <int NTB, int MT = 2, int EPI = GE_PLAIN, bool UNFOLD = false>
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
 {
     // r03: a wave stages exactly the 32 MT rows it multiplies, so its slice of the LDS buffers is private to it (a wave's LDS
@@ -598,7 +600,13 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
         for (int k = 0; k < NLD; ++k) {
             const int idx = lane + k * 64, row = idx / Q, q = idx - row * Q;
             buf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < nrows) buf[k] = *reinterpret_cast<const float4*>(in + (size_t)(r0 + row) * a.istride + ch * CC + 4 * q);
+            if (r0 + row < nrows) {
+                if constexpr (UNFOLD) {       // channels 32 ch + 4 q .. + 3 of cell (Y, X) = four adjacent pixels of cell row 4 ch + q / 2
+                    const int r = r0 + row, Y = r / a.W, X = r - Y * a.W;
+                    buf[k] = *reinterpret_cast<const float4*>(a.in + ((size_t)b * 8 * a.H + 8 * Y + 4 * ch + (q >> 1)) * a.unfold_w + 8 * X + 4 * (q & 1));
+                } else
+                    buf[k] = *reinterpret_cast<const float4*>(in + (size_t)(r0 + row) * a.istride + ch * CC + 4 * q);
+            }
         }
     };
     auto stage = [&](int which, bool first) {

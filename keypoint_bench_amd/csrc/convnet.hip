@@ -203,6 +203,230 @@ __global__ __launch_bounds__(256) void xfeat_block1_01(const float* __restrict__
     }
 }
 
+// XFeat block1.2 (8 -> 8, 3x3) + block1.3 (8 -> 24, 3x3, stride 2) + the skip connection, on the matrix cores (r04; XFeat.py:32-33,
+// 27-28, 127).  As fp32 vector kernels the two layers were bound by vector issue (576 / 1 728 FMAs per output pixel: 1.04 + 0.96 ms per
+// 512 images against 0.3 ms of traffic each) and the 8-channel half-resolution map between them went through HBM.  Here both are
+// v_mfma_f32_16x16x32_f16 products on split operands (x = hi + lo halves, three MFMAs per product, fp32 accumulation: the arithmetic of
+// every other layer of the net from block2 on), the map between them stays in LDS:
+//   conv A (8 -> 8, stride 1), alike_block1_h's conv2 form: one accumulator column stands for a PAIR of horizontally adjacent positions,
+//     N = (position of the pair, output channel), K = the 3 x 4 input window the pair shares = three 32-deep k-blocks (kb = window row,
+//     lane group g = window column); the weight of window cell (ky, kx) for position s is w[ky][kx - s], zero outside the kernel.
+//   conv B (8 -> 24, stride 2): M = 16 output channels (two tiles: 24 real rows of 32), N = 16 adjacent outputs of a row, K = three
+//     k-blocks (kb = ky; lane group = kx, the fourth group's weights are zero).
+// Both read their input from LDS planes [hi | lo][column parity][row][column / 2] of 16-byte slots (8 channels of one position): the 16
+// lanes of a read group hit 16 consecutive slots whether neighbouring lanes are two columns apart (pairs; stride 2) or one.
+// Operand range: the tile is split at the scale of its own largest input magnitude (cm_scale_of), conv A's output at the scale of its
+// bound amax l1 + bmax; both are divided out of the fp32 accumulators again, exactly.  Workgroup = 8 x 16 outputs of block1.3.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+struct XfB1Args {
+    const float* in;        // block1.1's output [B][H2][W2][8]
+    float* out;             // x1 [B][H4][W4][32]: 24 channels + 8 zeros (the MFMA layers behind it read 32)
+    const uint4* wA;        // [3 kb][hi / lo][64 lanes]: conv A pair fragments, scaled by 1 / inv_wsA
+    const uint4* wB;        // [2 m-tiles][3 kb][hi / lo][64 lanes]: conv B fragments, scaled by 1 / inv_wsB
+    const float* bA; const float* bB;       // biases [8], [32] (zero padded)
+    const float* gray; const float* skw; const float* skb;      // the skip connection: avg_pool4(gray) * skw[c] + skb[c], c < 24, added after the ReLU
+    int H2, W2;
+    float inv_wsA, inv_wsB, l1A, bmaxA;
+};
+constexpr int XQ_TH = 8, XQ_TW = 16;                               // outputs per workgroup (quarter resolution)
+constexpr int XQ_MH = 2 * XQ_TH + 1, XQ_MW = 2 * XQ_TW + 1;         // conv A positions conv B taps (half resolution)
+constexpr int XQ_IH = XQ_MH + 2, XQ_IW = XQ_MW + 2;                 // input positions conv A taps
+constexpr int XQ_HWM = (XQ_MW + 1) / 2, XQ_HWI = (XQ_IW + 1) / 2;   // slots per row and parity
+constexpr int XQ_PLM = XQ_MH * XQ_HWM, XQ_REGM = 2 * XQ_PLM, XQ_PLI = XQ_IH * XQ_HWI, XQ_REGI = 2 * XQ_PLI;
+
+__global__ __launch_bounds__(256, 4) void xfeat_block1_23(XfB1Args a)
+{
+    __shared__ __attribute__((aligned(16))) uint4 pin[2 * XQ_REGI];      // [hi | lo][parity][row][column / 2]
+    __shared__ __attribute__((aligned(16))) uint4 mid[2 * XQ_REGM];
+    __shared__ __attribute__((aligned(16))) float s_amax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = blockIdx.z;
+    const int H4 = a.H2 / 2, W4 = a.W2 / 2;
+    const int oy0 = blockIdx.y * XQ_TH, ox0 = blockIdx.x * XQ_TW;        // first output of the tile
+    const int my0 = 2 * oy0 - 1, mx0 = 2 * ox0 - 1;                       // first conv A position (half resolution)
+    const int iy0 = my0 - 1, ix0 = mx0 - 1;                               // first input position
+    const float* in = a.in + (size_t)b * a.H2 * a.W2 * 8;
+    cm_h8 wAh[3], wAl[3];
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        wAh[kb] = __builtin_bit_cast(cm_h8, a.wA[(kb * 2 + 0) * 64 + lane]);
+        wAl[kb] = __builtin_bit_cast(cm_h8, a.wA[(kb * 2 + 1) * 64 + lane]);
+    }
+    const int pr = lane & 15, g = lane >> 4;
+    const float4 biasA = *reinterpret_cast<const float4*>(a.bA + 4 * (g & 1));
+    int e_in;
+    {   // stage the input tile: a thread takes half positions (4 channels), all its loads in flight before the first use
+        constexpr int NH = XQ_IH * XQ_IW * 2, PER = (NH + 255) / 256;
+        float4 ld[PER];
+        float am = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * 256, pos = i >> 1, y = pos / XQ_IW, x = pos - y * XQ_IW;
+            const int gy = iy0 + y, gx = ix0 + x;
+            const bool ok = i < NH && gy >= 0 && gy < a.H2 && gx >= 0 && gx < a.W2;
+            ld[k] = ok ? *reinterpret_cast<const float4*>(in + ((size_t)gy * a.W2 + gx) * 8 + 4 * (i & 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            am = cm_amax4(am, ld[k]);
+        }
+        am = cm_wave_max(am);
+        if (lane == 0) s_amax[wv] = am;
+        // the pad column (odd parity, last slot of every row) is read by the last pair's window: finite zeros
+        for (int i = tid; i < 2 * XQ_IH; i += 256) pin[(i / XQ_IH) * XQ_REGI + XQ_PLI + (i % XQ_IH) * XQ_HWI + XQ_HWI - 1] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const float4 q = *reinterpret_cast<const float4*>(s_amax);
+        e_in = cm_exp_of(fmaxf(fmaxf(q.x, q.y), fmaxf(q.z, q.w)));
+        const float sc = cm_scale_of(e_in);
+        uint2* pinh = reinterpret_cast<uint2*>(pin);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = tid + k * 256, pos = i >> 1, y = pos / XQ_IW, x = pos - y * XQ_IW;
+            uint2 hi, lo;
+            cm_split4(make_float4(ld[k].x * sc, ld[k].y * sc, ld[k].z * sc, ld[k].w * sc), hi, lo);
+            if (i < NH) {
+                const int h8 = (((x & 1) * XQ_PLI + y * XQ_HWI + (x >> 1)) << 1) + (i & 1);
+                pinh[h8] = hi;
+                pinh[h8 + 2 * XQ_REGI] = lo;
+            }
+        }
+    }
+    __syncthreads();
+    const int e_mid = cm_exp_of(fmaf(__uint_as_float((unsigned)(e_in - 126 + 127) << 23), a.l1A, a.bmaxA));
+    const float unA = a.inv_wsA * cm_unscale_of(e_in), sc_mid = cm_scale_of(e_mid), unB = a.inv_wsB * cm_unscale_of(e_mid);
+    const int sN = g >> 1;                            // conv A accumulator: position sN of the pair, channels 4 (g & 1) .. + 3
+    {   // conv A + ReLU on the MH x MW positions, 16 pairs per MFMA group: group gi < MH = pairs 0..15 of row gi; the 17th pair of
+        // every row goes to two extra groups (rows 0..15 and row 16)
+        uint2* midh = reinterpret_cast<uint2*>(mid);
+#pragma unroll 1
+        for (int gi = wv; gi < XQ_MH + (XQ_MH + 15) / 16; gi += 4) {
+            const bool extra = gi >= XQ_MH;
+            const int y = extra ? 16 * (gi - XQ_MH) + pr : gi, pc = extra ? 16 : pr;
+            const int my = min(y, XQ_MH - 1);
+            f32x4m acc = {0.f, 0.f, 0.f, 0.f};
+            const int abase = (g & 1) * XQ_PLI + my * XQ_HWI + pc + (g >> 1);
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                const cm_h8 ihi = __builtin_bit_cast(cm_h8, pin[abase + kb * XQ_HWI]);
+                const cm_h8 ilo = __builtin_bit_cast(cm_h8, pin[XQ_REGI + abase + kb * XQ_HWI]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wAh[kb], ilo, acc, 0, 0, 0);      // small terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wAl[kb], ihi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wAh[kb], ihi, acc, 0, 0, 0);
+            }
+            const int gy = my0 + y, gx = mx0 + 2 * pc + sN;
+            const bool inside = gy >= 0 && gy < a.H2 && gx >= 0 && gx < a.W2;       // conv B pads its INPUT (the ReLU'd map) with zeros
+            float4 v = make_float4(relu(fmaf(acc[0], unA, biasA.x)) * sc_mid, relu(fmaf(acc[1], unA, biasA.y)) * sc_mid,
+                                   relu(fmaf(acc[2], unA, biasA.z)) * sc_mid, relu(fmaf(acc[3], unA, biasA.w)) * sc_mid);
+            if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 hi, lo;
+            cm_split4(v, hi, lo);
+            if (y < XQ_MH) {
+                const int h8 = ((sN * XQ_PLM + y * XQ_HWM + pc) << 1) + (g & 1);
+                midh[h8] = hi;
+                midh[h8 + 2 * XQ_REGM] = lo;
+            }
+        }
+    }
+    cm_h8 wBh[2][3], wBl[2][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            wBh[mt][kb] = __builtin_bit_cast(cm_h8, a.wB[((mt * 3 + kb) * 2 + 0) * 64 + lane]);
+            wBl[mt][kb] = __builtin_bit_cast(cm_h8, a.wB[((mt * 3 + kb) * 2 + 1) * 64 + lane]);
+        }
+    float4 biasB[2], skw[2], skb[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int c = 16 * mt + 4 * g;
+        biasB[mt] = *reinterpret_cast<const float4*>(a.bB + c);
+        skw[mt] = c < 24 ? *reinterpret_cast<const float4*>(a.skw + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        skb[mt] = c < 24 ? *reinterpret_cast<const float4*>(a.skb + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    // conv B + ReLU + skip: a wave owns two output rows; lane (n = output column, g): tap column g of row 2 ly + kb at column 2 n + g
+    const int bbase = (g & 1) * XQ_PLM + pr + (g >> 1);
+    const int ox = ox0 + pr, Wg = 2 * a.W2;
+    const float* gimg = a.gray + (size_t)b * (2 * a.H2) * Wg;
+#pragma unroll
+    for (int rr = 0; rr < XQ_TH / 4; ++rr) {
+        const int ly = (XQ_TH / 4) * wv + rr, oy = oy0 + ly;
+        const bool live = oy < H4 && ox < W4;
+        // the skip term's 4 x 4 grey patch is requested before the products, by the first lane group only (all four groups of a column
+        // need the same average).  Requested earlier -- at the top of the kernel, or once the input tile has landed -- the kernel was
+        // 6-12 % slower.
+        float4 gp[4];
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+            gp[dy] = (live && g == 0) ? *reinterpret_cast<const float4*>(gimg + (size_t)(4 * oy + dy) * Wg + 4 * ox) : make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4m acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int kb = 0; kb < 3; ++kb) {
+            const int at = bbase + (2 * ly + kb) * XQ_HWM;
+            const cm_h8 ihi = __builtin_bit_cast(cm_h8, mid[at]);
+            const cm_h8 ilo = __builtin_bit_cast(cm_h8, mid[XQ_REGM + at]);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wBh[mt][kb], ilo, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wBl[mt][kb], ihi, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wBh[mt][kb], ihi, acc[mt], 0, 0, 0);
+            }
+        }
+        float sacc = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy) { sacc += gp[dy].x; sacc += gp[dy].y; sacc += gp[dy].z; sacc += gp[dy].w; }       // avg_pool2d's order (conv_valu_t)
+        const float avg = __shfl(sacc * (1.0f / 16.0f), pr, 64);
+        if (live) {
+            float* o = a.out + (((size_t)b * H4 + oy) * W4 + ox) * 32 + 4 * g;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float4 v = make_float4(relu(fmaf(acc[mt][0], unB, biasB[mt].x)), relu(fmaf(acc[mt][1], unB, biasB[mt].y)),
+                                       relu(fmaf(acc[mt][2], unB, biasB[mt].z)), relu(fmaf(acc[mt][3], unB, biasB[mt].w)));
+                if (16 * mt + 4 * g < 24) {
+                    v.x += fmaf(avg, skw[mt].x, skb[mt].x); v.y += fmaf(avg, skw[mt].y, skb[mt].y);
+                    v.z += fmaf(avg, skw[mt].z, skb[mt].z); v.w += fmaf(avg, skw[mt].w, skb[mt].w);
+                }
+                *reinterpret_cast<float4*>(o + 16 * mt) = v;
+            }
+        }
+    }
+}
+
+// conv A of xfeat_block1_23, OIHW [8][8][3][3] -> [3 kb = ky][hi / lo][64 lanes][8 halves = cin]: lane (n = (s, cout), g = column of the
+// 3 x 4 window) holds w[cout][cin][ky][g - s], zero outside the kernel (alike.hip's pack_b1c2_pairs: the same product)
+std::vector<float> pack_xf_pairs(const float* w, float scale)
+{
+    std::vector<uint16_t> hl((size_t)3 * 2 * 64 * 8, 0);
+    for (int kb = 0; kb < 3; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int n = l & 15, g = l >> 4, s2 = n >> 3, co = n & 7, kx = g - s2;
+                const float v = (kx >= 0 && kx <= 2) ? w[((size_t)co * 8 + j) * 9 + kb * 3 + kx] * scale : 0.0f;
+                const uint16_t hi = f16_bits_rtn(v), lo = f16_bits_rtn(v - f16_bits_to_float(hi));
+                hl[(((size_t)kb * 2 + 0) * 64 + l) * 8 + j] = hi;
+                hl[(((size_t)kb * 2 + 1) * 64 + l) * 8 + j] = lo;
+            }
+    std::vector<float> out(hl.size() / 2);
+    std::memcpy(out.data(), hl.data(), hl.size() * 2);
+    return out;
+}
+
+// conv B, OIHW [COUT <= 32][8][3][3] -> [2 m-tiles][3 kb = ky][hi / lo][64 lanes][8 halves = cin]: lane (m = output channel of the tile,
+// kq = kx; kq = 3 and channels >= COUT are zero)
+std::vector<float> pack_xf_s2(const float* w, int cout, float scale)
+{
+    std::vector<uint16_t> hl((size_t)2 * 3 * 2 * 64 * 8, 0);
+    for (int mt = 0; mt < 2; ++mt)
+        for (int kb = 0; kb < 3; ++kb)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 8; ++j) {
+                    const int m = l & 15, kq = l >> 4, co = 16 * mt + m;
+                    const float v = (kq <= 2 && co < cout) ? w[((size_t)co * 8 + j) * 9 + kb * 3 + kq] * scale : 0.0f;
+                    const uint16_t hi = f16_bits_rtn(v), lo = f16_bits_rtn(v - f16_bits_to_float(hi));
+                    hl[((((size_t)mt * 3 + kb) * 2 + 0) * 64 + l) * 8 + j] = hi;
+                    hl[((((size_t)mt * 3 + kb) * 2 + 1) * 64 + l) * 8 + j] = lo;
+                }
+    std::vector<float> out(hl.size() / 2);
+    std::memcpy(out.data(), hl.data(), hl.size() * 2);
+    return out;
+}
+
 // SuperPoint conv1a (1 -> 64, 3x3, ReLU; SuperPoint.py:44): 16 lanes share a pixel, each lane keeps the 9 taps of its
 // 4 output channels in registers and walks down a column of pixels, so a wave store is 4 whole 256-byte pixels.
 __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block)
@@ -427,14 +651,16 @@ struct Layer {      // one convolution of a network plan
 };
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr)
+                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0)
 {
     const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
     ConvM a;
     a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf; a.res = nullptr;
     a.active = nullptr; a.istride = L.cin; a.ostride = L.cout; a.ooff = 0;
-    a.Hi = Hi; a.Wi = Wi;
+    a.Hi = Hi; a.Wi = Wi; a.unfold_w = unfold_w;
+    if (unfold_w && !(conv_mfma_use_h16() && L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !xf && L.cin == 64))
+        return kpb_fail(ctx, KPB_E_INVALID, "launch_mfma: the unfolded input exists for 64-channel 1x1 layers of the split-f16 form only");
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
     a.CIN = L.cin; a.COUT = L.cout; a.NCH = L.cin / CC; a.relu = relu_ ? 1 : 0; a.nblk = (L.cout + 32 * L.ntb - 1) / (32 * L.ntb);
     hipStream_t st = ctx->stream;
@@ -449,6 +675,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && unfold_w) KPB_LAUNCH(ctx, name, (gemm_h<2, 1, GE_PLAIN, true>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2, 1>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 2, 2>), g2, block, 0, st, a);
@@ -670,6 +897,13 @@ struct XFeatNet : kpb_net {
                        wp("block1.0.w"), wp("block1.0.b"), wp("block1.1.w"), wp("block1.1.b"), H, W);
             (void)a1;
         }
+        if (conv_mfma_use_h16()) {      // block1.2 + block1.3 + skip on the matrix cores, the map between them in LDS (xfeat_block1_23)
+            XfB1Args xa{b1, x1, reinterpret_cast<const uint4*>(wp("block1.23.wA")), reinterpret_cast<const uint4*>(wp("block1.23.wB")),
+                        wp("block1.23.bA"), wp("block1.23.bB"), gray, wp("skip1.w"), wp("skip1.b"), H2, W2,
+                        wscale.at("block1.23.inv_wsA"), wscale.at("block1.23.inv_wsB"), wscale.at("block1.23.l1A"), wscale.at("block1.23.bmaxA")};
+            KPB_LAUNCH(ctx, "xf_block1.23", xfeat_block1_23, dim3(cdiv(W4, XQ_TW), cdiv(H4, XQ_TH), batch), dim3(256), 0, st, xa);
+            (void)c1;
+        } else {
         if ((rc = conv("block1.2", b1, c1, batch, H2, W2))) return rc;
         // block1's last layer with the skip connection (AvgPool2d(4) -> Conv2d(1, 24, 1), XFeat.py:27-28, 127) added in its epilogue:
         // as a kernel of its own (r02: xf_skip_add, 1.12 ms per 512 images) it read x1 back and wrote it again
@@ -678,6 +912,7 @@ struct XFeatNet : kpb_net {
             if (l.mfma || l.ks != 3 || l.cin != 8 || l.stride != 2 || ((l.cout + 7) / 8) * 8 != 32)
                 return kpb_fail(ctx, KPB_E_INVALID, "XFeat block1.3: unexpected layer plan");
             if ((rc = launch_valu(ctx, "xf_block1.3", this, l, c1, x1, batch, H2, W2, relu_of.at("block1.3"), nullptr, gray, wp("skip1.w"), wp("skip1.b"), 24))) return rc;
+        }
         }
         if ((rc = conv("block2.0", x1, t2, batch, H4, W4))) return rc;
         if ((rc = conv("block2.1", t2, x2, batch, H4, W4))) return rc;
@@ -699,8 +934,14 @@ struct XFeatNet : kpb_net {
         if ((rc = conv("block_fusion.2", u8[5], desc_out, batch, H8, W8))) return rc;
         KPB_LAUNCH(ctx, "xf_l2norm", l2norm_nhwc, dim3((unsigned)((B * H8 * W8 + 4 * PXW - 1) / (4 * PXW))), dim3(256), 0, st, desc_out, 64, B * H8 * W8, 1e-12f);   // F.normalize
         // keypoint head on the 8x8-unfolded normalised image (XFeat.py:138-139)
-        KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 16, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
-        if ((rc = conv("keypoint_head.0", u8[0], u8[1], batch, H8, W8))) return rc;
+        if (conv_mfma_use_h16() && L.at("keypoint_head.0").mfma && W % 8 == 0) {
+            // the first layer reads the 8 x 8 cells straight from the normalised image (ConvM::unfold_w): as a kernel of its own the
+            // unfolding wrote and re-read 0.63 GB per 512 images (xf_unfold8, 0.24 ms)
+            if ((rc = launch_mfma(ctx, "xf_keypoint_head.0", this, L.at("keypoint_head.0"), gray, u8[1], batch, H8, W8, false, false, relu_of.at("keypoint_head.0"), nullptr, W))) return rc;
+        } else {
+            KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 16, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
+            if ((rc = conv("keypoint_head.0", u8[0], u8[1], batch, H8, W8))) return rc;
+        }
         if ((rc = conv("keypoint_head.1", u8[1], u8[0], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.2", u8[0], u8[1], batch, H8, W8))) return rc;
         if ((rc = conv("keypoint_head.3", u8[1], semi, batch, H8, W8))) return rc;
@@ -740,6 +981,32 @@ int xfeat_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         stage_layer(ws, L, w, b);
         net->L[L.name] = L;
         net->relu_of[L.name] = q.relu;
+    }
+    if (conv_mfma_use_h16()) {      // the fused matrix form of block1.2 + block1.3 (xfeat_block1_23)
+        const float* wA = bl.get("block1.2.w", {8, 8, 3, 3});
+        const float* bA = bl.get("block1.2.b", {8});
+        const float* wB = bl.get("block1.3.w", {24, 8, 3, 3});
+        const float* bB = bl.get("block1.3.b", {24});
+        if (!wA || !bA || !wB || !bB || !net->relu_of.at("block1.2") || !net->relu_of.at("block1.3")) {
+            delete net;
+            return kpb_fail(ctx, KPB_E_WEIGHTS, "kpb_net_create: XFeat block1.2 / block1.3: unexpected layer plan");
+        }
+        const float scA = weight_scale_h(wA, 8 * 8 * 9), scB = weight_scale_h(wB, 24 * 8 * 9);
+        ws.put("block1.23.wA", pack_xf_pairs(wA, scA));
+        ws.put("block1.23.wB", pack_xf_s2(wB, 24, scB));
+        ws.put("block1.23.bA", pad_bias(bA, 8, 8));
+        ws.put("block1.23.bB", pad_bias(bB, 24, 32));
+        float l1 = 0.0f, bmax = 0.0f;
+        for (int o = 0; o < 8; ++o) {
+            float s1 = 0.0f;
+            for (int i = 0; i < 8 * 9; ++i) s1 += std::fabs(wA[(size_t)o * 72 + i]);
+            l1 = std::max(l1, s1);
+            bmax = std::max(bmax, std::fabs(bA[o]));
+        }
+        ws.wscale["block1.23.inv_wsA"] = 1.0f / scA;
+        ws.wscale["block1.23.inv_wsB"] = 1.0f / scB;
+        ws.wscale["block1.23.l1A"] = l1 * 1.0001f;       // the bound is taken in fp32: a hair of slack for its own rounding
+        ws.wscale["block1.23.bmaxA"] = bmax;
     }
     const float* sw = bl.get("skip1.w", {24});
     const float* sb = bl.get("skip1.b", {24});
