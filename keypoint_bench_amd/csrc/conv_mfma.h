@@ -46,7 +46,8 @@ struct ConvM {
 // elements of that head in its first tile and the 32 odd ones in its second, so a lane holds one rotary pair; q and k are rotated by
 // (aux0, aux1) = (cos, sin) [row][32] and all three go out head-major as float2 (lightglue.py:71-78, 179-183).
 // GE_SPLIT2: output tiles from column 256 on go to out1 (two Linears over the same input as one product).
-enum { GE_PLAIN = 0, GE_RESIDUAL = 1, GE_ROTARY = 2, GE_SPLIT2 = 3 };
+// GE_L2NORM: COUT = 64 = the workgroup's two tiles, so a wave holds whole rows: out = v / max(||v||_2, xb) (F.normalize, XFeat.py:136).
+enum { GE_PLAIN = 0, GE_RESIDUAL = 1, GE_ROTARY = 2, GE_SPLIT2 = 3, GE_L2NORM = 4 };
 
 template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2>
 __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
@@ -198,18 +199,6 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvM a)
 typedef _Float16 cm_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
 
-// x - (float)h for the low (HI = 0) or high (HI = 1) half of a packed f16 pair, in ONE instruction: v_fma_mix_f32 converts the
-// f16 source on the fly (exactly) and the fused multiply-add by 1.0 rounds once -- x - hi is exact anyway.  The plain form
-// (v_cvt_f32_f16 + v_sub_f32) costs two issue slots per element in kernels that are bound by vector issue.
-template <int HI>
-__device__ __forceinline__ float cm_residual(float x, unsigned packed)
-{
-    float r;
-    if (HI) asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(x));
-    else asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(packed), "v"(x));
-    return r;
-}
-
 // fp32 x 2 -> (hi, lo) half-precision pairs: hi = f16(x), lo = f16(x - hi), BOTH rounded to nearest (v_cvt_pk_f16_f32, new on
 // gfx950; r02-r03 used v_cvt_pkrtz).  Toward zero leaves |x - hi| < 2^-10 |x| and a lo half that is itself truncated: x is
 // represented to 2^-20 |x| in the worst case, 2^-22 on average -- 21-22 significant bits against fp32's 24.  To nearest halves both
@@ -222,10 +211,22 @@ __device__ __forceinline__ unsigned cm_cvt_pk_rtn(float x, float y)
     const cm_f2 v = {x, y};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h2_t));
 }
+// The residuals x - (float)hi are plain C: v_cvt_f32_f16 + a (packed) subtraction, exact (x - hi fits fp32).
+// NO INLINE ASSEMBLY HERE (r04).  r03-r04 computed them with v_fma_mix_f32 from an asm statement (one issue slot less per element).
+// v_fma_mix_f32, like the packed fp32 instructions hipcc feeds these operands from (v_pk_mul_f32, v_pk_fma_f32), is a VOP3P
+// instruction: its result -- and a packed result it consumes -- needs ONE wait state before a dependent vector instruction, and the
+// upper 16 lanes of each half-wave are what a too-early reader gets stale.  The compiler pads the pairs it can see (`v_pk_mul_f32 ...;
+// s_nop 0; v_cvt_pk_f16_f32 ...` is all over the ISA); it does not look inside an asm string, and whether a dependent instruction
+// lands right behind one is a matter of scheduling and of what else the SIMD issues in between.  Effect: run-to-run differences of
+// 1e-5 .. 1e-1 in 16-pixel groups of ~0.5 % of ALIKE's dense maps from the moment the head's a2 interpolation compiled to
+// v_pk_fma_f32 (775c39f) -- inside every parity tolerance, caught by one shape test failing once.  Found with
+// scripts/determinism_probe.py (run against run, bit for bit), bisected over commits, pinned by tests/test_gpu_determinism.py.
 __device__ __forceinline__ void cm_split2(float x, float y, unsigned& hi, unsigned& lo)
 {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     hi = cm_cvt_pk_rtn(x, y);
-    lo = cm_cvt_pk_rtn(cm_residual<0>(x, hi), cm_residual<1>(y, hi));
+    const h2_t hh = __builtin_bit_cast(h2_t, hi);
+    lo = cm_cvt_pk_rtn(x - (float)hh[0], y - (float)hh[1]);
 }
 
 __device__ __forceinline__ void cm_split4(const float4 v, uint2& hi, uint2& lo)
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
     const int nrows_all = a.H * a.W, r0 = blockIdx.x * ROWS + WROWS * wv;      // this wave's first row
     const int nrows = a.rowcnt ? min(nrows_all, a.rowcnt[b]) : nrows_all;
     if (r0 >= nrows) return;                                     // wave-level: the kernel has no barrier
-    if (EPI != GE_PLAIN && blockIdx.x * ROWS + ROWS > nrows_all) return;     // the fused forms read whole row tiles (LightGlue pads to 128 rows)
+    if ((EPI == GE_RESIDUAL || EPI == GE_ROTARY) && blockIdx.x * ROWS + ROWS > nrows_all) return;     // these forms read whole row tiles ahead (LightGlue pads to 128 rows)
     const float* in = a.in + (size_t)b * nrows_all * a.istride;
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)a.NCH * NKB * 4 * 32;
@@ -726,6 +727,26 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
                     o.y = __fadd_rn(__fmul_rn(od, c), __fmul_rn(ev, s));
                 }
                 *reinterpret_cast<float2*>(dst + (size_t)row * 256) = o;
+            }
+        return;
+    }
+    if constexpr (EPI == GE_L2NORM) {
+        static_assert(EPI != GE_L2NORM || NTB == 2, "gemm_h: the norm is taken over the workgroup's two tiles");
+        float* o = a.out + (size_t)b * nrows_all * a.ostride + a.ooff + p;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = r0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v0 = fmaf(acc[m][0][r], unscale, biasv[0]), v1 = fmaf(acc[m][1][r], unscale, biasv[1]);
+                if (a.relu) { v0 = relu(v0); v1 = relu(v1); }
+                float ss = fmaf(v0, v0, v1 * v1);                    // the 32 lanes of a half hold the row's 64 columns
+                ss += kpb_shfl_xor<16>(ss); ss += kpb_shfl_xor<8>(ss); ss += kpb_shfl_xor<4>(ss); ss += kpb_shfl_xor<2>(ss); ss += kpb_shfl_xor<1>(ss);
+                const float nrm = fmaxf(sqrtf(ss), a.xb);
+                if (row < nrows) {
+                    o[(size_t)row * a.ostride] = __fdiv_rn(v0, nrm);
+                    o[(size_t)row * a.ostride + 32] = __fdiv_rn(v1, nrm);
+                }
             }
         return;
     }

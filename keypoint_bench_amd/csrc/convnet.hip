@@ -651,7 +651,7 @@ struct Layer {      // one convolution of a network plan
 };
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0)
+                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f)
 {
     const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
@@ -675,6 +675,11 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && l2_eps > 0.0f) {
+            if (L.cout != 64 || L.ntb != 2) return kpb_fail(ctx, KPB_E_INVALID, "launch_mfma: the fused L2 norm needs a 64-channel layer");
+            a.xb = l2_eps;
+            KPB_LAUNCH(ctx, name, (gemm_h<2, 1, GE_L2NORM>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
+        }
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && unfold_w) KPB_LAUNCH(ctx, name, (gemm_h<2, 1, GE_PLAIN, true>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2, 1>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
@@ -931,8 +936,12 @@ struct XFeatNet : kpb_net {
                    H8, W8, H16, W16, H32, W32);
         if ((rc = conv("block_fusion.0", u8[3], u8[4], batch, H8, W8))) return rc;
         if ((rc = conv("block_fusion.1", u8[4], u8[5], batch, H8, W8))) return rc;
+        if (conv_mfma_use_h16() && L.at("block_fusion.2").mfma) {     // F.normalize in the product's epilogue (a wave holds whole 64-channel rows)
+            if ((rc = launch_mfma(ctx, "xf_block_fusion.2", this, L.at("block_fusion.2"), u8[5], desc_out, batch, H8, W8, false, false, relu_of.at("block_fusion.2"), nullptr, 0, 1e-12f))) return rc;
+        } else {
         if ((rc = conv("block_fusion.2", u8[5], desc_out, batch, H8, W8))) return rc;
         KPB_LAUNCH(ctx, "xf_l2norm", l2norm_nhwc, dim3((unsigned)((B * H8 * W8 + 4 * PXW - 1) / (4 * PXW))), dim3(256), 0, st, desc_out, 64, B * H8 * W8, 1e-12f);   // F.normalize
+        }
         // keypoint head on the 8x8-unfolded normalised image (XFeat.py:138-139)
         if (conv_mfma_use_h16() && L.at("keypoint_head.0").mfma && W % 8 == 0) {
             // the first layer reads the 8 x 8 cells straight from the normalised image (ConvM::unfold_w): as a kernel of its own the

@@ -1,0 +1,79 @@
+"""Run-to-run determinism (r04).  Every kernel of this library is a fixed sequence of fp32 / integer operations with no atomics on
+floating point, so the same input must give the same BITS on every run.  It did not: from the commit that made the ALIKE head's a2
+interpolation four weighted taps (775c39f) about 0.5 % of the dense maps differed from one run to the next in 16-pixel groups
+(pixels 16..31 of a 32-pixel tile = the upper 16 lanes of each half-wave) by 1e-5 .. 1e-1 -- inside every parity tolerance, so no
+oracle comparison saw it; one shape test failing once did.  The cause was a wait state missing behind packed-fp32 instructions
+(csrc/conv_mfma.h cm_split2, csrc/alike.hip up8ch_lerp4 have the story; scripts/determinism_probe.py is the tool that found and
+bisected it).  A missing wait state is a matter of instruction scheduling and of what else the SIMD issues in between: it comes and
+goes with unrelated edits and with occupancy, and only repetition shows it.  Hence this file: each network, several runs of the same
+batch, bit for bit; sizes chosen so that thousands of tiles pass through every matrix kernel per run."""
+import numpy as np
+import pytest
+import torch
+
+from keypoint_bench_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(seed, H, W, B):
+    imgs = [synthetic.image_pair(seed + i, H, W)[0] for i in range(min(B, 4))]
+    x = torch.from_numpy(np.stack(imgs)).to(DEV)
+    return x.repeat((B + x.shape[0] - 1) // x.shape[0], 1, 1, 1)[:B].contiguous()
+
+
+def _same_bits(model, x, runs):
+    with torch.no_grad():
+        model(x)                                    # allocations, lazy initialisation
+        ref = [t.clone() for t in model(x) if isinstance(t, torch.Tensor)]
+        for it in range(runs):
+            out = [t for t in model(x) if isinstance(t, torch.Tensor)]
+            for k, (a, b) in enumerate(zip(out, ref)):
+                if not torch.equal(a, b):
+                    d = (a != b)
+                    where = torch.nonzero(d.reshape(d.shape[0], -1).any(dim=1)).flatten().tolist()
+                    raise AssertionError("run %d, output %d: %d elements differ from the first run (images %s), max |d| %.3g"
+                                         % (it, k, int(d.sum()), where[:8], (a - b).abs().max().item()))
+
+
+@pytest.mark.parametrize("shape,batch,runs", [((480, 640), 96, 30), ((800, 1216), 4, 60), ((1216, 1600), 1, 300)])
+@pytest.mark.parametrize("dense", [True, False])
+def test_alike_gives_the_same_bits_every_run(shape, batch, runs, dense):
+    from keypoint_bench_amd.models.ALike import alike_t
+    _same_bits(alike_t(dense_descriptors=dense).eval(), _batch(41, *shape, batch), runs if dense else max(runs // 3, 4))
+
+
+def test_superpoint_gives_the_same_bits_every_run():
+    from keypoint_bench_amd.models.SuperPoint import superpoint_random
+    _same_bits(superpoint_random(7).eval(), _batch(42, 480, 640, 8), 20)
+
+
+def test_xfeat_gives_the_same_bits_every_run():
+    from keypoint_bench_amd.models.XFeat import xfeat_random
+    _same_bits(xfeat_random(5).eval(), _batch(43, 480, 640, 64), 30)
+
+
+def test_disk_gives_the_same_bits_every_run():
+    from keypoint_bench_amd.models.disk import disk_random
+    _same_bits(disk_random(3).eval(), _batch(44, 480, 640, 2), 10)
+
+
+def test_lightglue_gives_the_same_matches_every_run():
+    import sys
+    from conftest import GOLDEN
+    from keypoint_bench_amd import weights
+    from keypoint_bench_amd.models.lightglue import LightGlue
+    sys.path.insert(0, GOLDEN)
+    import make_golden_lightglue as mk
+    dim, scale, seed = 256, 8, 23
+    dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale, n0=1000, n1=1000)
+    m = LightGlue(features=None, desc_scale=scale)
+    m.load_state_dict(weights.random_lightglue_state_dict(seed, dim, "plain"))
+    T = lambda a: torch.from_numpy(a).to(DEV)
+    args = (T(p0), T(p1), T(dm0), T(dm1), {"w": 320, "h": 240})
+    m.match_indices(*args)
+    pairs0, scores0, stop0 = m.match_indices(*args)
+    for it in range(20):
+        pairs, scores, stop = m.match_indices(*args)
+        assert stop == stop0 and torch.equal(pairs, pairs0) and torch.equal(scores, scores0), "run %d differs from the first" % it
