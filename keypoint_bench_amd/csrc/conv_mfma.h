@@ -605,6 +605,10 @@ __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
                 if constexpr (UNFOLD) {       // channels 32 ch + 4 q .. + 3 of cell (Y, X) = four adjacent pixels of cell row 4 ch + q / 2
                     const int r = r0 + row, Y = r / a.W, X = r - Y * a.W;
                     buf[k] = *reinterpret_cast<const float4*>(a.in + ((size_t)b * 8 * a.H + 8 * Y + 4 * ch + (q >> 1)) * a.unfold_w + 8 * X + 4 * (q & 1));
+                    if (a.aux0) {       // (mean, 1 / std) of image b: the image is normalised as it is read (XFeat.py:122-123)
+                        const float2 nm = reinterpret_cast<const float2*>(a.aux0)[b];
+                        buf[k].x = (buf[k].x - nm.x) * nm.y; buf[k].y = (buf[k].y - nm.x) * nm.y; buf[k].z = (buf[k].z - nm.x) * nm.y; buf[k].w = (buf[k].w - nm.x) * nm.y;
+                    }
                 } else
                     buf[k] = *reinterpret_cast<const float4*>(in + (size_t)(r0 + row) * a.istride + ch * CC + 4 * q);
             }

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_valu_t(ConvV a)
 constexpr int XB_TH = 8, XB_TW = 32, XB_AH = 2 * XB_TH + 1, XB_AW = 2 * XB_TW + 1, XB_GH = XB_AH + 2, XB_GW = XB_AW + 2;
 __global__ __launch_bounds__(256) void xfeat_block1_01(const float* __restrict__ gray, float* __restrict__ out, const float* __restrict__ w0,
                                                        const float* __restrict__ b0, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                       int H, int W)
+                                                       int H, int W, const float2* __restrict__ mr /* null: gray is normalised already */)
 {
     __shared__ float g[XB_GH * XB_GW];
     __shared__ __attribute__((aligned(16))) float4 a1[XB_AH * XB_AW];
@@ -155,9 +155,15 @@ __global__ __launch_bounds__(256) void xfeat_block1_01(const float* __restrict__
     const int ay0 = 2 * oy0 - 1, ax0 = 2 * ox0 - 1;                      // first block1.0 position block1.1 taps
     const int gy0 = ay0 - 1, gx0 = ax0 - 1;                              // first grey pixel block1.0 taps
     const float* gi = gray + (size_t)b * H * W;
+    const float2 nm = mr ? mr[b] : make_float2(0.0f, 1.0f);
     for (int i = tid; i < XB_GH * XB_GW; i += 256) {
         const int y = i / XB_GW, x = i - y * XB_GW, gy = gy0 + y, gx = gx0 + x;
-        g[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? gi[(size_t)gy * W + gx] : 0.0f;
+        float v = 0.0f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            v = gi[(size_t)gy * W + gx];
+            if (mr) v = (v - nm.x) * nm.y;          // InstanceNorm2d(1) applied on the way in; the zero padding is of the NORMALISED image
+        }
+        g[i] = v;
     }
     __syncthreads();
     for (int i = tid; i < XB_AH * XB_AW; i += 256) {
@@ -225,6 +231,7 @@ struct XfB1Args {
     const uint4* wB;        // [2 m-tiles][3 kb][hi / lo][64 lanes]: conv B fragments, scaled by 1 / inv_wsB
     const float* bA; const float* bB;       // biases [8], [32] (zero padded)
     const float* gray; const float* skw; const float* skb;      // the skip connection: avg_pool4(gray) * skw[c] + skb[c], c < 24, added after the ReLU
+    const float2* mr;       // per image (mean, 1 / std) of the grey image, applied to the patch as it is read; null: gray is normalised already
     int H2, W2;
     float inv_wsA, inv_wsB, l1A, bmaxA;
 };
@@ -344,6 +351,7 @@ __global__ __launch_bounds__(256, 4) void xfeat_block1_23(XfB1Args a)
     const int bbase = (g & 1) * XQ_PLM + pr + (g >> 1);
     const int ox = ox0 + pr, Wg = 2 * a.W2;
     const float* gimg = a.gray + (size_t)b * (2 * a.H2) * Wg;
+    const float2 nm = a.mr ? a.mr[b] : make_float2(0.0f, 1.0f);
 #pragma unroll
     for (int rr = 0; rr < XQ_TH / 4; ++rr) {
         const int ly = (XQ_TH / 4) * wv + rr, oy = oy0 + ly;
@@ -370,7 +378,10 @@ __global__ __launch_bounds__(256, 4) void xfeat_block1_23(XfB1Args a)
         }
         float sacc = 0.0f;
 #pragma unroll
-        for (int dy = 0; dy < 4; ++dy) { sacc += gp[dy].x; sacc += gp[dy].y; sacc += gp[dy].z; sacc += gp[dy].w; }       // avg_pool2d's order (conv_valu_t)
+        for (int dy = 0; dy < 4; ++dy) {                    // avg_pool2d's order (conv_valu_t), over the normalised pixels
+            if (a.mr) { gp[dy].x = (gp[dy].x - nm.x) * nm.y; gp[dy].y = (gp[dy].y - nm.x) * nm.y; gp[dy].z = (gp[dy].z - nm.x) * nm.y; gp[dy].w = (gp[dy].w - nm.x) * nm.y; }
+            sacc += gp[dy].x; sacc += gp[dy].y; sacc += gp[dy].z; sacc += gp[dy].w;
+        }
         const float avg = __shfl(sacc * (1.0f / 16.0f), pr, 64);
         if (live) {
             float* o = a.out + (((size_t)b * H4 + oy) * W4 + ox) * 32 + 4 * g;
@@ -589,6 +600,18 @@ __global__ void instnorm_apply(float* gray, const double* stats, size_t P)      
     *g = v;
 }
 
+// The same two numbers per image, for the kernels that normalise the grey image as they read it (r04: xfeat_block1_01, the skip term of
+// xfeat_block1_23, the keypoint head's unfolded input -- instnorm_apply's pass over the image, 0.19 ms per 512 images, is gone for
+// the split-f16 form; (x - m) * r is evaluated with the same two operations, so the values are bit for bit instnorm_apply's)
+__global__ void instnorm_params(const double* stats, size_t P, float2* mr, int B)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const double mean = stats[2 * b] / (double)P;
+    const double var = fmax(stats[2 * b + 1] / (double)P - mean * mean, 0.0);
+    mr[b] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
+}
+
 // XFeat.py:133-135: x3 + interpolate(x4, size(x3), bilinear) + interpolate(x5, ...) (align_corners=False), 64 channels
 __device__ __forceinline__ float4 bilerp4(const float* m, int Hs, int Ws, int Hd, int Wd, int y, int x, int c4)
 {
@@ -651,14 +674,14 @@ struct Layer {      // one convolution of a network plan
 };
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f)
+                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f, const float2* unfold_mr = nullptr)
 {
     const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
     ConvM a;
     a.in = in; a.out = out; a.wp = net->wp((L.name + ".w").c_str()); a.bias = net->wp((L.name + ".b").c_str()); a.xf = xf; a.res = nullptr;
     a.active = nullptr; a.istride = L.cin; a.ostride = L.cout; a.ooff = 0;
-    a.Hi = Hi; a.Wi = Wi; a.unfold_w = unfold_w;
+    a.Hi = Hi; a.Wi = Wi; a.unfold_w = unfold_w; a.aux0 = reinterpret_cast<const float*>(unfold_mr);
     if (unfold_w && !(conv_mfma_use_h16() && L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !xf && L.cin == 64))
         return kpb_fail(ctx, KPB_E_INVALID, "launch_mfma: the unfolded input exists for 64-channel 1x1 layers of the split-f16 form only");
     a.H = (Hc + 2 * PAD - L.ks) / S + 1; a.W = (Wc + 2 * PAD - L.ks) / S + 1;
@@ -876,9 +899,10 @@ struct XFeatNet : kpb_net {
         const size_t n_gray = P, n_a = P * 4, n_b = P / 4 * 8, n_c = P / 4 * 8, n_x1 = P / 16 * 32, n_t = P / 16 * 32, n_x2 = P / 16 * 32,
                      n_8 = P / 64 * 64, n_16 = P / 256 * 64, n_32a = P / 1024 * 128, n_semi = P / 64 * 65;
         const size_t total = B * (n_gray + n_a + n_b + n_c + n_x1 + n_t + n_x2 + 6 * n_8 + 3 * n_16 + 3 * n_32a + n_semi) + 64;
-        if (int rc = kpb_reserve(ctx, act, total * sizeof(float) + 16 * B)) return rc;
+        if (int rc = kpb_reserve(ctx, act, total * sizeof(float) + 16 * B + 8 * B)) return rc;
         float* p = static_cast<float*>(act.p);
         double* stats = reinterpret_cast<double*>(p); p += 2 * ((2 * B + 1) / 2 * 2);     // 2 doubles per image
+        float* mrbuf = p; p += 2 * B;                                                      // (mean, 1 / std) per image
         float* gray = p; p += B * n_gray;
         float* a1 = p; p += B * n_a; float* b1 = p; p += B * n_b; float* c1 = p; p += B * n_c;
         float* x1 = p; p += B * n_x1; float* t2 = p; p += B * n_t; float* x2 = p; p += B * n_x2;
@@ -890,7 +914,14 @@ struct XFeatNet : kpb_net {
         hipStream_t st = ctx->stream;
         KPB_HIP(ctx, hipMemsetAsync(stats, 0, 2 * B * sizeof(double), st));
         KPB_LAUNCH(ctx, "xf_gray_stats", gray_mean_stats, dim3(64, batch), dim3(256), 0, st, img, gray, stats, P);
-        KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P / 4 + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
+        // the split-f16 form normalises the grey image where it is read (three consumers) from per-image (mean, 1 / std)
+        const bool fold_norm = conv_mfma_use_h16() && L.at("keypoint_head.0").mfma && W % 8 == 0;
+        float2* mr = nullptr;
+        if (fold_norm) {
+            mr = reinterpret_cast<float2*>(mrbuf);
+            KPB_LAUNCH(ctx, "xf_instnorm_params", instnorm_params, dim3(cdiv(batch, 256)), dim3(256), 0, st, stats, P, mr, batch);
+        } else
+            KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P / 4 + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
         int rc;
         // block1 (XFeat.py:30-35) and the skip connection (27-28, 127)
         {   // block1.0 + block1.1 fused: the 4-channel full-resolution map never reaches HBM (r04)
@@ -899,12 +930,12 @@ struct XFeatNet : kpb_net {
                 !relu_of.at("block1.0") || !relu_of.at("block1.1"))
                 return kpb_fail(ctx, KPB_E_INVALID, "XFeat block1.0 / block1.1: unexpected layer plan");
             KPB_LAUNCH(ctx, "xf_block1.01", xfeat_block1_01, dim3(cdiv(W2, XB_TW), cdiv(H2, XB_TH), batch), dim3(256), 0, st, gray, b1,
-                       wp("block1.0.w"), wp("block1.0.b"), wp("block1.1.w"), wp("block1.1.b"), H, W);
+                       wp("block1.0.w"), wp("block1.0.b"), wp("block1.1.w"), wp("block1.1.b"), H, W, mr);
             (void)a1;
         }
         if (conv_mfma_use_h16()) {      // block1.2 + block1.3 + skip on the matrix cores, the map between them in LDS (xfeat_block1_23)
             XfB1Args xa{b1, x1, reinterpret_cast<const uint4*>(wp("block1.23.wA")), reinterpret_cast<const uint4*>(wp("block1.23.wB")),
-                        wp("block1.23.bA"), wp("block1.23.bB"), gray, wp("skip1.w"), wp("skip1.b"), H2, W2,
+                        wp("block1.23.bA"), wp("block1.23.bB"), gray, wp("skip1.w"), wp("skip1.b"), mr, H2, W2,
                         wscale.at("block1.23.inv_wsA"), wscale.at("block1.23.inv_wsB"), wscale.at("block1.23.l1A"), wscale.at("block1.23.bmaxA")};
             KPB_LAUNCH(ctx, "xf_block1.23", xfeat_block1_23, dim3(cdiv(W4, XQ_TW), cdiv(H4, XQ_TH), batch), dim3(256), 0, st, xa);
             (void)c1;
@@ -946,7 +977,7 @@ struct XFeatNet : kpb_net {
         if (conv_mfma_use_h16() && L.at("keypoint_head.0").mfma && W % 8 == 0) {
             // the first layer reads the 8 x 8 cells straight from the normalised image (ConvM::unfold_w): as a kernel of its own the
             // unfolding wrote and re-read 0.63 GB per 512 images (xf_unfold8, 0.24 ms)
-            if ((rc = launch_mfma(ctx, "xf_keypoint_head.0", this, L.at("keypoint_head.0"), gray, u8[1], batch, H8, W8, false, false, relu_of.at("keypoint_head.0"), nullptr, W))) return rc;
+            if ((rc = launch_mfma(ctx, "xf_keypoint_head.0", this, L.at("keypoint_head.0"), gray, u8[1], batch, H8, W8, false, false, relu_of.at("keypoint_head.0"), nullptr, W, 0.0f, mr))) return rc;
         } else {
             KPB_LAUNCH(ctx, "xf_unfold8", unfold8, dim3(cdiv(H8 * W8 * 16, 256), batch), dim3(256), 0, st, gray, u8[0], H, W);
             if ((rc = conv("keypoint_head.0", u8[0], u8[1], batch, H8, W8))) return rc;
