@@ -77,3 +77,42 @@ def test_lightglue_gives_the_same_matches_every_run():
     for it in range(20):
         pairs, scores, stop = m.match_indices(*args)
         assert stop == stop0 and torch.equal(pairs, pairs0) and torch.equal(scores, scores0), "run %d differs from the first" % it
+
+
+def test_detection_and_matching_give_the_same_rows_every_run():
+    """The integer half of the path builds its lists with atomics (NMS maxima, undecided pixels, candidates): the ORDER in which
+    lanes arrive differs from run to run, the rows handed back must not."""
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.utils.extracter import detection
+    from keypoint_bench_amd.utils.matcher import brute_force_matcher
+    EP = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
+    BF = dict(metric="euclidean", max_distance=5, cross_check=True)
+    v0, v1 = synthetic.image_pair(3)
+    net = alike_t(dense_descriptors=True).eval()
+    with torch.no_grad():
+        s0, d0 = net(torch.from_numpy(v0)[None].to(DEV))
+        s1, d1 = net(torch.from_numpy(v1)[None].to(DEV))
+    k0, k1 = detection(s0, EP), detection(s1, EP)
+    m0, m1 = brute_force_matcher(k0, k1, d0, d1, BF)
+    for it in range(40):
+        a0, a1 = detection(s0, EP), detection(s1, EP)
+        assert torch.equal(a0, k0) and torch.equal(a1, k1), "detection, run %d" % it
+        b0, b1 = brute_force_matcher(a0, a1, d0, d1, BF)
+        assert torch.equal(b0, m0) and torch.equal(b1, m1), "matcher, run %d" % it
+
+
+def test_batched_detection_gives_the_same_rows_every_run():
+    from keypoint_bench_amd.models.ALike import alike_t
+    from keypoint_bench_amd.utils.extracter import detection_batch
+    EP = dict(nms_dist=6, threshold=0.0, border_dist=8, top_k=1000, min_score=0.0)
+    net = alike_t(dense_descriptors=False).eval()
+    with torch.no_grad():
+        s, _ = net(_batch(11, 480, 640, 64))
+    def rows():
+        kps, idx, n = detection_batch(s, EP)
+        valid = torch.arange(kps.shape[1], device=DEV)[None, :] < n[:, None]       # rows past n are not written
+        return n.clone(), torch.where(valid[..., None], kps, torch.zeros_like(kps)), torch.where(valid, idx, torch.zeros_like(idx))
+    ref = rows()
+    for it in range(10):
+        for a, b in zip(rows(), ref):
+            assert torch.equal(a, b), "run %d" % it
