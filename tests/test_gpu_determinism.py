@@ -116,3 +116,26 @@ def test_batched_detection_gives_the_same_rows_every_run():
     for it in range(10):
         for a, b in zip(rows(), ref):
             assert torch.equal(a, b), "run %d" % it
+
+
+@pytest.mark.parametrize("task", ["repeatability", "MHA", "FundamentalMatrix"])
+def test_task_rows_through_the_runner_are_the_same_every_run(task):
+    """The whole chain a task row comes out of -- nets, detection, covisibility warp, matcher, the seeded RANSAC estimators on the
+    device -- five runs of the same eight pairs."""
+    from keypoint_bench_amd import runner
+    EP = dict(nms_dist=4, threshold=0.0, border_dist=8, top_k=300, min_score=0.0)
+    BF = dict(metric="euclidean", max_distance=5, cross_check=True)
+    H01 = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
+    prm = {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64), "extractor_params": EP,
+           "matcher_params": {"type": "brute_force", "brute_force_params": BF}, "repeatability_params": {"th": 3},
+           "FundamentalMatrix_params": {"th": 3.0}, "MHA_params": {"th": [3, 5, 7]}}
+    ds = []
+    for i in range(8):
+        v0, v1 = synthetic.image_pair(200 + i, 192, 256)
+        ds.append({"image0": v0, "image1": v1, "dataset": "HPatches",
+                   "warp01_params": dict(mode="homo", homography_matrix=H01, width=np.int64(256), height=np.int64(192), resize=np.int64(256)),
+                   "warp10_params": dict(mode="homo", homography_matrix=np.linalg.inv(H01).astype(np.float32), width=256, height=192)})
+    _, ref = runner.PairRunner(prm, device=DEV, batch=4).run(ds)
+    for it in range(5):
+        _, rows = runner.PairRunner(prm, device=DEV, batch=4).run(ds)
+        assert rows.tobytes() == ref.tobytes(), "run %d" % it
