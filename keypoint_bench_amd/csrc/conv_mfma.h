@@ -282,6 +282,10 @@ __device__ __forceinline__ float cm_wave_max(float v)
 // weight round trip is not what keeps the matrix pipe at 46 %.  Nor is the slab staging: a persistent form that fetches the next
 // slab (or the next tile's first slab) into registers before the taps of the current one ran 2 % faster on conv1b at two
 // waves per SIMD and 20 % slower on DISK's up_3 (the 44 registers of the slab in flight cost the third wave).)
+// (Tried, r04: the next slab's input requested into registers right after this slab's split, its round trip flying under the nine taps,
+// with the fragments taken one 16-deep k-block at a time so that the 44 staging registers fit beside the accumulators at three waves per
+// SIMD (no spill in the loops): every SuperPoint layer 10-14 % SLOWER (conv1b 2.10 -> 2.38 ms), DISK's 5 x 5 layers 0-8 % slower -- the
+// half-size fragment sets cost the tap loop more than the hidden load gives back.)
 // (Tried, r04: the workgroups sharing a CU start together and take the same time per phase, so their load / split / store phases
 // might coincide and idle the matrix pipe together; delaying the first generation's slot k by k x 8-48 k cycles changed no layer of
 // SuperPoint by more than 1 % -- the phases are not in lockstep.)
