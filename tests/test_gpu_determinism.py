@@ -37,26 +37,29 @@ def _same_bits(model, x, runs):
                                          % (it, k, int(d.sum()), where[:8], (a - b).abs().max().item()))
 
 
-@pytest.mark.parametrize("shape,batch,runs", [((480, 640), 96, 30), ((800, 1216), 4, 60), ((1216, 1600), 1, 300)])
+@pytest.mark.parametrize("shape,batch,runs", [((480, 640), 96, 30), ((480, 640), 1, 300), ((480, 640), 3, 100), ((800, 1216), 4, 60), ((1216, 1600), 1, 300)])
 @pytest.mark.parametrize("dense", [True, False])
 def test_alike_gives_the_same_bits_every_run(shape, batch, runs, dense):
     from keypoint_bench_amd.models.ALike import alike_t
     _same_bits(alike_t(dense_descriptors=dense).eval(), _batch(41, *shape, batch), runs if dense else max(runs // 3, 4))
 
 
-def test_superpoint_gives_the_same_bits_every_run():
+@pytest.mark.parametrize("batch,runs", [(8, 20), (1, 60)])
+def test_superpoint_gives_the_same_bits_every_run(batch, runs):
     from keypoint_bench_amd.models.SuperPoint import superpoint_random
-    _same_bits(superpoint_random(7).eval(), _batch(42, 480, 640, 8), 20)
+    _same_bits(superpoint_random(7).eval(), _batch(42, 480, 640, batch), runs)
 
 
-def test_xfeat_gives_the_same_bits_every_run():
+@pytest.mark.parametrize("batch,runs", [(64, 30), (1, 200)])
+def test_xfeat_gives_the_same_bits_every_run(batch, runs):
     from keypoint_bench_amd.models.XFeat import xfeat_random
-    _same_bits(xfeat_random(5).eval(), _batch(43, 480, 640, 64), 30)
+    _same_bits(xfeat_random(5).eval(), _batch(43, 480, 640, batch), runs)
 
 
-def test_disk_gives_the_same_bits_every_run():
+@pytest.mark.parametrize("batch,runs", [(2, 10), (1, 20)])
+def test_disk_gives_the_same_bits_every_run(batch, runs):
     from keypoint_bench_amd.models.disk import disk_random
-    _same_bits(disk_random(3).eval(), _batch(44, 480, 640, 2), 10)
+    _same_bits(disk_random(3).eval(), _batch(44, 480, 640, batch), runs)
 
 
 def test_lightglue_gives_the_same_matches_every_run():
