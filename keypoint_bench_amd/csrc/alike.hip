@@ -985,10 +985,11 @@ struct Up8Taps { float4 t[8]; float ly, lx; };
 // instructions fewer per pixel.  hipcc compiled that form to chains of v_pk_fma_f32, and from that commit on ~0.5 % of the dense maps
 // differed RUN TO RUN in 16-pixel groups -- pixels 16..31 of a 32-pixel tile, i.e. the upper 16 lanes of each half-wave, by 1e-5 .. 1e-1:
 // inside every parity tolerance, caught by one shape test failing once.  scripts/determinism_probe.py compares run against run bit
-// for bit and bisected it to this function; knocking out the LDS-DMA rings, the waits, the deferred stores or the MFMA register
-// overlap moved the rate up and down but never to zero, this form is at zero over 400 runs per shape.  The mechanism is a wait state
-// missing behind a packed-fp32 result somewhere in that instruction stream (conv_mfma.h, cm_split2, has what is known);
-// tests/test_gpu_determinism.py now holds every network to run-to-run equality.)
+// for bit; a debug build showed these eight a2 features to be what differed, a bisection over commits showed this function to be
+// where it began (r03's head and every r04 head before 775c39f: 0 of 400 runs).  Knocking out the LDS-DMA rings, their waits, the
+// deferred stores or the MFMA destination overlap moved the rate up and down but never to zero; with cm_split2's inline asm gone
+// (conv_mfma.h) AND this form back, every shape is at 0 of 400.  The exact instruction pair is not pinned (see there);
+// tests/test_gpu_determinism.py holds every network to run-to-run equality.)
 __device__ __forceinline__ void up8ch_lerp4(const Up8Taps& u, float* f, float sc)
 {
     const float lx = u.lx, hx = 1.0f - lx, hy = (1.0f - u.ly) * sc, ly = u.ly * sc;
