@@ -1,12 +1,12 @@
-"""Run-to-run determinism (r04).  Every kernel of this library is a fixed sequence of fp32 / integer operations with no atomics on
-floating point, so the same input must give the same BITS on every run.  It did not: from the commit that made the ALIKE head's a2
+"""Run-to-run determinism.  Every kernel of this library is a fixed sequence of fp32 / integer operations with no atomics on floating
+point, so the same input must give the same BITS on every run.  In r04 it did not: from the commit that made the ALIKE head's a2
 interpolation four weighted taps (775c39f) about 0.5 % of the dense maps differed from one run to the next in 16-pixel groups
-(pixels 16..31 of a 32-pixel tile = the upper 16 lanes of each half-wave) by 1e-5 .. 1e-1 -- inside every parity tolerance, so no
-oracle comparison saw it; one shape test failing once did.  An inline-asm v_fma_mix_f32 and a v_pk_fma_f32 code shape were the two
-triggers (csrc/conv_mfma.h cm_split2, csrc/alike.hip up8ch_lerp4 and DESIGN.md section 3 have the story; scripts/determinism_probe.py
-is the tool that found and bisected it).  Faults of this kind are a matter of instruction scheduling and of what else the SIMD issues
-in between: they come and go with unrelated edits and with occupancy, and only repetition shows them.  Hence this file: each network, several runs of the same
-batch, bit for bit; sizes chosen so that thousands of tiles pass through every matrix kernel per run."""
+(pixels 16..31 of a 32-pixel tile) by 1e-5 .. 1e-1 -- inside every parity tolerance, so no oracle comparison saw it; one shape test
+failing once did.  r05 named the cause: gfx950 returns a wrong LOW result in lanes 48..63 for v_pk_{mul,add,fma}_f32 with op_sel[0] = 0,
+op_sel[1] = 1 while an f16 MFMA executes on the SIMD (scripts/ubench/pk_opsel.hip; the build rewrites the encoding,
+keypoint_bench_amd/isa_fixup.py, and scripts/isa_lint.py checks the library).  Faults of this kind depend on what else the SIMD is
+doing: they come and go with unrelated edits and with occupancy, and only repetition shows them.  Hence this file: each network, several
+runs of the same batch, bit for bit; sizes chosen so that thousands of tiles pass through every matrix kernel per run."""
 import numpy as np
 import pytest
 import torch
