@@ -117,6 +117,93 @@ def fp32_companion(args):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+
+# ---------------------------------------------------------------------------------------- what ran, and the rank logic
+def build_identity():
+    """Which library produced this line: the .so's content hash and mtime, the commit it was built from (recorded by build.py; the GPU
+    box has no .git) and, where git is at hand, the tree's own HEAD."""
+    import hashlib
+    import subprocess
+    so = os.path.join(ROOT, "keypoint_bench_amd", "libkpb.so")
+    out = {"lib_sha256": None, "lib_mtime": None, "built_from": None, "tree_head": None}
+    try:
+        out["lib_sha256"] = hashlib.sha256(open(so, "rb").read()).hexdigest()[:12]
+        out["lib_mtime"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(so)))
+    except OSError:
+        pass
+    try:
+        out["built_from"] = json.load(open(os.path.join(ROOT, "keypoint_bench_amd", "_obj", "build_info.json")))
+    except (OSError, ValueError):
+        pass
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
+        out["tree_head"] = r.stdout.strip() or None
+    except Exception:
+        pass
+    return out
+
+
+def timed_steps(run, steps, warmup, dev, use_dist, dist=None):
+    """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by synchronize + barrier on both sides,
+    MAX over ranks.  Returns (seconds, seconds of the last half or None): the second figure comes from two events on the launch stream
+    (no extra synchronisation inside the region) and is what the chip SUSTAINS -- a 20-step run right after an idle period reads ~3 %
+    faster than the state an uninterrupted stream settles into.  `run()` performs one step; on a CPU device (the
+    gloo test) the events are perf_counter stamps."""
+    import torch
+    cuda = dev.type == "cuda"
+
+    def barrier():
+        if cuda:
+            torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+            if cuda:
+                torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        run()
+    barrier()
+    half = steps // 2 if steps >= 100 else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if (cuda and half) else None
+    t_half = None
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if half is not None and i == half:
+            if ev:
+                ev[0].record(torch.cuda.current_stream(dev))
+            else:
+                t_half = time.perf_counter()
+        run()
+    if ev:
+        ev[1].record(torch.cuda.current_stream(dev))
+    t_own = time.perf_counter()         # this rank's own end (the CPU stand-in of the second event)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tail = None
+    if half is not None:
+        tail = ev[0].elapsed_time(ev[1]) * 1e-3 if ev else (t_own - t_half)
+    if use_dist:
+        t = torch.tensor([elapsed, tail if tail is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, tail = float(t[0].item()), (float(t[1].item()) if tail is not None else None)
+    return elapsed, tail
+
+
+def exchange_rows(rows, world, use_dist, dist=None):
+    """fixed-width per-pair rows, ONE all-gather at the end of the run (rank r's rows land at [r * B, (r + 1) * B))."""
+    import torch
+    if not use_dist:
+        return rows
+    allrows = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    dist.all_gather_into_tensor(allrows, rows.contiguous())
+    return allrows
+
+
+def generator_threads(world):
+    """Host threads one rank may use to synthesise its pairs: the visible cores shared by the ranks of the node (8 ranks x 16 threads on
+    one node's cores would oversubscribe them)."""
+    return max(1, min(len(os.sched_getaffinity(0)) // max(world, 1), 16))
+
 # whole-path algorithmic work per pair (SURVEY.md 8d): conv / GEMM FLOPs (2 x MAC) and compulsory HBM bytes
 NET_GFLOP_PER_IMAGE = {"alike": 3.8885, "alike_sparse": 1.3720 + 0.0082, "superpoint": 52.10, "xfeat": 2.54, "disk": 197.8}
 DESC_CHANNELS = {"alike": 64, "superpoint": 256, "xfeat": 64, "disk": 128}
@@ -181,6 +268,11 @@ def other_net_costs(B2):
     def conv(name, px, cin, cout, k):
         c[name] = (2 * px * k * k * cin * cout * B2, px * (cin + cout) * 4 * B2)
     conv("xf_block1.3", P // 16, 8, 24, 3)
+    # the fused block-1 kernels (r04): block1.0 (1 -> 4 at full resolution) + block1.1 (4 -> 8, stride 2) read the grey image and write the
+    # 8-channel half-resolution map; block1.2 (8 -> 8) + block1.3 (8 -> 24, stride 2) + the 4 x 4-averaged skip term read that map and the
+    # grey image and write the 24-channel quarter-resolution map (XFeat.py:44-59, 124-126)
+    c["xf_block1.01"] = (2 * (P * 9 * 1 * 4 + (P // 4) * 9 * 4 * 8) * B2, (P * 4 + (P // 4) * 32) * B2)
+    c["xf_block1.23"] = (2 * ((P // 4) * 9 * 8 * 8 + (P // 16) * 9 * 8 * 24 + (P // 16) * 24) * B2, ((P // 4) * 32 + P * 4 + (P // 16) * 96) * B2)
     conv("xf_block2.0", P // 16, 24, 24, 3); conv("xf_block2.1", P // 16, 24, 24, 3)
     conv("xf_block3.1", P // 64, 64, 64, 3); conv("xf_block_fusion.0", P // 64, 64, 64, 3); conv("xf_block_fusion.1", P // 64, 64, 64, 3)
     conv("disk_up3", P, 80, 129, 5); conv("disk_up2", P // 4, 96, 64, 5); conv("disk_up1", P // 16, 128, 64, 5)
@@ -330,57 +422,26 @@ def main():
     # synthetic pairs, different per rank, resident in HBM
     nd = min(args.distinct or B, B)
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max(1, min(len(os.sched_getaffinity(0)), 16))) as ex:     # numpy releases the GIL: ~0.1 s per pair per thread
+    with ThreadPoolExecutor(generator_threads(world)) as ex:     # numpy releases the GIL: ~0.1 s per pair per thread; cores // ranks
         v0s, v1s = zip(*ex.map(lambda i: synthetic.image_pair(rank * 1000 + i, H, W), range(nd)))
     sel = [i % nd for i in range(B)]
     images = torch.from_numpy(np.stack([v0s[i] for i in sel] + [v1s[i] for i in sel])).to(dev).contiguous()
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        pipe.run(images)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.run(images)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, tail = timed_steps(lambda: pipe.run(images), args.steps, args.warmup, dev, use_dist, dist)
     value = world * B * args.steps / elapsed
+    value_sustained = (world * B * (args.steps - args.steps // 2) / tail) if tail else None
 
     # end-of-run exchange: fixed-width per-pair rows [n0, n1, matches], one RCCL all-gather
     rows = torch.stack([pipe.n[:B].float(), pipe.n[B:].float(), pipe.k.float()], dim=1).contiguous()
-    if use_dist:
-        allrows = torch.empty((world * B, 3), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(allrows, rows)
-    else:
-        allrows = rows
-    allrows = allrows.cpu().numpy()
+    allrows = exchange_rows(rows, world, use_dist, dist).cpu().numpy()
+    world_seen = dist.get_world_size() if use_dist else 1
 
     # the same pairs with keypoint-only descriptors (ALNet(dense_descriptors=False): same keypoints and matches, the
     # 78.6 MB/image descriptor map is never written; SURVEY 8d asks to say which was run): timed like the main loop
     variant = None
     if args.model == "alike" and not args.sparse and args.matcher == "brute_force" and not args.no_variants:
         pipe2 = PairPipeline(alike_t(dense_descriptors=False).eval(), EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
-        for _ in range(args.warmup):
-            pipe2.run(images)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            pipe2.run(images)
-        barrier()
-        e2 = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([e2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
+        e2, _ = timed_steps(lambda: pipe2.run(images), args.steps, args.warmup, dev, use_dist, dist)
         same = bool(torch.equal(pipe2.k, pipe.k) and torch.equal(pipe2.pairs[:, :16], pipe.pairs[:, :16]))
         variant = {"descriptors": "keypoint-only", "value": round(world * B * args.steps / e2, 2), "unit": "pairs/s",
                    "ms_per_step": round(1e3 * e2 / args.steps, 3), "same_matches_as_dense": same}
@@ -425,17 +486,20 @@ def main():
         out = {
             "metric": "image-pairs/sec (extract+NMS+%s, 640x480, top_k=1000)" % ("BF-match" if args.matcher == "brute_force" else "LightGlue-match"),
             "value": round(value, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # rate of the LAST HALF of the timed steps (events on the launch stream; steps >= 100): the state an uninterrupted launch stream settles into
+            "value_sustained": round(value_sustained, 2) if value_sustained else None,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_label(args.model, args.matcher),
                        "matcher": args.matcher, "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
-                       "nms_reruns": pipe.reruns,
+                       "nms_reruns": pipe.reruns, "build": build_identity(), "world_size_seen": world_seen,
                        "arithmetic": ("strict fp32 (KPB_FP32_MATRIX=1): fp32 MFMA / fp32 vector ALUs, fp64 match" if strict_fp32() else
                                       "fp32 results; matrix products as split-f16 MFMA triples with fp32 accumulation (2^-22 per product), operands "
                                       "scaled per tile to the f16 window (no fixed range), fp64 match")},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
-                        "pairs_gathered": int(allrows.shape[0])},
+                        "pairs_gathered": int(allrows.shape[0]),
+                        "pairs_gathered_per_rank": [int((allrows[r * B:(r + 1) * B, 0] > 0).sum()) for r in range(world)]},
             "roofline": roof, "roofline_step": step_roofline(args.model, args.matcher, args.sparse, value / world),
             "cpu_baseline": cpu, "variant": variant, "variant_fp32": fp32,
         }

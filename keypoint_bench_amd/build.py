@@ -113,7 +113,26 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    _write_build_info()
     return SO
+
+
+def _write_build_info():
+    """_obj/build_info.json: the commit (and whether the tree was dirty) this library was linked from.  The GPU box receives the tree
+    without .git, so bench.py reads the record from here (config.build in its JSON line)."""
+    import json
+    import time
+    info = {"git": None, "dirty": None, "time": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
+    try:
+        root = os.path.dirname(HERE)
+        info["git"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                                     timeout=10).stdout.strip() or None
+        info["dirty"] = bool(subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], stdout=subprocess.PIPE,
+                                            stderr=subprocess.DEVNULL, text=True, timeout=10).stdout.strip())
+    except Exception:
+        pass
+    with open(os.path.join(OBJ, "build_info.json"), "w") as f:
+        json.dump(info, f)
 
 
 if __name__ == "__main__":

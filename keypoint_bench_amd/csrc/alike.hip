@@ -1264,14 +1264,31 @@ __device__ __forceinline__ void split8(const float* f, h8v& hi, h8v& lo)
 //     a wave's vector-memory operations complete in order, so `s_waitcnt vmcnt(63)` two groups (>= 68 operations) later proves
 //     its requests have landed without draining its stores.  The DMA is issued from inline assembly: the compiler's own LDS-DMA
 //     tracking would put a full wait in front of the first ring read after every request.
-// Ring capacities: a group g computes while rows up to group g + 2 arrive; those span at most floor(11 s) + 2 source rows for a
-// vertical scale s = (Hs - 1) / (H - 1) < 1/2, 1/8, 1/32: 7, 3, 2 -- inside 8, 4, 4, so a request never lands on a row in use.
+// Ring capacities: a group g computes while rows up to group g + HP_LA arrive; output rows 4 g .. 4 (g + HP_LA) + 3 tap source rows
+// floor(4 g s) .. floor((4 (g + HP_LA) + 3) s) + 1, at most floor(11 s) + 3 of them for a vertical scale s = (Hs - 1) / (H - 1) < 1/2,
+// 1/8, 1/32: 8, 4, 3 -- the a2 and E3 rings (8 and 4 rows) are exactly full, with no slack (ADVICE r04 corrected the count: the r04
+// comment said 7, 3, 2).  It is safe because the barrier at the top of a group precedes the next request; hp_ring_rows_ok() below
+// re-derives the bound on the host for the launch's H and refuses a shape / look-ahead that would alias a live row.
 // LDS 50.8 KB with the x1 slots (r03: 52.9), three workgroups per CU as before; whole-pixel stores (see above).
 constexpr int HP_TILES = 2, HP_BW = 32 * HP_TILES;
 constexpr int HP_A2C = 34, HP_A2R = 8, HP_A2S = HP_A2C * 4;                   // a2 ring: rows x 16-byte slots (136 per row)
 constexpr int HP_NT3 = 10, HP_NT4 = 5, HP_ER = 4;                             // raw E3 / E4 rings: rows x band columns x ESTRIDE
 constexpr int HP_E3S = HP_NT3 * (ESTRIDE / 4), HP_E4S = HP_NT4 * (ESTRIDE / 4);     // 16-byte slots per ring row: 170, 85
 constexpr int HP_LA = 2;                                                      // row groups of look-ahead
+
+// rows of a source map (height Hs) live at once while the head walks an image of height H: lo(g) .. hi(g + HP_LA) over all groups g
+inline bool hp_ring_rows_ok(int H, int Hs, int ring_rows)
+{
+    const float s = (float)(Hs - 1) / (float)(H - 1);
+    for (int g = 0; g < H / 4; ++g) {
+        const int lo = (int)(s * (float)(4 * g));
+        const int last = std::min(H / 4 - 1, g + HP_LA);
+        const int r = (int)(s * (float)(4 * last + 3));
+        const int hi = r + (r < Hs - 1 ? 1 : 0);
+        if (hi - lo + 1 > ring_rows) return false;
+    }
+    return true;
+}
 
 // 16 bytes per active lane from global memory to LDS at lds_wave_base + 16 * lane (wave-uniform base), no VGPR in between.
 template <bool NT = false>
@@ -1958,6 +1975,8 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             // row groups per persistent workgroup: 30 (15: +1-2 %, 40 / 60: the same, 120: +1 %; profiles/r04_ab_knobs.txt); H is a
             // multiple of 32 (kpb_net_forward checks), so every group has its four rows
             // -- as long as that leaves about two rounds of workgroups for the chip's 768 slots: a single image walks 2 groups per workgroup
+            if (!hp_ring_rows_ok(H, H / 2, HP_A2R) || !hp_ring_rows_ok(H, H / 8, HP_ER) || !hp_ring_rows_ok(H, H / 32, HP_ER))
+                return kpb_fail(ctx, KPB_E_UNSUPPORTED, "alike head: the LDS rings cannot hold the source rows of %d row groups at height %d", HP_LA + 1, H);
             const int bands_ = cdiv(W / 32, HP_TILES), groups_ = H / 4;
             const int hp = std::max(2, std::min(30, (int)(((long long)bands_ * groups_ * batch) / 1536)));
             KPB_LAUNCH(ctx, "alike_head_dense", alike_head_f16p, dim3(cdiv(W / 32, HP_TILES) * cdiv(H / 4, hp), batch), dim3(256), 0, st, hy,

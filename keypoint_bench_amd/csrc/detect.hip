@@ -1224,6 +1224,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect(kpb_ctx* ctx, c
                           int32_t* out_n_dev, int sync)
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_detect: null context");
+    ctx->det_counts_valid = 0;          // whatever happens below, the mirror no longer belongs to a completed detection
     if (!score_dev || !prm || !out_kps_dev || !out_n_dev || batch <= 0 || H <= 0 || W <= 0)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect: bad argument");
     if (prm->nms_dist < 0 || prm->nms_dist > KPB_MAX_NMS_DIST)
@@ -1276,6 +1277,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
     if (d.prm.nms_dist == 0) {
         KPB_HIP(ctx, kpb_wait_stream(ctx, d.batch < 16));
         ctx->det_pending = 0;
+        ctx->det_counts_valid = 1;
         return KPB_OK;
     }
     const int chunk = 6;
@@ -1303,6 +1305,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_check(kpb_ctx* 
         if (int rc = det_select(ctx, d)) return rc;
     }
     ctx->det_pending = 0;
+    ctx->det_counts_valid = 1;
     return rerun;   // 1: the outputs were rewritten after extra sweeps (the loop's last synchronisation covers them)
 }
 
@@ -1311,7 +1314,8 @@ extern "C" __attribute__((visibility("default"))) int kpb_detect_counts(kpb_ctx*
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_detect_counts: null context");
     if (!out_n_host || batch <= 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: bad argument");
     if (ctx->det_pending) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: the last kpb_detect has not been completed (kpb_detect_check)");
-    if (!ctx->det_state || !ctx->host_det) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: no detection has run");
+    if (!ctx->det_state || !ctx->host_det || !ctx->det_counts_valid)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: no completed detection (the last kpb_detect failed, was rejected, or none has run)");
     const DetState& d = det_state(ctx);
     if (batch != d.batch) return kpb_fail(ctx, KPB_E_INVALID, "kpb_detect_counts: the last kpb_detect had %d images, not %d", d.batch, batch);
     for (int b = 0; b < batch; ++b) out_n_host[b] = ctx->host_det[3 * b + 2];

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "../../include/kpb.h"
+#include <chrono>
 
 // The two 32-lane halves of a wave exchanged on the vector ALU (gfx950's v_permlane32_swap): `lo` = the value of lane & 31 in
 // every lane, `hi` = that of lane | 32.  A commutative op(lo, hi) equals op(v, __shfl_xor(v, 32)) bit for bit in every lane,
@@ -153,6 +154,9 @@ struct kpb_ctx {
     void* det_state = nullptr;
     void (*det_state_free)(void*) = nullptr;
     int det_pending = 0;
+    // the pinned count mirrors hold the counts of a COMPLETED call: set only when kpb_detect(_check) / kpb_match has enqueued (and, for a
+    // detection, confirmed) everything, cleared at entry to the next call and on every error path; kpb_*_counts refuse otherwise
+    int det_counts_valid = 0, match_counts_valid = 0;
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, device) pair: remembered per CONTEXT (= per device),
     // not in a process-wide static that a second device would find already set
     unsigned lds_attr_done = 0;
@@ -193,7 +197,11 @@ inline hipError_t kpb_wait_stream(kpb_ctx* ctx, bool small)
     }
     hipError_t e = hipEventRecord(ctx->wait_ev, ctx->stream);
     if (e != hipSuccess) return e;
-    while ((e = hipEventQuery(ctx->wait_ev)) == hipErrorNotReady) {}
+    // a bounded spin (a single pair is ~0.6 ms of kernels), then the parked wait: a kernel that hangs must not burn a host core for ever
+    // (ADVICE r04).  A context -- its stream, this event, its workspaces -- is used from ONE thread at a time (include/kpb.h).
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((e = hipEventQuery(ctx->wait_ev)) == hipErrorNotReady)
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) return hipStreamSynchronize(ctx->stream);
     return e;
 }
 

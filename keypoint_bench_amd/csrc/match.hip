@@ -579,6 +579,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
                          int32_t* out_pairs_dev, double* out_dist_dev, int32_t* out_k_dev)
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_match: null context");
+    ctx->match_counts_valid = 0;        // set again only when everything of this call has been enqueued
     if (!prm || !out_k_dev || batch <= 0 || C <= 0 || max_n < 0 || max_m < 0)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: bad argument");
     KPB_HIP(ctx, hipSetDevice(ctx->device));
@@ -594,6 +595,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
         KPB_HIP(ctx, hipMemsetAsync(out_k_dev, 0, (size_t)batch * sizeof(int), ctx->stream));
         KPB_HIP(ctx, hipStreamSynchronize(ctx->stream));        // (a kernel of an earlier call may still be writing the mirror)
         for (int b = 0; b < batch; ++b) ctx->host_match[b] = 0;
+        ctx->match_counts_valid = 1;
         return KPB_OK;
     }
     if (!d0_dev || !d1_dev || !out_pairs_dev) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match: null buffer");
@@ -656,6 +658,7 @@ extern "C" __attribute__((visibility("default"))) int kpb_match(kpb_ctx* ctx, co
               max_n, max_m, tiles_i, tiles_j, prm->cross_check, prm->max_distance};
     KPB_LAUNCH(ctx, "match_finalize", match_finalize, dim3(batch), dim3(FIN_THREADS), (size_t)max_m * sizeof(int), ctx->stream, f);
     KPB_HIP(ctx, hipGetLastError());
+    ctx->match_counts_valid = 1;
     return KPB_OK;
 }
 
@@ -663,7 +666,9 @@ extern "C" __attribute__((visibility("default"))) int kpb_match_counts(kpb_ctx* 
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_match_counts: null context");
     if (!out_k_host || batch <= 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_match_counts: bad argument");
-    if (!ctx->host_match || batch != ctx->host_match_n)
+    if (!ctx->host_match || !ctx->match_counts_valid)
+        return kpb_fail(ctx, KPB_E_INVALID, "kpb_match_counts: no completed match (the last kpb_match failed, was rejected, or none has run)");
+    if (batch != ctx->host_match_n)
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_match_counts: the last kpb_match had %d pairs, not %d", ctx->host_match_n, batch);
     KPB_HIP(ctx, hipSetDevice(ctx->device));
     KPB_HIP(ctx, kpb_wait_stream(ctx, batch < 8));

@@ -137,3 +137,66 @@ def viewpoint_case(i):
     """(strength, noise) of pair i in the graded viewpoint family the end-to-end metric tests use: four warp strengths x four noise
     levels, so that repeatability and the homography's corner error spread over easy, typical and failing pairs."""
     return (0.5, 1.0, 1.25, 1.5)[i % 4], (0.02, 0.07, 0.12, 0.16)[(i // 4) % 4]
+
+
+# ---------------------------------------------------------------------------------------------- pose pairs (the AUC task's inputs)
+def _rot(rx, ry, rz):
+    import math
+    cx, sx, cy, sy, cz, sz = math.cos(rx), math.sin(rx), math.cos(ry), math.sin(ry), math.cos(rz), math.sin(rz)
+    Rx = [[1.0, 0.0, 0.0], [0.0, cx, -sx], [0.0, sx, cx]]
+    Ry = [[cy, 0.0, sy], [0.0, 1.0, 0.0], [-sy, 0.0, cy]]
+    Rz = [[cz, -sz, 0.0], [sz, cz, 0.0], [0.0, 0.0, 1.0]]
+    return _mm3(Rz, _mm3(Ry, Rx))
+
+
+def pose_case(i):
+    """(strength, noise) of pose pair i: four motion strengths x four noise levels, as viewpoint_case."""
+    return (0.5, 1.0, 1.5, 2.0)[i % 4], (0.02, 0.05, 0.09, 0.13)[(i // 4) % 4]
+
+
+def pose_pair(i, H=480, W=640, strength=1.0, noise=0.02):
+    """Pair i of the POSE family (tasks/AUC.py's inputs; r05): (view0, view1, K, pose01) -- two views of a scene made of TWO fronto-parallel
+    planes (the left half of the blurred-noise canvas at depth 1, the right half at depth 1.6: points on one plane alone leave the
+    essential matrix two-fold ambiguous), the second camera rotated by up to 2 / 2 / 5 degrees x strength about x / y / z and moved by
+    0.06 x strength in a seeded direction.  K [3,3] float32 is the intrinsic matrix IN THE TASK'S pixel convention -- a keypoint at pixel
+    centre (col, row) reaches the task as ((col + 0.5) (W - 1) / W, (row + 0.5) (H - 1) / H) (extracter.py:149, AUC.py:125-126), so
+    K = S K_pixel with S that map -- and pose01 [4,4] float32 is T_0to1 = [R | t] (datasets/megadepth.py: 'pose01').
+    view1[r1, c1] shows, of the two planes' pre-images under their homographies K (R + t n^T / d) K^-1, the nearer one that falls on its own
+    half of the canvas (the other where only one does)."""
+    import math
+    rng = np.random.default_rng(91000 + i)
+    canvas = rng.random((3, H + 2 * MARGIN, W + 2 * MARGIN), dtype=np.float32)
+    canvas = np.stack([_box_blur(c, 5) for c in canvas])
+    lo, hi = canvas.min(), canvas.max()
+    canvas = (canvas - lo) / (hi - lo)
+    v0 = canvas[:, MARGIN:MARGIN + H, MARGIN:MARGIN + W].astype(np.float32)
+    u = [float(v) for v in rng.uniform(-1.0, 1.0, size=6)]
+    R = _rot(math.radians(2.0) * strength * u[0], math.radians(2.0) * strength * u[1], math.radians(5.0) * strength * u[2])
+    tv = [u[3] + (0.5 if u[3] >= 0 else -0.5), u[4], 0.6 * u[5]]                 # never along the optical axis alone
+    nt = math.sqrt(tv[0] ** 2 + tv[1] ** 2 + tv[2] ** 2)
+    t = [0.06 * strength * c / nt for c in tv]
+    f, cx, cy = 520.0, (W - 1) / 2.0, (H - 1) / 2.0
+    K = [[f, 0.0, cx], [0.0, f, cy], [0.0, 0.0, 1.0]]
+    Ki = _inv3(K)
+    r1, c1 = np.mgrid[0:H, 0:W].astype(np.float64)
+    split = (W - 1) / 2.0                                                        # view-0 column where the scene's depth jumps
+    src = []
+    for d, left in ((1.0, True), (1.6, False)):
+        M = [[R[a][b] + (t[a] / d if b == 2 else 0.0) for b in range(3)] for a in range(3)]       # R + t n^T / d, n = (0, 0, 1)
+        Gi = _inv3(_mm3(_mm3(K, M), Ki))
+        den = Gi[2][0] * c1 + Gi[2][1] * r1 + Gi[2][2]
+        x0 = (Gi[0][0] * c1 + Gi[0][1] * r1 + Gi[0][2]) / den
+        y0 = (Gi[1][0] * c1 + Gi[1][1] * r1 + Gi[1][2]) / den
+        src.append((x0, y0, (x0 <= split) if left else (x0 > split)))
+    (xa, ya, oka), (xb, yb, okb) = src
+    use_a = oka | ~okb                                                           # the near plane wherever its pre-image lies on its half, else the far one
+    x0, y0 = np.where(use_a, xa, xb), np.where(use_a, ya, yb)
+    v1 = _bilinear(canvas, x0 + MARGIN, y0 + MARGIN)
+    v1 = np.clip(v1 + rng.normal(0.0, 1.0, size=(3, H, W)) * noise, 0.0, 1.0).astype(np.float32)
+    sx, sy = (W - 1.0) / W, (H - 1.0) / H
+    S = [[sx, 0.0, 0.5 * sx], [0.0, sy, 0.5 * sy], [0.0, 0.0, 1.0]]
+    Kt = np.array(_mm3(S, K), np.float64).astype(np.float32)
+    pose = np.eye(4, dtype=np.float64)
+    pose[:3, :3] = np.array(R)
+    pose[:3, 3] = np.array(t)
+    return v0, v1, Kt, pose.astype(np.float32)

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 # north_star: descriptors within 1e-4 fp32.  Score maps: 1e-5 (observed ~4e-6 against the reference,
 # from BN folding and a different fp32 summation order than oneDNN).
-ATOL_DESC, ATOL_SCORE = 1e-4, 1e-5
+ATOL_DESC, ATOL_SCORE = 1e-4, 7e-6      # score: measured 4.9e-6 on 256 full-size pairs with the round-to-nearest split (r04); r03's truncating split (8.0e-6) would fail here, as it should
 
 
 def _oracle_forward(img, intermediates=False):

@@ -145,3 +145,31 @@ def test_metric_bar_on_64_viewpoint_pairs_gpu_chain_vs_oracle_chain():
     assert 0.2 < r["repeatability_cpu"] < 0.8 and 0.3 < r["mha_cpu"][0] < 1.0, brief       # the family is discriminating
     # GPU RANSAC = numpy restatement hypothesis for hypothesis: on the SAME rows in the SAME order nothing may flip
     assert r["mha_flag_flips_gpu_vs_cpu_in_gpu_row_order"] == [0, 0, 0], brief
+
+
+@pytest.mark.timeout(1500)
+def test_auc_bar_on_64_pose_pairs_gpu_chain_vs_oracle_chain():
+    """BASELINE configs[2]'s estimator (tasks/AUC.py:101-154: essential-matrix RANSAC + recoverPose, order-dependent sampler) from
+    pixels on 64 pairs with known camera motion: on the SAME rows in the SAME order the GPU chain is the oracle chain; what row order
+    alone does to the pose error is measured and bounded."""
+    import metric_sweep
+    r = metric_sweep.sweep_auc(64)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "metric_sweep_auc_64.json"), "w") as f:
+        json.dump(r, f, indent=1)
+    brief = {k: v for k, v in r.items() if k != "per_pair"}
+    # what r05 measured on these 64 pairs (profiles/r05_metric_sweep_auc_64.json): 63 pairs with the oracle chain's exact keypoint and match sets
+    # (one top-K cut between scores ~1e-6 apart: its 331 instead of 330 matches lead RANSAC elsewhere, 7.5 against 1.1 degrees); ROW ORDER ALONE
+    # moved no pose error at all (the orders differ by swaps of near-equal rows, which the winning samples did not touch); on the same rows in
+    # the same order 59 of 63 pairs agree to 1e-3 degrees and 4 keep a different model -- equal or nearly equal inlier counts (583 / 583,
+    # 575 / 566): fp64 rounding at the Sampson threshold and the order of a sample's up to ten roots decide such ties; OpenCV's own order there
+    # is unknowable without cv2 (PARITY UNPINNED, DESIGN.md section 3).  AUC@5/10/20 differ by 0.006 / 0.004 / 0.001.
+    assert r["pairs_with_identical_keypoint_sets"] >= 62, brief
+    assert r["pairs_with_identical_match_sets"] >= 62, brief
+    assert 0.1 < r["auc_cpu"][1] < 0.98 and r["median_err_cpu_deg"] < 20, brief            # the family is discriminating and solvable
+    agree = sum(p["err_cpu_in_gpu_row_order"] is not None and abs(p["err_gpu"] - p["err_cpu_in_gpu_row_order"]) <= 1e-3 for p in r["per_pair"])
+    assert agree >= 56, (agree, brief)                                                   # same rows, same order: the same pose
+    assert r["pairs_with_different_inlier_count_in_gpu_row_order"] <= 4, brief
+    assert max(r["abs_diff_auc_gpu_vs_cpu"]) <= 0.015, brief                               # north_star's +-0.001 is stated for repeatability / MHA; this is the pose metric's own spread
+    # row order alone: a different minimal sample may win; its effect on the metric is what the record states, bounded loosely here
+    assert max(r["abs_diff_auc_from_row_order_alone"]) <= 0.03, brief

@@ -133,3 +133,61 @@ def test_crop32_and_config_loading(tmp_path):
                    "      extractor_params: {nms_dist: 6, min_score: 0.0, top_k: 1000, threshold: 0, border_dist: 8}\n")
     p = runner.load_config(str(cfg))
     assert p["model_type"] == "Alike" and p["extractor_params"]["top_k"] == 1000 and p["data_params"]["batch_size"] == 1
+
+
+def _bench_rank(rank, world, port, q):
+    """One rank of bench.py's timed region and row exchange over gloo, with a stub step."""
+    import importlib.util
+    import time as _t
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    calls = []
+
+    def step():                                   # rank 1 is the slow one: the reported time must be ITS time
+        calls.append(1)
+        _t.sleep(0.002 * (1 + 2 * rank))
+
+    elapsed, tail = bench.timed_steps(step, 100, 3, dev, True, dist)
+    B = 5
+    rows = torch.tensor([[100.0 * rank + i, 1.0 + rank, float(i)] for i in range(B)])
+    allrows = bench.exchange_rows(rows, world, True, dist)
+    q.put((rank, len(calls), elapsed, tail, allrows.numpy().tolist(), dist.get_world_size()))
+    dist.destroy_process_group()
+
+
+def test_bench_rank_logic_over_gloo():
+    """bench.py's contract under two ranks: W untimed + exactly K timed steps per rank, MAX-over-ranks time (and last-half time),
+    one all-gather with rank r's rows at [r B, (r + 1) B) -- the 8-GPU run is the driver's, this is what can be checked here."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    ps = [ctx.Process(target=_bench_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, n0, e0, t0, rows0, w0), (r1, n1, e1, t1, rows1, w1) = res
+    assert n0 == n1 == 103 and w0 == w1 == 2
+    assert e0 == e1 and t0 == t1                           # both ranks report the MAX
+    assert e0 >= 100 * 0.006 and e0 < 100 * 0.006 * 3      # the slow rank's 6 ms steps, not the fast rank's 2 ms
+    assert 0.4 * e0 < t0 < 0.6 * e0                        # the last 50 of 100 steps
+    assert rows0 == rows1 and [r[0] for r in rows0] == [0, 1, 2, 3, 4, 100, 101, 102, 103, 104]
+
+
+def test_generator_threads_share_the_cores():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cores = len(os.sched_getaffinity(0))
+    assert bench.generator_threads(1) == max(1, min(cores, 16))
+    assert bench.generator_threads(8) == max(1, min(cores // 8, 16))
+    assert bench.generator_threads(8) * 8 <= max(cores, 8)
