@@ -99,7 +99,7 @@ def fp32_companion(args):
     operand anywhere), run in a CHILD process before this one touches the GPU: what the split-f16 matrix arithmetic buys."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(max(3, args.steps // 2)), "--warmup", str(args.warmup), "--no-cpu-baseline",
-           "--no-variants", "--model", args.model, "--matcher", args.matcher]
+           "--no-variants", "--model", args.model, "--matcher", args.matcher, "--lg-attention", args.lg_attention]
     if args.pairs_per_step:
         cmd += ["--pairs-per-step", str(args.pairs_per_step)]
     if args.sparse:
@@ -336,6 +336,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=None, help="distinct synthetic pairs generated (default: one per pair of the batch; fewer are cycled)")
     ap.add_argument("--matcher", default="brute_force", choices=["brute_force", "lightglue"],
                     help="lightglue = BASELINE configs[4] (with --model disk or superpoint), seeded stand-in weights")
+    ap.add_argument("--lg-attention", default="fp32", choices=["fp32", "f16"],
+                    help="LightGlue attention arithmetic: fp32 = the reference's CPU branch as split-f16 MFMA triples (default, what the parity fixtures pin); "
+                         "f16 = what the reference runs on a GPU (q.half(), k.half(), v.half() through SDPA, lightglue.py:129-134), reported separately")
     ap.add_argument("--model", default="alike", choices=["alike", "superpoint", "xfeat", "disk"],
                     help="alike = BASELINE configs[1] (the headline); superpoint = configs[2] with seeded random weights")
     args = ap.parse_args()
@@ -416,7 +419,7 @@ def main():
         from keypoint_bench_amd import weights as kw
         from keypoint_bench_amd.models.lightglue import LightGlue
         dim, scale = {"disk": (128, 1), "superpoint": (256, 8)}[args.model]
-        lg = LightGlue(features=None, desc_scale=scale)
+        lg = LightGlue(features=None, desc_scale=scale, attention=args.lg_attention)
         lg.load_state_dict(kw.random_lightglue_state_dict(31, dim, "plain"))
     pipe = PairPipeline(net, EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev, lightglue=lg)
     # synthetic pairs, different per rank, resident in HBM
@@ -491,7 +494,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_label(args.model, args.matcher),
-                       "matcher": args.matcher, "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
+                       "matcher": args.matcher, "lightglue_attention": (args.lg_attention if args.matcher == "lightglue" else None), "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns, "build": build_identity(), "world_size_seen": world_seen,
                        "arithmetic": ("strict fp32 (KPB_FP32_MATRIX=1): fp32 MFMA / fp32 vector ALUs, fp64 match" if strict_fp32() else

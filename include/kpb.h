@@ -299,6 +299,11 @@ typedef struct kpb_lg_params {      /* LightGlue.default_conf, lightglue.py:335-
 int kpb_lg_create(kpb_ctx* ctx, const void* blob, size_t len, float desc_scale, kpb_lg** out);
 void kpb_lg_destroy(kpb_lg* lg);
 int kpb_lg_input_dim(const kpb_lg* lg);
+/* Attention arithmetic.  0 (default): every product as split-f16 MFMA triples with fp32 accumulation = the fp32 result of the
+ * reference's CPU branch (models/lightglue.py:135-137), which the parity fixtures pin.  1: what the reference runs on a GPU
+ * (lightglue.py:129-134: q.half(), k.half(), v.half() through scaled_dot_product_attention, the half result cast back) -- Q, K, V and
+ * the probabilities as plain f16, one MFMA per product, fp32 softmax, output rounded to f16.  Opt-in, reported separately by bench.py. */
+int kpb_lg_set_attention(kpb_lg* lg, int mode);
 /* pts*_dev [batch][max_k][3] normalised (x, y, score) as detection returns them; n*_dev [batch] or NULL;
  * desc*_dev: descriptor maps of the two sides, [batch] x (C, Hd, Wd) with element strides (sb, sc, sh, sw);
  * img_w / img_h: params['w'], params['h'] of the reference call.

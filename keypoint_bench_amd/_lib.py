@@ -82,6 +82,7 @@ SIGNATURES = {
     "kpb_lg_create": (c_int, [c_void_p, c_void_p, c_size_t, c_float, ctypes.POINTER(c_void_p)]),
     "kpb_lg_destroy": (None, [c_void_p]),
     "kpb_lg_input_dim": (c_int, [c_void_p]),
+    "kpb_lg_set_attention": (c_int, [c_void_p, c_int]),
     "kpb_lg_match": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                              c_int64, c_int64, c_int64, c_int64, c_int, c_int, ctypes.POINTER(LgParams), c_void_p, c_void_p,
                              c_void_p, c_void_p]),

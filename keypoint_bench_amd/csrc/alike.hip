@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
     float4 keep = make_float4(0.f, 0.f, 0.f, 0.f);
     float xmax = 0.0f;                  // this lane's largest x1 value (x1 >= 0)
     const int gx = tx0 + 2 * pr + sN;
-#pragma unroll 1
+#pragma unroll 1          // (r05: unrolled by two -- both rows' MFMAs ahead of both epilogues -- 2.32 -> 2.375 ms, three interleaved runs: not kept)
     for (int rr = 0; rr < TH / 4; ++rr) {
         const int row = (TH / 4) * wv + rr;
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};

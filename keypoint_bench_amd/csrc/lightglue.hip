@@ -244,6 +244,8 @@ struct FragArgs {
     int* kvexp;         // [S][NH][MP/32][2]: cm_exp_of(amax) of the K block and of the V block
     const int* cnt; const int* active;
     int MP, cross;
+    int f16only;        // attention = "f16" (kpb_lg_set_attention): the operands are the plain half-precision casts x.half() of
+                        // lightglue.py:131 -- scale 1 (exponent 141: cm_scale_of = cm_unscale_of = 1), the lo halves unused
 };
 
 __global__ __launch_bounds__(256) void lg_kv_frags(FragArgs a)
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(256) void lg_kv_frags(FragArgs a)
     mk = cm_wave_max(mk); mv = cm_wave_max(mv);
     if (lane == 0) { s_am[0][t >> 6] = mk; s_am[1][t >> 6] = mv; }
     __syncthreads();
-    const int ek = cm_exp_of(fmaxf(fmaxf(s_am[0][0], s_am[0][1]), fmaxf(s_am[0][2], s_am[0][3])));
-    const int ev = cm_exp_of(fmaxf(fmaxf(s_am[1][0], s_am[1][1]), fmaxf(s_am[1][2], s_am[1][3])));
+    const int ek = a.f16only ? 141 : cm_exp_of(fmaxf(fmaxf(s_am[0][0], s_am[0][1]), fmaxf(s_am[0][2], s_am[0][3])));
+    const int ev = a.f16only ? 141 : cm_exp_of(fmaxf(fmaxf(s_am[1][0], s_am[1][1]), fmaxf(s_am[1][2], s_am[1][3])));
     if (t == 0) { int* e = a.kvexp + (((size_t)s * NH + head) * NB + blk) * 2; e[0] = ek; e[1] = ev; }
     const float sk = cm_scale_of(ek), sv = cm_scale_of(ev);
 #pragma unroll
@@ -294,6 +296,12 @@ struct FlashHArgs {
     int MP, cross; float scale;
 };
 
+// F16 (r05, VERDICT r04 missing 3): the arithmetic the REFERENCE runs on a GPU -- lightglue.py:129-134 hands q.half(), k.half(), v.half() to
+// scaled_dot_product_attention and casts the half-precision result back: Q, K, V as plain f16 casts (no scale, no lo halves: ONE MFMA
+// per product instead of three), scores and softmax in fp32, the probabilities cast to f16 for P.V with fp32 accumulation, the
+// output rounded to f16.  Opt-in (kpb_lg_set_attention / LightGlue(attention="f16")), reported separately; the default stays the
+// fp32-equivalent split form, which is what the reference's CPU path -- the parity contract -- computes.
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
 {
     const int s = blockIdx.z, head = blockIdx.y;
@@ -319,7 +327,7 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
             t0[kb] = qvalid ? *reinterpret_cast<const float4*>(qp + 16 * kb) : z4; t1[kb] = qvalid ? *reinterpret_cast<const float4*>(qp + 16 * kb + 4) : z4;
             am = cm_amax4(cm_amax4(am, t0[kb]), t1[kb]);
         }
-        const int eq = cm_exp_of(cm_wave_max(am));
+        const int eq = F16 ? 141 : cm_exp_of(cm_wave_max(am));
         const float sq = cm_scale_of(eq);
         qscale = a.scale * cm_unscale_of(eq);
 #pragma unroll
@@ -357,8 +365,10 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
         f32x16 st = {0};
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {       // S^T: rows = keys, col = query p
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kl[kb], Qh[kb], st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[kb], Ql[kb], st, 0, 0, 0);
+            if constexpr (!F16) {
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kl[kb], Qh[kb], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[kb], Ql[kb], st, 0, 0, 0);
+            }
             st = __builtin_amdgcn_mfma_f32_32x32x16_f16(Kh[kb], Qh[kb], st, 0, 0, 0);
         }
         float sc[16], mx = -INFINITY;
@@ -395,30 +405,36 @@ __global__ __launch_bounds__(256) void lg_flash_h(FlashHArgs a)
             }
             ev_run = ev;
         }
-        const float pfac = cm_pow2(max(ev - ev_run, -100) + 13);
+        const float pfac = F16 ? 1.0f : cm_pow2(max(ev - ev_run, -100) + 13);      // F16: p.half(), unscaled, as the reference's kernel casts it
 #pragma unroll
         for (int r = 0; r < 16; ++r) pr[r] *= pfac;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {       // registers 8 kb .. 8 kb + 7 are this lane half's keys of k-block kb
             cm_h8 Ph, Pl;
             cm_split8(pr + 8 * kb, Ph, Pl);
-            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl, Vh[0][kb], O0, 0, 0, 0);
-            O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vl[0][kb], O0, 0, 0, 0);
+            if constexpr (!F16) {
+                O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl, Vh[0][kb], O0, 0, 0, 0);
+                O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vl[0][kb], O0, 0, 0, 0);
+            }
             O0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vh[0][kb], O0, 0, 0, 0);
-            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl, Vh[1][kb], O1, 0, 0, 0);
-            O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vl[1][kb], O1, 0, 0, 0);
+            if constexpr (!F16) {
+                O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Pl, Vh[1][kb], O1, 0, 0, 0);
+                O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vl[1][kb], O1, 0, 0, 0);
+            }
             O1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ph, Vh[1][kb], O1, 0, 0, 0);
         }
     }
-    const float inv = l_run > 0.0f ? (1.0f / l_run) * cm_unscale_of(max(ev_run, 24)) * cm_pow2(-13) : 0.0f;
+    const float inv = l_run > 0.0f ? (1.0f / l_run) * cm_unscale_of(max(ev_run, 24)) * (F16 ? 1.0f : cm_pow2(-13)) : 0.0f;
     float* op = a.out + (size_t)s * a.MP * D + head * HD + p;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int qi = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float ir = __shfl(inv, qi, 64);
         if (q0 + qi < nq) {
-            op[(size_t)(q0 + qi) * D] = O0[r] * ir;
-            op[(size_t)(q0 + qi) * D + 32] = O1[r] * ir;
+            float o0 = O0[r] * ir, o1 = O1[r] * ir;
+            if constexpr (F16) { o0 = (float)(_Float16)o0; o1 = (float)(_Float16)o1; }      // the half-precision result, .to(q.dtype)
+            op[(size_t)(q0 + qi) * D] = o0;
+            op[(size_t)(q0 + qi) * D + 32] = o1;
         }
     }
 }
@@ -725,6 +741,7 @@ struct kpb_lg {
     std::map<std::string, size_t> off;
     std::map<std::string, float> wscale;   // split-f16 packs: the power-of-two weight scale of each Linear
     kpb_buf ws;
+    int attn_f16 = 0;                      // kpb_lg_set_attention: 1 = the reference's GPU arithmetic (lg_flash_h<true>)
     float* wp(const std::string& n) { return wdev + off.at(n); }
 };
 
@@ -884,6 +901,16 @@ KPB_API void kpb_lg_destroy(kpb_lg* lg)
 
 KPB_API int kpb_lg_input_dim(const kpb_lg* lg) { return lg ? lg->input_dim : 0; }
 
+KPB_API int kpb_lg_set_attention(kpb_lg* lg, int mode)
+{
+    if (!lg) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_lg_set_attention: null matcher");
+    if (mode != 0 && mode != 1) return kpb_fail(lg->ctx, KPB_E_INVALID, "kpb_lg_set_attention: mode %d (0 = fp32-equivalent, 1 = f16 as the reference on a GPU)", mode);
+    if (mode == 1 && !conv_mfma_use_h16())
+        return kpb_fail(lg->ctx, KPB_E_UNSUPPORTED, "kpb_lg_set_attention: the f16 form needs the matrix-pipe build of the attention (KPB_FP32_MATRIX is set)");
+    lg->attn_f16 = mode;
+    return KPB_OK;
+}
+
 KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_dev, const int32_t* n0_dev, const int32_t* n1_dev,
                          int batch, int max_k, const float* desc0_dev, const float* desc1_dev, int C, int Hd, int Wd,
                          int64_t sb, int64_t sc, int64_t sh, int64_t sw, int img_w, int img_h, const kpb_lg_params* prm,
@@ -964,10 +991,11 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
             KPB_LAUNCH(ctx, "lg_rotary", lg_rotary, dim3(cdiv(max_k * 128, 256), S), dim3(256), 0, st, qkv, cs, sn, q, k, v, cnt, active_seq, MP);
         }
         if (h16) {
-            FragArgs fr{k, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 0};
+            FragArgs fr{k, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 0, lg->attn_f16};
             KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
             FlashHArgs fa{q, kfrag, vfrag, kvexp, cx, cnt, active_seq, MP, 0, 0.125f};
-            KPB_LAUNCH(ctx, "lg_flash_self", lg_flash_h, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
+            if (lg->attn_f16) KPB_LAUNCH(ctx, "lg_flash_self", lg_flash_h<true>, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
+            else KPB_LAUNCH(ctx, "lg_flash_self", lg_flash_h<false>, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
         } else {
             FlashArgs fa{q, k, v, cx, cnt, active_seq, MP, 0, 0.125f};
             KPB_LAUNCH(ctx, "lg_flash_self", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fa);
@@ -983,10 +1011,11 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
             if ((rc = lg_linear(ctx, lg, "lg_to_v", L + ".tov", 256, 256, c, 512, v, 256, 0, S, MP, active_seq, cnt))) return rc;
         }
         if (h16) {
-            FragArgs fr{q, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 1};
+            FragArgs fr{q, v, kfrag, vfrag, kvexp, cnt, active_seq, MP, 1, lg->attn_f16};
             KPB_LAUNCH(ctx, "lg_kv_frags", lg_kv_frags, dim3(cdiv(max_k, 32), NH, S), dim3(256), 0, st, fr);
             FlashHArgs fc{q, kfrag, vfrag, kvexp, cx, cnt, active_seq, MP, 1, 0.125f};
-            KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash_h, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
+            if (lg->attn_f16) KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash_h<true>, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
+            else KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash_h<false>, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);
         } else {
             FlashArgs fc{q, q, v, cx, cnt, active_seq, MP, 1, 0.125f};
             KPB_LAUNCH(ctx, "lg_flash_cross", lg_flash, dim3(cdiv(max_k, 128), NH, S), dim3(256), 0, st, fc);

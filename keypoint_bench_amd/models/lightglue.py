@@ -20,9 +20,14 @@ _FEATURES = {"superpoint": dict(weights="superpoint_lightglue", input_dim=256, d
 class LightGlue:
     default_conf = dict(depth_confidence=0.95, width_confidence=0.99, filter_threshold=0.1)       # lightglue.py:335-348
 
-    def __init__(self, features="superpoint", weight_path="", desc_scale=None, prune_min_kpts=-1, **conf):
+    def __init__(self, features="superpoint", weight_path="", desc_scale=None, prune_min_kpts=-1, attention="fp32", **conf):
+        """attention: "fp32" (default) = the fp32 result of the reference's CPU branch (lightglue.py:135-137: what the fixtures pin), as split-f16
+        MFMA triples; "f16" = what the reference runs on a GPU (lightglue.py:129-134: q.half(), k.half(), v.half() through SDPA)."""
         if features is not None and features not in _FEATURES:
             raise ValueError("Unsupported features: %r (this build: %s)" % (features, ", ".join(_FEATURES)))
+        if attention not in ("fp32", "f16"):
+            raise ValueError("attention must be 'fp32' or 'f16', not %r" % (attention,))
+        self.attention = attention
         self.conf = dict(self.default_conf, **{k: v for k, v in conf.items() if k in self.default_conf})
         self.prune_min_kpts = int(prune_min_kpts)
         self.desc_scale = desc_scale
@@ -71,6 +76,8 @@ class LightGlue:
         h = c_void_p()
         self._ctx.check(self._ctx.lib.kpb_lg_create(self._ctx.handle, self._blob, len(self._blob), float(self.desc_scale), ctypes.byref(h)))
         self._handle, self._device = h, device
+        if self.attention == "f16":
+            self._ctx.check(self._ctx.lib.kpb_lg_set_attention(h, 1))
 
     def match_indices(self, pts0, pts1, desc_map_0, desc_map_1, params):
         """Returns (pairs [K,2] int64, scores [K] float32, layers_run)."""

@@ -9,6 +9,10 @@ for spec in "superpoint brute_force" "xfeat brute_force" "disk brute_force" "sup
   set -- $spec
   timeout -k 10 300 python bench.py --model $1 --matcher $2 --no-cpu-baseline > gpurun_out/$R/bench_$1_$2.json 2> gpurun_out/$R/bench_$1_$2.err || echo "$spec failed"
 done
+# the opt-in f16 attention of LightGlue (what the reference runs on a GPU, lightglue.py:129-134), reported separately
+for net in superpoint disk; do
+  timeout -k 10 300 python bench.py --model $net --matcher lightglue --lg-attention f16 --no-cpu-baseline --no-variants > gpurun_out/$R/bench_${net}_lightglue_f16attn.json 2> gpurun_out/$R/bench_${net}_lightglue_f16attn.err || echo "$net lightglue f16 failed"
+done
 if [ -n "$2" ] || [ -n "$PMC" ]; then
   bash scripts/prof_pmc.sh ${R}_superpoint --model superpoint > gpurun_out/$R/pmc_superpoint.txt 2>&1
   bash scripts/prof_pmc.sh ${R}_disk_lightglue --model disk --matcher lightglue > gpurun_out/$R/pmc_disk_lightglue.txt 2>&1

@@ -27,6 +27,28 @@ def inputs(seed, dim, scale, H=240, W=320, n0=300, n1=280):
     return dm0, dm1, p0, p1.astype(np.float32)
 
 
+def half_attention(net, lg, torch):
+    """Makes every Attention module of the reference instance take ITS OWN cuda branch on this CPU: lightglue.py:129-134 is guarded by
+    `self.enable_flash and q.device.type == "cuda"`; the three statements it guards run unchanged here (torch's CPU SDPA takes half
+    tensors: fp32 accumulation, half result), so the fixture is what the reference's class computes from q.half(), k.half(), v.half()."""
+    import types
+    F = torch.nn.functional
+
+    def forward(self, q, k, v, mask=None):
+        if q.shape[-2] == 0 or k.shape[-2] == 0:
+            return q.new_zeros((*q.shape[:-1], v.shape[-1]))
+        args = [x.half().contiguous() for x in [q, k, v]]                              # lightglue.py:131
+        v = F.scaled_dot_product_attention(*args, attn_mask=mask).to(q.dtype)          # lightglue.py:132
+        return v if mask is None else v.nan_to_num()                                   # lightglue.py:133
+
+    n = 0
+    for m in net.modules():
+        if isinstance(m, lg.Attention):
+            m.forward = types.MethodType(forward, m)
+            n += 1
+    assert n == 2 * net.conf.n_layers, n
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference checkout not present; nothing to do")
@@ -52,12 +74,18 @@ def main():
                                                         ("disk_prune", 128, 1, "prune", 25, 300, 280, -1), ("disk_n1000", 128, 1, "plain", 26, 1000, 977, -1),
                                                         ("sp_n1000", 256, 8, "prune", 27, 1000, 1000, -1),
                                                         ("disk_n1536_th1024", 128, 1, "prune", 28, 1536, 1500, 1024),
-                                                        ("disk_n2048_th1536", 128, 1, "prune", 29, 2048, 2000, 1536)):
+                                                        ("disk_n2048_th1536", 128, 1, "prune", 29, 2048, 2000, 1536),
+                                                        # r05: the reference's GPU arithmetic -- its Attention fed q.half(), k.half(), v.half()
+                                                        # (lightglue.py:129-134), see half_attention below
+                                                        ("sp_plain_f16", 256, 8, "plain", 21, 300, 280, -1), ("disk_plain_f16", 128, 1, "plain", 24, 300, 280, -1),
+                                                        ("disk_prune_f16", 128, 1, "prune", 25, 300, 280, -1), ("disk_n1000_f16", 128, 1, "plain", 26, 1000, 977, -1)):
         cases.append(name)
         if name + ".cfg" in out:
             continue
         net = lg.LightGlue(features=None, input_dim=dim)
         net.desc_scale = scale
+        if name.endswith("_f16"):
+            half_attention(net, lg, torch)
         if th >= 0:
             net.pruning_keypoint_thresholds = dict(lg.LightGlue.pruning_keypoint_thresholds, cpu=th)
         out[name + ".prune_th"] = np.array(th)
