@@ -47,9 +47,14 @@ def posenc(t, kpts):
     return emb.repeat_interleave(2, dim=-1)
 
 
+HALF_ATTENTION = False      # True: the reference's cuda branches (lightglue.py:129-134, 226-230): q.half(), k.half(), v.half() through SDPA
+
+
 def _attention(q, k, v):
     if q.shape[-2] == 0 or k.shape[-2] == 0:
         return q.new_zeros((*q.shape[:-1], v.shape[-1]))
+    if HALF_ATTENTION:                                                  # lightglue.py:131-132
+        return F.scaled_dot_product_attention(q.half().contiguous(), k.half().contiguous(), v.half().contiguous()).to(q.dtype)
     s = q.shape[-1] ** -0.5
     attn = F.softmax(torch.einsum("...id,...jd->...ij", q, k) * s, -1)
     return torch.einsum("...ij,...jd->...id", attn, v)
@@ -76,6 +81,11 @@ def cross_block(t, i, x0, x1):                                         # lightgl
     lin = lambda n, x: F.linear(x, t[p + "." + n + ".weight"], t[p + "." + n + ".bias"])
     split = lambda z: z.unflatten(-1, (HEADS, -1)).transpose(1, 2)
     qk0, qk1, v0, v1 = split(lin("to_qk", x0)), split(lin("to_qk", x1)), split(lin("to_v", x0)), split(lin("to_v", x1))
+    if HALF_ATTENTION:                                                  # lightglue.py:226-230
+        m0, m1 = _attention(qk0, qk1, v1), _attention(qk1, qk0, v0)
+        m0, m1 = (z.transpose(1, 2).flatten(start_dim=-2) for z in (m0, m1))
+        m0, m1 = lin("to_out", m0), lin("to_out", m1)
+        return x0 + _ffn(t, p, torch.cat([x0, m0], -1)), x1 + _ffn(t, p, torch.cat([x1, m1], -1))
     scale = qk0.shape[-1] ** -0.5
     qk0, qk1 = qk0 * scale ** 0.5, qk1 * scale ** 0.5
     sim = torch.einsum("bhid, bhjd -> bhij", qk0, qk1)

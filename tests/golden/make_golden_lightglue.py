@@ -28,25 +28,42 @@ def inputs(seed, dim, scale, H=240, W=320, n0=300, n1=280):
 
 
 def half_attention(net, lg, torch):
-    """Makes every Attention module of the reference instance take ITS OWN cuda branch on this CPU: lightglue.py:129-134 is guarded by
-    `self.enable_flash and q.device.type == "cuda"`; the three statements it guards run unchanged here (torch's CPU SDPA takes half
-    tensors: fp32 accumulation, half result), so the fixture is what the reference's class computes from q.half(), k.half(), v.half()."""
+    """Makes the reference instance take ITS OWN cuda branches on this CPU.  lightglue.py:129-134 (Attention.forward) is guarded by
+    `self.enable_flash and q.device.type == "cuda"` and lightglue.py:226-230 (CrossBlock.forward) by `self.flash is not None and
+    qk0.device.type == "cuda"`; the statements they guard run unchanged here (torch's CPU SDPA takes half tensors: fp32 accumulation,
+    half result), so the fixture is what the reference's classes compute from q.half(), k.half(), v.half() in BOTH attention blocks."""
     import types
     F = torch.nn.functional
 
-    def forward(self, q, k, v, mask=None):
+    def attn_forward(self, q, k, v, mask=None):
         if q.shape[-2] == 0 or k.shape[-2] == 0:
             return q.new_zeros((*q.shape[:-1], v.shape[-1]))
         args = [x.half().contiguous() for x in [q, k, v]]                              # lightglue.py:131
         v = F.scaled_dot_product_attention(*args, attn_mask=mask).to(q.dtype)          # lightglue.py:132
         return v if mask is None else v.nan_to_num()                                   # lightglue.py:133
 
-    n = 0
+    def cross_forward(self, x0, x1, mask=None):                                        # lightglue.py:216-243 with the branch of 226-230
+        qk0, qk1 = self.map_(self.to_qk, x0, x1)
+        v0, v1 = self.map_(self.to_v, x0, x1)
+        qk0, qk1, v0, v1 = map(lambda t: t.unflatten(-1, (self.heads, -1)).transpose(1, 2), (qk0, qk1, v0, v1))
+        m0 = self.flash(qk0, qk1, v1, mask)
+        m1 = self.flash(qk1, qk0, v0, mask.transpose(-1, -2) if mask is not None else None)
+        m0, m1 = self.map_(lambda t: t.transpose(1, 2).flatten(start_dim=-2), m0, m1)
+        m0, m1 = self.map_(self.to_out, m0, m1)
+        x0 = x0 + self.ffn(torch.cat([x0, m0], -1))
+        x1 = x1 + self.ffn(torch.cat([x1, m1], -1))
+        return x0, x1
+
+    n = c = 0
     for m in net.modules():
         if isinstance(m, lg.Attention):
-            m.forward = types.MethodType(forward, m)
+            m.forward = types.MethodType(attn_forward, m)
             n += 1
-    assert n == 2 * net.conf.n_layers, n
+        if isinstance(m, lg.CrossBlock):
+            assert m.flash is not None
+            m.forward = types.MethodType(cross_forward, m)
+            c += 1
+    assert n == 2 * net.conf.n_layers and c == net.conf.n_layers, (n, c)
 
 
 def main():

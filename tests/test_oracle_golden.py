@@ -189,6 +189,7 @@ def test_lightglue_restatement_matches_reference():
         t = {k: torch.from_numpy(v) for k, v in weights.tensors_lightglue(weights.random_lightglue_state_dict(seed, dim, str(g[name + ".variant"]))).items()}
         dm0, dm1, p0, p1 = mk.inputs(seed, dim, scale, n0=n0, n1=n1)
         th = int(g[name + ".prune_th"]) if name + ".prune_th" in g else -1      # the reference's CUDA pruning thresholds (1024 / 1536)
+        R.HALF_ATTENTION = str(name).endswith("_f16")       # r05: fixtures of the reference's cuda attention branches (half operands)
         with torch.no_grad():
             m0, m1, out = R.match(t, torch.from_numpy(p0), torch.from_numpy(p1), torch.from_numpy(dm0), torch.from_numpy(dm1), {"w": 320, "h": 240}, scale,
                                   pruning_th=th)
@@ -196,3 +197,4 @@ def test_lightglue_restatement_matches_reference():
         np.testing.assert_allclose(out["scores"].numpy(), g[name + ".scores"], rtol=1e-4, atol=1e-6, err_msg=name)
         assert out["stop"] == int(g[name + ".stop"]), name
         np.testing.assert_array_equal(m0.numpy(), g[name + ".m0"])
+    R.HALF_ATTENTION = False
