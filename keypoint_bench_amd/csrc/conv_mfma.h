@@ -37,6 +37,12 @@ struct ConvM {
     const float* aux1 = nullptr;
     float* out1 = nullptr;
     float* out2 = nullptr;
+    // conv_mfma_h<.., PRE> (r05): `in` holds the activations ALREADY SPLIT by the producing kernel -- per pixel and 32-channel slab 128 bytes
+    // = [4 x 16 B of hi halves | 4 x 16 B of lo halves], taken at the per-image power-of-two scale of cm_exp_of(amax_in l1 + bmax), a rigorous
+    // bound of the producer's output (amax_in: the producer's INPUT maximum, measured; l1 / bmax: its largest row L1 norm / |bias|), so the
+    // scale is known before the producer stores and the consumer lands raw bytes in its tile by LDS-DMA: no staging registers, no maximum
+    // pass, no split, one barrier per slab.  pre_zero: 128 zero bytes (the source of pixels outside the image).
+    const unsigned* pre_amax = nullptr; float pre_l1 = 0.0f, pre_bmax = 0.0f; const void* pre_zero = nullptr;
     int unfold_w = 0;             // gemm_h<.., UNFOLD>: `in` is a single-channel [B][8 H][unfold_w] image and row r, channel c stand for pixel
                                   // (8 (r / W) + c / 8, 8 (r % W) + c % 8): XFeat's _unfold2d(x, 8) read in place (XFeat.py:96-103, 138)
 };
@@ -289,6 +295,16 @@ __device__ __forceinline__ float cm_wave_max(float v)
 // waves per SIMD the register allocation is held to: what r02's code reached without being told (accumulators 16 MT NTB) --
 // left alone, the allocator keeps a second copy of the accumulators in VGPRs for the rare rescale below (+64 registers, a wave
 // per SIMD lost on every two-tile layer)
+// 16 bytes per lane from global memory to LDS at lds_wave_base + 16 * lane (wave-uniform base), no register in between (the head of
+// ALIKE has the story: alike.hip hp_dma16).  M0 belongs to the compiler: saved and restored around the one instruction that reads it.
+__device__ __forceinline__ void cm_dma16(const void* gsrc, const void* lds_wave_base)
+{
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)reinterpret_cast<uintptr_t>(lds_wave_base));
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(m0v), "v"(gsrc) : "memory");
+}
+
 constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
 {
     return MT * NTB >= 4 ? ((KS == 5 && CC == 32) || POOL_IN ? 2 : 3) : (MT * NTB == 2 ? (KS == 3 && CC == 16 ? 3 : 4) : 5);
@@ -299,9 +315,10 @@ constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
 // slab are requested before the slab's input is even loaded and land while it is staged: one round trip per slab instead of ten.
 // Costs T x 4 NTB NKB registers (144 for a 3 x 3 kernel, one n-tile), irrelevant at one wave per SIMD; the arithmetic and its order
 // are those of the throughput form.
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false>
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false>
 __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
+    static_assert(!PRE || (CC == 32 && S == 1 && !POOL_IN && !XF && !XC && !WPRE), "conv_mfma_h: the pre-split input form exists for plain stride-1 32-channel slabs");
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
     constexpr int PITCH = 4 * CC + 16, LO = 2 * CC;                 // bytes per pixel, offset of its lo halves
@@ -351,6 +368,29 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                     }
             }
         }
+        if constexpr (PRE) {
+            // the tile as DENSE 128-byte pixels t = y IW + x, slot s of pixel t at 16-byte position s ^ (t & 7): the sixteen lanes of a
+            // fragment read touch sixteen consecutive pixels at one slot -- eight distinct positions per eight lanes.  A DMA unit = one
+            // wave instruction = 8 pixels x 8 slots = 1 KB; lane i lands at position i & 7 of pixel 8 u + (i >> 3), so the slot it has to
+            // fetch, (i & 7) ^ (i >> 3), is a constant of the lane.
+            constexpr int NPIX = IH * IW, NU = (NPIX + 7) / 8;
+            static_assert(NU * 1024 <= IH * ROWP, "conv_mfma_h<PRE>: the dense tile must fit the padded one's LDS");
+            if (ch == 0) e_cur = cm_exp_of(fmaf(__uint_as_float(a.pre_amax[b]), a.pre_l1, a.pre_bmax));
+            __syncthreads();                    // the previous slab's taps are done with the tile
+            const int myslot = (lane & 7) ^ ((lane >> 3) & 7);
+            const unsigned char* src0 = reinterpret_cast<const unsigned char*>(in) + (size_t)ch * 128 + myslot * 16;
+            const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.pre_zero) + myslot * 16;
+#pragma unroll 2
+            for (int u = wv; u < NU; u += 4) {
+                const int t = 8 * u + (lane >> 3);
+                const int y = t / IW, x = t - y * IW;
+                const int gy = iy0 + y, gx = ix0 + x;
+                const bool ok = t < NPIX && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc;
+                const unsigned char* src = ok ? src0 + ((size_t)gy * a.Wi + gx) * (size_t)(a.istride * 4) : zsrc;
+                cm_dma16(src, tile + u * 1024);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
         float4 buf[NLD];
         float amax = 0.0f;
 #pragma unroll
@@ -420,6 +460,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                 }
             }
         }
+        }       // !PRE
         __syncthreads();
         float xpart = 0.0f;      // XC: this slab's share of the extra channel, in the slab's activation scale
         static_assert(!WPRE || !XC, "conv_mfma_h: no latency form of the extra-channel layers");
@@ -465,11 +506,21 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int orow = 2 * (wv * MT + m) + (p >> 4);
+                if constexpr (PRE) {
+                    const int t = (orow + ky) * IW + ocol + kx, key = t & 7;
+                    const unsigned char* ap = &tile[t * 128];
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb) {
+                        Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * ((2 * h + kb) ^ key)));
+                        Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * ((4 + 2 * h + kb) ^ key)));
+                    }
+                } else {
                 const unsigned char* ap = &tile[(orow * S + ky) * ROWP + (ocol * S + kx) * PITCH + h * KC * 2];
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
                     Ah[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + 16 * kb));
                     Al[m][kb] = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + LO + 16 * kb));
+                }
                 }
             }
 #pragma unroll

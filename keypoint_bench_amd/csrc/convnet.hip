@@ -440,7 +440,11 @@ std::vector<float> pack_xf_s2(const float* w, int cout, float scale)
 
 // SuperPoint conv1a (1 -> 64, 3x3, ReLU; SuperPoint.py:44): 16 lanes share a pixel, each lane keeps the 9 taps of its
 // 4 output channels in registers and walks down a column of pixels, so a wave store is 4 whole 256-byte pixels.
-__global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block)
+// pre (r05): when pre_amax is given the 64 channels leave ALREADY SPLIT for conv_mfma_h<.., PRE> -- per pixel two 128-byte slabs of
+// [4 x 16 B hi halves | 4 x 16 B lo halves] -- at the power-of-two scale of cm_exp_of(amax(gray) l1 + bmax), the bound of this layer's output
+// (ConvM::pre_amax); a thread's four channels are 8 bytes of a hi slot and 8 of the matching lo slot.
+__global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block,
+                                                  const unsigned* pre_amax, float pre_l1, float pre_bmax)
 {
     const int b = blockIdx.z, lane16 = threadIdx.x & 15, c4 = lane16 * 4;
     const int x = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -472,6 +476,16 @@ __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out,
                 acc[j] = fmaf(r1[k], wr[3 + k][j], acc[j]);
                 acc[j] = fmaf(r2[k], wr[6 + k][j], acc[j]);
             }
+        if (pre_amax) {
+            const float sc = cm_scale_of(cm_exp_of(fmaf(__uint_as_float(pre_amax[b]), pre_l1, pre_bmax)));
+            uint2 hi, lo;
+            cm_split4(make_float4(relu(acc[0]) * sc, relu(acc[1]) * sc, relu(acc[2]) * sc, relu(acc[3]) * sc), hi, lo);
+            unsigned char* px = reinterpret_cast<unsigned char*>(out + (((size_t)b * H + y) * W + x) * 64);
+            const int slab = c4 >> 5, c = c4 & 31;
+            unsigned char* d = px + slab * 128 + (c >> 3) * 16 + ((c >> 2) & 1) * 8;
+            *reinterpret_cast<uint2*>(d) = hi;
+            *reinterpret_cast<uint2*>(d + 64) = lo;
+        } else
         *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * 64 + c4) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
 #pragma unroll
         for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; r2[k] = r3[k]; }
@@ -485,6 +499,29 @@ __global__ void rgb_sum(const float* img, float* gray, size_t P)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t b = blockIdx.y;
     if (i < P) gray[b * P + i] = (img[(b * 3 + 0) * P + i] + img[(b * 3 + 1) * P + i]) + img[(b * 3 + 2) * P + i];
+}
+
+// largest |value| of each image of a single-channel map, as float bits (one workgroup per image: 1.2 MB at 480 x 640; the input of the
+// bound the pre-split layers scale by).  Non-finite values are skipped, as amax_reduce does.
+__global__ __launch_bounds__(1024) void plane_abs_max(const float* __restrict__ g, size_t P, unsigned* out)
+{
+    __shared__ float s[16];
+    const float* p = g + (size_t)blockIdx.x * P;
+    float m = 0.0f;
+    for (size_t i = (size_t)threadIdx.x * 4; i + 3 < P; i += 4096) {
+        const float4 v = *reinterpret_cast<const float4*>(p + i);
+        const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+        m = fmaxf(m, fmaxf(fmaxf(a0 < INFINITY ? a0 : 0.0f, a1 < INFINITY ? a1 : 0.0f), fmaxf(a2 < INFINITY ? a2 : 0.0f, a3 < INFINITY ? a3 : 0.0f)));
+    }
+    for (size_t i = (P & ~(size_t)3) + threadIdx.x; i < P; i += 1024) { const float a0 = fabsf(p[i]); m = fmaxf(m, a0 < INFINITY ? a0 : 0.0f); }
+    m = cm_wave_max(m);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.0f;
+        for (int i = 0; i < 16; ++i) r = fmaxf(r, s[i]);
+        out[blockIdx.x] = __float_as_uint(r);
+    }
 }
 
 // SuperPoint.py:64-69: softmax over the 65 logits of a cell, drop the dustbin, depth-to-space 8x8.
@@ -673,8 +710,11 @@ struct Layer {      // one convolution of a network plan
     int ntb = 2;    // 32-wide output tiles per workgroup
 };
 
+struct PreSplit { const unsigned* amax = nullptr; float l1 = 0.0f, bmax = 0.0f; const void* zero = nullptr; };     // ConvM::pre_*
+
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
-                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f, const float2* unfold_mr = nullptr)
+                bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f, const float2* unfold_mr = nullptr,
+                const PreSplit* pre = nullptr)
 {
     const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
@@ -694,6 +734,13 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         const dim3 g2(cdiv(a.W, 16), cdiv(a.H, 16), B * a.nblk), g1(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk);
         // one-tile layers (cout <= 32) are bound by per-workgroup latency: 8-row tiles (one M tile per wave, 28 KB of LDS, five
         // workgroups per CU) measured 8-16 % faster; layers with two output tiles lose the fragment reuse that way (+8 % time)
+        if (pre) {      // the input arrives already split (ConvM::pre_amax): raw bytes land in the tile by LDS-DMA
+            a.pre_amax = pre->amax; a.pre_l1 = pre->l1; a.pre_bmax = pre->bmax; a.pre_zero = pre->zero;
+            if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2)
+                KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2, false, 2, false, true>), g2, block, 0, st, a);
+            else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no pre-split instance for %s", L.name.c_str());
+            return KPB_OK;
+        }
         if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), g1, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
@@ -791,6 +838,9 @@ void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b
 // ================================================================================================ SuperPoint
 struct SuperPointNet : kpb_net {
     std::map<std::string, Layer> L;
+    kpb_buf aux;                    // per-image maxima of the grey image + 128 zero bytes (the pre-split path)
+    const void* aux_zeroed = nullptr;
+    ~SuperPointNet() override { if (aux.p) (void)hipFree(aux.p); }
     int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
     {
         if ((H_ % 8) || (W_ % 8)) return kpb_fail(ctx, KPB_E_INVALID, "kpb_net_forward: SuperPoint needs H and W multiples of 8 (got %dx%d)", H_, W_);
@@ -819,8 +869,22 @@ struct SuperPointNet : kpb_net {
         hipStream_t st = ctx->stream;
         KPB_LAUNCH(ctx, "sp_rgb_sum", rgb_sum, dim3((unsigned)((P + 255) / 256), batch), dim3(256), 0, st, img, gray, P);
         int rc;
-        KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32);   // :44
-        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], x1a, x1b, batch, H, W, false, true, true))) return rc;      // :45-46 (+pool)
+        // r05: conv1a hands conv1b its 64 channels ALREADY SPLIT (ConvM::pre_amax), at the scale of the bound amax(gray) l1 + bmax of its
+        // own output -- known before it stores, so conv1b's tile is filled by LDS-DMA with no staging arithmetic (KPB_PRESPLIT=0: the r04 path)
+        static const int presplit = kpb_env_int("KPB_PRESPLIT", 1);
+        const bool pre = presplit && conv_mfma_use_h16() && (W % 4) == 0;
+        PreSplit ps;
+        if (pre) {
+            if ((rc = kpb_reserve(ctx, aux, (size_t)batch * sizeof(unsigned) + 256))) return rc;
+            unsigned* amax_gray = static_cast<unsigned*>(aux.p);
+            unsigned char* zero = reinterpret_cast<unsigned char*>(aux.p) + (((size_t)batch * sizeof(unsigned) + 127) / 128) * 128;
+            if (aux_zeroed != aux.p) { KPB_HIP(ctx, hipMemsetAsync(aux.p, 0, aux.cap, st)); aux_zeroed = aux.p; }     // (re-)allocated: the zero pixel must be zero
+            KPB_LAUNCH(ctx, "sp_gray_amax", plane_abs_max, dim3(batch), dim3(1024), 0, st, gray, P, amax_gray);
+            ps.amax = amax_gray; ps.l1 = wscale.at("conv1a.l1"); ps.bmax = wscale.at("conv1a.bmax"); ps.zero = zero;
+        }
+        KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32,
+                   ps.amax, ps.l1, ps.bmax);   // :44
+        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], x1a, x1b, batch, H, W, false, true, true, nullptr, 0, 0.0f, nullptr, pre ? &ps : nullptr))) return rc;      // :45-46 (+pool)
         if ((rc = launch_mfma(ctx, "sp_conv2a", this, L["conv2a"], x1b, x2a, batch, H / 2, W / 2, false, false, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv2b", this, L["conv2b"], x2a, x2b, batch, H / 2, W / 2, false, true, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv3a", this, L["conv3a"], x2b, x3a, batch, H / 4, W / 4, false, false, true))) return rc;
@@ -858,6 +922,17 @@ int superpoint_create(kpb_ctx* ctx, const KpbwBlob& bl, kpb_net** out)
         }
         stage_layer(ws, L, w, b);
         net->L[L.name] = L;
+        if (L.name == "conv1a") {       // |conv1a output| <= amax(gray) l1 + bmax (its channels' largest L1 norm, its largest |bias|)
+            float l1 = 0.0f, bmax = 0.0f;
+            for (int co = 0; co < L.cout; ++co) {
+                float r = 0.0f;
+                for (int k = 0; k < L.cin * 9; ++k) r += std::fabs(w[(size_t)co * L.cin * 9 + k]);
+                l1 = std::max(l1, r);
+                bmax = std::max(bmax, std::fabs(b[co]));
+            }
+            ws.wscale["conv1a.l1"] = l1 * 1.0001f;      // the bound is taken in fp32: a hair of slack for its own rounding
+            ws.wscale["conv1a.bmax"] = bmax;
+        }
     }
     if (int rc = ws.upload(net)) { delete net; return rc; }
     *out = net;
