@@ -11,6 +11,7 @@ of this GPU-initialised process):
   KPB_MATCH_PREFILTER=2  the MFMA prefilter + exact refinement for ANY number of pairs: the single-pair match goldens and the fuzz
                          then run on the path the batched pipelines take from 8 pairs up.
 
+  KPB_PRESPLIT=0         SuperPoint's conv1a -> conv1b hand-off as plain fp32 (r04) instead of pre-split halves landed by LDS-DMA (r05)
 Experiment knobs of r02 (KPB_HEAD_MAP / PIPE / WPS / PF, KPB_*_MT1, KPB_GEMM_*, KPB_BLOCK*_H16, KPB_CONV_H16) lost their
 non-default branches: the measured choice is the code."""
 import os
@@ -59,6 +60,13 @@ def test_prefilter_forced_on_single_pairs_passes_the_goldens():
     _child({"KPB_MATCH_PREFILTER": "2"}, ["tests/test_gpu_match.py", "tests/test_gpu_fuzz.py", "tests/test_gpu_range.py", "tests/test_gpu_pipeline.py"])
 
 
+@pytest.mark.timeout(900)
+def test_superpoint_without_the_presplit_handoff_passes_the_goldens():
+    """KPB_PRESPLIT=0: conv1a hands conv1b plain fp32 activations again (r04's path: staged through registers, split per slab); the default
+    since r05 is the pre-split hand-off landed by LDS-DMA (conv_mfma_h<.., PRE>)."""
+    _child({"KPB_PRESPLIT": "0"}, ["tests/test_gpu_superpoint.py", "tests/test_gpu_range.py", "tests/test_gpu_shapes.py"])
+
+
 def test_no_other_environment_knob_selects_a_kernel():
     """`kpb_env_int` may appear for exactly the knobs above (and the NMS schedule knobs tests/test_gpu_detect.py drives)."""
     import glob
@@ -66,5 +74,5 @@ def test_no_other_environment_knob_selects_a_kernel():
     names = set()
     for f in glob.glob(os.path.join(ROOT, "keypoint_bench_amd", "csrc", "*")):
         names |= set(re.findall(r'(?:env_int|getenv)\("(KPB_[A-Z0-9_]+)"', open(f).read()))
-    allowed = {"KPB_FP32_MATRIX", "KPB_MATCH_PREFILTER", "KPB_NMS_TILED", "KPB_NMS_PRUNE", "KPB_NMS_TAIL_ROUNDS"}
+    allowed = {"KPB_FP32_MATRIX", "KPB_MATCH_PREFILTER", "KPB_NMS_TILED", "KPB_NMS_PRUNE", "KPB_NMS_TAIL_ROUNDS", "KPB_PRESPLIT"}
     assert names <= allowed, names - allowed
