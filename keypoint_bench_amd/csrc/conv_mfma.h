@@ -614,6 +614,10 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
 // under the matrix work.  Workgroup = 256 rows x 32 NTB columns; wave = 64 rows (two M tiles); weights in pack_mfma_h's
 // KS = 1 order; LDS rows as in conv_mfma_h (hi | lo | pad, 144 bytes: nine 16-byte slots, conflict-free).
 template <int NTB, int MT = 2, int EPI = GE_PLAIN, bool UNFOLD = false>
+// (at four waves per SIMD the one-tile GE_RESIDUAL / GE_ROTARY forms spill 2 / 11 registers to scratch -- their epilogue operands
+// xv sit beside the accumulators in the last slab.  r05 measured the alternative it named, three waves per SIMD for those two (132 / 144
+// registers, no scratch): ffn3 + residual 0.915 -> 1.09 ms per 18 launches, three interleaved runs -- the spill is the cheaper evil; loading
+// the second k-block's weight fragments behind the first one's products changed nothing, the scheduler hoists them back.)
 __global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
 {
     // r03: a wave stages exactly the 32 MT rows it multiplies, so its slice of the LDS buffers is private to it (a wave's LDS

@@ -1,0 +1,88 @@
+// Does the ORDER in which the persistent ALIKE head walks its tiles cost memory bandwidth?  (r05)  The head writes [B][H][W][64] fp32:
+// a tile = 32 pixels of one row = 8 KB contiguous; a wave of the real kernel writes two tiles side by side (16 KB), then jumps four rows
+// down its 64-pixel column band (4 x W x 256 B = 640 KB at W = 640), and the four waves of a workgroup sit on four consecutive rows.
+// scripts/hbm_store_patterns.hip, where 5.77 TB/s was measured for the head's store shape, lets every wave stream a CONTIGUOUS region.
+//   MODE 0  contiguous per wave (that microbenchmark)
+//   MODE 1  the head's walk: band of 64 pixels, waves = rows y .. y + 3, groups down the image
+//   MODE 2  row walk: a workgroup takes 4 rows x 160 pixels (each wave 5 tiles = 40 KB contiguous), then the next 4 rows of the same 160 columns
+//   MODE 3  row walk, whole rows: a workgroup takes 4 rows x 640 pixels (each wave 20 tiles = 160 KB contiguous)
+// every mode: whole-pixel non-temporal stores (one 256-byte pixel per instruction) + one 1 KB load per tile, 512 images of 480 x 640.
+//   hipcc -O3 --offload-arch=gfx950 -o head_walk head_walk.hip && ./head_walk
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+constexpr int H = 480, W = 640, TPR = W / 32;      // tiles per row
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// tile index (row y, tile column tc) of image b -> float offset
+__device__ __forceinline__ size_t tile_off(int b, int y, int tc) { return (((size_t)b * H + y) * W + 32 * tc) * 64; }
+
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k(float* out, const float* in, int B, int groups_per_wg)
+{
+    __shared__ float pad[13000];                // 52 KB: three workgroups per CU, as the head
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (pad[threadIdx.x] == 77.0f) out[0] = 1.0f;
+    float v = (float)lane;
+    const int b = blockIdx.y;
+    const float* ib = in + ((size_t)b * gridDim.x + blockIdx.x) * 4096 + wv * 1024 + lane * 4;
+    f4 cur = *reinterpret_cast<const f4*>(ib);
+    auto tile = [&](size_t off, int t) {
+        const f4 nxt = *reinterpret_cast<const f4*>(ib + ((t + 1) & 3) * 256);
+        float* d = out + off + lane;
+        const float w = v + cur.x + cur.y + cur.z + cur.w;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) __builtin_nontemporal_store(w + r, d + r * 64);
+        cur = nxt;
+    };
+    if (MODE == 0) {            // contiguous region per wave: the same number of tiles as MODE 1
+        const int ntile = 2 * groups_per_wg;
+        const size_t seg = ((size_t)b * gridDim.x + blockIdx.x) * 4 + wv;
+        for (int t = 0; t < ntile; ++t) tile(seg * ntile * 2048 + (size_t)t * 2048, t);
+    } else if (MODE == 1) {
+        const int bands = TPR / 2, band = blockIdx.x % bands, seg = blockIdx.x / bands;
+        const int g0 = seg * groups_per_wg, g1 = min(g0 + groups_per_wg, H / 4);
+        for (int g = g0; g < g1; ++g) { tile(tile_off(b, 4 * g + wv, 2 * band), 0); tile(tile_off(b, 4 * g + wv, 2 * band + 1), 1); }
+    } else {
+        constexpr int TW = MODE == 2 ? 5 : 20;       // tiles per wave and row group (both divide the 20 tiles of a row)
+        const int cols = TPR / TW, col = blockIdx.x % cols, seg = blockIdx.x / cols;
+        const int gpw = groups_per_wg * 2 / TW > 0 ? groups_per_wg * 2 / TW : 1;       // the same tiles per workgroup
+        const int g0 = seg * gpw, g1 = min(g0 + gpw, H / 4);
+        for (int g = g0; g < g1; ++g)
+            for (int t = 0; t < TW; ++t) tile(tile_off(b, 4 * g + wv, TW * col + t), t);
+    }
+}
+
+template <int MODE>
+double run(float* out, float* in, int B, int gpw, hipEvent_t e0, hipEvent_t e1)
+{
+    int gx;
+    if (MODE <= 1) gx = (TPR / 2) * ((H / 4 + gpw - 1) / gpw);
+    else { const int TW = MODE == 2 ? 5 : 20; const int g = gpw * 2 / TW > 0 ? gpw * 2 / TW : 1; gx = (TPR / TW) * ((H / 4 + g - 1) / g); }
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k<MODE>, dim3(gx, B), dim3(256), 0, 0, out, in, B, gpw);
+    CK(hipEventRecord(e0));
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k<MODE>, dim3(gx, B), dim3(256), 0, 0, out, in, B, gpw);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main()
+{
+    const int B = 512;
+    const size_t nout = (size_t)B * H * W * 64;
+    float *out, *in;
+    CK(hipMalloc(&out, nout * 4 + (64 << 20))); CK(hipMalloc(&in, (size_t)B * 4096 * 4096 * 4 / 8));
+    CK(hipMemset(in, 0, (size_t)B * 4096 * 4096 * 4 / 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const double gb = nout * 4 / 1e9 * (1.0 + 1.0 / 8.0);
+    printf("# 512 images of 480 x 640 x 64 fp32 = %.1f GB of stores + 1/8 of loads per launch; whole-pixel non-temporal stores, 3 workgroups per CU\n", nout * 4 / 1e9);
+    for (int gpw : {30, 15, 60}) {
+        const double t0 = run<0>(out, in, B, gpw, e0, e1), t1 = run<1>(out, in, B, gpw, e0, e1), t2 = run<2>(out, in, B, gpw, e0, e1), t3 = run<3>(out, in, B, gpw, e0, e1);
+        printf("row groups per workgroup %3d: contiguous per wave %.3f ms (%.2f TB/s) | head's band walk %.3f ms (%.2f TB/s) | 4 rows x 160 px %.3f ms (%.2f TB/s) | 4 whole rows %.3f ms (%.2f TB/s)\n",
+               gpw, t0, gb / t0, t1, gb / t1, t2, gb / t2, t3, gb / t3);
+    }
+    return 0;
+}
