@@ -6,7 +6,9 @@
 //   MODE 1  the head's walk: band of 64 pixels, waves = rows y .. y + 3, groups down the image
 //   MODE 2  row walk: a workgroup takes 4 rows x 160 pixels (each wave 5 tiles = 40 KB contiguous), then the next 4 rows of the same 160 columns
 //   MODE 3  row walk, whole rows: a workgroup takes 4 rows x 640 pixels (each wave 20 tiles = 160 KB contiguous)
-// every mode: whole-pixel non-temporal stores (one 256-byte pixel per instruction) + one 1 KB load per tile, 512 images of 480 x 640.
+// every mode: whole-pixel non-temporal stores (one 256-byte pixel per instruction) + one 1 KB load per tile (cache-resident: the rates are
+// STORE rates), 512 images of 480 x 640.  r05 result: every order gives 5.2-5.5 TB/s -- the band walk costs nothing, and 40.9 GB of stores
+// cannot leave faster than ~7.5 ms: with its 7.7 GB of reads the head (9.3 ms) is at what the memory system takes.
 //   hipcc -O3 --offload-arch=gfx950 -o head_walk head_walk.hip && ./head_walk
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -77,8 +79,8 @@ int main()
     CK(hipMalloc(&out, nout * 4 + (64 << 20))); CK(hipMalloc(&in, (size_t)B * 4096 * 4096 * 4 / 8));
     CK(hipMemset(in, 0, (size_t)B * 4096 * 4096 * 4 / 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const double gb = nout * 4 / 1e9 * (1.0 + 1.0 / 8.0);
-    printf("# 512 images of 480 x 640 x 64 fp32 = %.1f GB of stores + 1/8 of loads per launch; whole-pixel non-temporal stores, 3 workgroups per CU\n", nout * 4 / 1e9);
+    const double gb = nout * 4 / 1e9;       // the 1 KB loads per tile re-read a 16 KB window per workgroup: cache hits, not HBM traffic
+    printf("# 512 images of 480 x 640 x 64 fp32 = %.1f GB of stores per launch (rates count the stores only: the loads hit the cache); whole-pixel non-temporal stores, 3 workgroups per CU\n", nout * 4 / 1e9);
     for (int gpw : {30, 15, 60}) {
         const double t0 = run<0>(out, in, B, gpw, e0, e1), t1 = run<1>(out, in, B, gpw, e0, e1), t2 = run<2>(out, in, B, gpw, e0, e1), t3 = run<3>(out, in, B, gpw, e0, e1);
         printf("row groups per workgroup %3d: contiguous per wave %.3f ms (%.2f TB/s) | head's band walk %.3f ms (%.2f TB/s) | 4 rows x 160 px %.3f ms (%.2f TB/s) | 4 whole rows %.3f ms (%.2f TB/s)\n",
