@@ -20,4 +20,6 @@ python3 bench.py --sparse --no-cpu-baseline --no-variants > gpurun_out/$R/bench_
 python3 bench.py --spawn --no-cpu-baseline --no-variants > gpurun_out/$R/bench_spawn_w1.json 2> gpurun_out/$R/bench_spawn_w1.err || echo "spawn run failed"
 # the path main.py + install() really takes: one pair at a time through the drop-ins
 python3 scripts/single_pair_latency.py > gpurun_out/$R/single_pair_latency.txt 2>&1 || echo "latency script failed"
+python3 scripts/single_pair_kernels.py >> gpurun_out/$R/single_pair_latency.txt 2>&1 || echo "per-kernel latency script failed"
+python3 scripts/isa_lint.py > gpurun_out/$R/isa_lint.txt 2>&1 || echo "ISA LINT FAILED"
 cat gpurun_out/$R/bench_default.json

@@ -26,7 +26,18 @@ for net in ("superpoint", "disk_lightglue", "xfeat"):
         shutil.copy(os.path.join(d, "summary.txt"), os.path.join(dst, "%s_pmc_per_kernel_%s.csv" % (R, net)))
         if os.path.exists(os.path.join(d, "traffic.json")):
             shutil.copy(os.path.join(d, "traffic.json"), os.path.join(dst, "%s_pmc_traffic_%s.json" % (R, net)))
-for f in glob.glob(os.path.join(src, R, "runner_rate*.json")) + glob.glob(os.path.join(src, R, "parity_sweep*.json")):
+for f in (glob.glob(os.path.join(src, R, "runner_rate*.json")) + glob.glob(os.path.join(src, R, "parity_sweep*.json")) +
+          glob.glob(os.path.join(src, R, "bench_500_steps.json")) + glob.glob(os.path.join(src, R, "rates_build.txt"))):
     if os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (R, os.path.basename(f))))
+# which library every bench line of the round came from (config.build of bench.py's JSON line): one build, or the README must say so
+libs = {}
+for f in sorted(glob.glob(os.path.join(dst, "%s_bench_*.json" % R))):
+    try:
+        j = json.loads(open(f).read().strip().splitlines()[-1])
+        libs[os.path.basename(f)] = (j.get("config", {}).get("build") or {}).get("lib_sha256")
+    except Exception:
+        libs[os.path.basename(f)] = None
+json.dump(libs, open(os.path.join(dst, "%s_builds.json" % R), "w"), indent=1)
+print("libraries:", sorted(set(v for v in libs.values() if v)))
 print("published", R, "value", b["value"], "roofline", {k: b["roofline"][k] for k in ("kernel", "frac", "avg_ms", "traffic")})
