@@ -369,24 +369,29 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
             }
         }
         if constexpr (PRE) {
-            // the tile as DENSE 128-byte pixels t = y IW + x, slot s of pixel t at 16-byte position s ^ (t & 7): the sixteen lanes of a
-            // fragment read touch sixteen consecutive pixels at one slot -- eight distinct positions per eight lanes.  A DMA unit = one
-            // wave instruction = 8 pixels x 8 slots = 1 KB; lane i lands at position i & 7 of pixel 8 u + (i >> 3), so the slot it has to
-            // fetch, (i & 7) ^ (i >> 3), is a constant of the lane.
+            // the tile as DENSE 128-byte pixels t = y IW + x, slot s of pixel t at 16-byte position s ^ ((x >> 1) & 7).  ds_read_b128
+            // banks are (a / 4) mod 64 -- a 256-byte row = TWO pixels -- and are arbitrated in the 16-lane groups {0-3, 12-15, 20-27},
+            // {4-11, 16-19, 28-31} (+32): in a fragment read each group holds the sixteen output columns once (eight of one tile row, eight
+            // of the next), i.e. sixteen consecutive x.  IW is even, so x & 1 picks the half of the bank row and (x >> 1) & 7 is distinct
+            // over the eight x of either parity: sixteen lanes, sixteen positions.  (The first form keyed on t & 7 for a 128-byte bank
+            // row: every position used twice, SQ_LDS_BANK_CONFLICT 50 % -- profiles/r05_pmc_per_kernel_superpoint.csv.)  A DMA unit = one
+            // wave instruction = 8 pixels x 8 slots = 1 KB; lane i lands at position i & 7 of pixel 8 u + (i >> 3) and fetches the slot
+            // that belongs there.
+            static_assert(IW % 2 == 0, "conv_mfma_h<PRE>: the swizzle key assumes pixel parity = column parity");
             constexpr int NPIX = IH * IW, NU = (NPIX + 7) / 8;
             static_assert(NU * 1024 <= IH * ROWP, "conv_mfma_h<PRE>: the dense tile must fit the padded one's LDS");
             if (ch == 0) e_cur = cm_exp_of(fmaf(__uint_as_float(a.pre_amax[b]), a.pre_l1, a.pre_bmax));
             __syncthreads();                    // the previous slab's taps are done with the tile
-            const int myslot = (lane & 7) ^ ((lane >> 3) & 7);
-            const unsigned char* src0 = reinterpret_cast<const unsigned char*>(in) + (size_t)ch * 128 + myslot * 16;
-            const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.pre_zero) + myslot * 16;
+            const unsigned char* src0 = reinterpret_cast<const unsigned char*>(in) + (size_t)ch * 128;
+            const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.pre_zero) + (lane & 7) * 16;
 #pragma unroll 2
             for (int u = wv; u < NU; u += 4) {
                 const int t = 8 * u + (lane >> 3);
                 const int y = t / IW, x = t - y * IW;
                 const int gy = iy0 + y, gx = ix0 + x;
                 const bool ok = t < NPIX && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc;
-                const unsigned char* src = ok ? src0 + ((size_t)gy * a.Wi + gx) * (size_t)(a.istride * 4) : zsrc;
+                const int slot = (lane & 7) ^ ((x >> 1) & 7);
+                const unsigned char* src = ok ? src0 + ((size_t)gy * a.Wi + gx) * (size_t)(a.istride * 4) + slot * 16 : zsrc;
                 cm_dma16(src, tile + u * 1024);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
             for (int m = 0; m < MT; ++m) {
                 const int orow = 2 * (wv * MT + m) + (p >> 4);
                 if constexpr (PRE) {
-                    const int t = (orow + ky) * IW + ocol + kx, key = t & 7;
+                    const int t = (orow + ky) * IW + ocol + kx, key = ((ocol + kx) >> 1) & 7;
                     const unsigned char* ap = &tile[t * 128];
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb) {

@@ -236,6 +236,15 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     // confirmed maxima are never re-derived, a tile only has to clear what they still cover
     __shared__ __attribute__((aligned(16))) float t[ROWS * PITCH];
     __shared__ __attribute__((aligned(16))) float e[ROWS * EP];      // row maxima over [x-R, x+R]
+    // row candidates (r05): bit i of hm[strip][row] = pixel 8 strip + i + R of the row is alive, equals its row maximum and is greater
+    // than the R cells to its left -- everything the maximum test needs to know about the pixel's own row, decided by the horizontal
+    // pass while the row is in its registers.  Bytes, [strip][row + HOFF] so that the rows of one vertical strip are whole words.
+    constexpr int HOFF = (4 - R % 4) % 4;
+    constexpr bool HALIGNED = VS % 4 == 0;                               // every strip starts on a word: (R + HOFF + VS s) % 4 == 0
+    constexpr int HNW = HALIGNED ? VS / 4 : (VS + 6) / 4;                // words one vertical strip reads
+    constexpr int HMR = (R + VS * NVS + HOFF + 8 + 3) / 4 * 4;           // bytes per strip column, incl. what the last strip's words overhang
+    static_assert(HMR >= LH + HOFF, "row-candidate plane too short");
+    __shared__ unsigned hm[NHS * HMR / 4];
     __shared__ int maxlist[MAXLIST];
     __shared__ int s_n[2], s_changed, s_over;
     constexpr int CLOCAL = 256;
@@ -382,34 +391,49 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
         for (int i = tid; i < LH * NHS; i += NMS_THREADS) {
             const int y = i / NHS, s8 = i - y * NHS;
             const float* row = t + y * PITCH + 8 * s8;
-            float v[HQ * 4];
+            float raw[HQ * 4], v[HQ * 4];
 #pragma unroll
             for (int q = 0; q < HQ; ++q) {      // |t|: a confirmed maximum (stored negated) still outranks everything near it
                 const float4 f = *reinterpret_cast<const float4*>(row + 4 * q);
+                raw[4 * q] = f.x; raw[4 * q + 1] = f.y; raw[4 * q + 2] = f.z; raw[4 * q + 3] = f.w;
                 v[4 * q] = fabsf(f.x); v[4 * q + 1] = fabsf(f.y); v[4 * q + 2] = fabsf(f.z); v[4 * q + 3] = fabsf(f.w);
             }
-            float o[8];
+            float o[8], wl[8];
             window_max<KS, 8, HQ * 4>(v, o);
+            window_max<R, 8, HQ * 4>(v, wl);     // wl[i] = max |t| over the R cells left of pixel i + R (shares its triples with o)
             float* er = e + y * EP + 8 * s8;
             *reinterpret_cast<float4*>(er) = make_float4(o[0], o[1], o[2], o[3]);
             *reinterpret_cast<float4*>(er + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            // c > wl >= 0 makes c alive (positive, not a confirmed maximum); c == o: nothing in the row window exceeds it; the strict
+            // test on the left is argmax's first-index rule (extracter.py:69-70)
+            unsigned m = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m |= (raw[k + R] > wl[k] && raw[k + R] == o[k]) ? 1u << k : 0u;
+            reinterpret_cast<unsigned char*>(hm)[s8 * HMR + y + HOFF] = (unsigned char)m;
         }
         __syncthreads();
-        // vertical pass on VS-row strips: a pixel is a maximum iff it is alive, equals its row maximum,
-        // is > every row maximum above and >= every one below (argmax = first index, extracter.py:69-70),
-        // and is > the R cells to its left.
+        // vertical pass on VS-row strips: a pixel is a maximum iff it is a row candidate (alive, equal to its row maximum, greater than
+        // the R cells to its left: hm), > every row maximum above and >= every one below (argmax = first index, extracter.py:69-70).
+        // r05: the row half of the test used to be made here, per pixel behind five-way branches (a candidate's R left neighbours
+        // read one by one): 700 instructions per strip, the largest phase of the sweep; now ~150, branch-free.
         for (int i0 = 0; i0 < NVS * IW; i0 += NMS_THREADS) {
             const int i = i0 + tid;
             const bool in_range = i < NVS * IW;
             const int s8 = in_range ? i / IW : 0, x = in_range ? i - s8 * IW + R : R;
             const int y0 = R + VS * s8;
-            float tv[VS];
-            bool any_alive = false;
+            unsigned rh = 0;
+            {
+                const int xe = x - R, hb = (xe >> 3) * HMR + y0 + HOFF;        // byte of row y0 in the strip column of pixel x
+                const unsigned* hw = hm + (hb >> 2);
 #pragma unroll
-            for (int k = 0; k < VS; ++k) { tv[k] = t[(y0 + k) * PITCH + x]; any_alive |= tv[k] > 0.0f; }
-            any_alive &= in_range;
+                for (int w = 0; w < HNW; ++w) rh |= ((((hw[w] >> (xe & 7)) & 0x01010101u) * 0x01020408u) >> 24) << (4 * w);
+                if (!HALIGNED) rh >>= hb & 3;
+                const int kmax = LH - R - y0;                                   // rows y0 + k < LH - R only
+                rh &= kmax >= VS ? (1u << VS) - 1u : (kmax > 0 ? (1u << kmax) - 1u : 0u);
+                if (!in_range) rh = 0;
+            }
             unsigned hits = 0;
-            if (any_alive) {
+            if (rh) {
                 float col[VS + 2 * R];
 #pragma unroll
                 for (int k = 0; k < VS + 2 * R; ++k) col[k] = e[(y0 - R + k) * EP + x - R];
@@ -417,14 +441,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
                 window_max<R, VS + R + 1, VS + 2 * R>(col, wr);    // wr[j] = max col[j .. j+R-1]
 #pragma unroll
                 for (int k = 0; k < VS; ++k) {
-                    const int y = y0 + k;
-                    const float v = tv[k];
-                    if (y < LH - R && v > 0.0f && v == col[k + R] && v > wr[k] && v >= wr[k + R + 1]) {
-                        bool ok = true;
-#pragma unroll
-                        for (int d = 1; d <= R; ++d) ok = ok && (v > fabsf(t[y * PITCH + x - d]));
-                        if (ok) hits |= 1u << k;
-                    }
+                    const float v = col[k + R];                      // a row candidate IS its row maximum
+                    hits |= (((rh >> k) & 1u) && v > wr[k] && v >= wr[k + R + 1]) ? 1u << k : 0u;
                 }
             }
             append_mask(hits, y0 * PITCH + x, PITCH, par);
