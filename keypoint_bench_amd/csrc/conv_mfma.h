@@ -315,11 +315,16 @@ constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
 // slab are requested before the slab's input is even loaded and land while it is staged: one round trip per slab instead of ten.
 // Costs T x 4 NTB NKB registers (144 for a 3 x 3 kernel, one n-tile), irrelevant at one wave per SIMD; the arithmetic and its order
 // are those of the throughput form.
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false>
+// WN (r05): the four waves as 4 / WN row groups x WN column groups.  WN = 1: every wave multiplies its MT row tiles by ALL NTB n-tiles of the
+// workgroup -- the four waves request the same weight fragments, 4 x the bytes through the CU's vector L1 (64 B/clk), and a knock-out
+// put 18 % of SuperPoint's conv1b there (profiles/r05_presplit_conv1b_ab.txt).  WN = 2: a wave takes twice the rows and half the
+// n-tiles: the same 64 accumulator registers and products, half the weight bytes, twice the activation reads -- which come from LDS.
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false, int WN = 1>
 __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
+    static_assert(WN == 1 || (WN == 2 && MT % 2 == 0 && !WPRE), "conv_mfma_h: waves split the n-tiles two ways at most");
     static_assert(!PRE || (CC == 32 && S == 1 && !POOL_IN && !XF && !XC && !WPRE), "conv_mfma_h: the pre-split input form exists for plain stride-1 32-channel slabs");
-    constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT;
+    constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT / WN;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
     constexpr int PITCH = 4 * CC + 16, LO = 2 * CC;                 // bytes per pixel, offset of its lo halves
     constexpr int ROWP = (IW * PITCH + 255) / 256 * 256;            // bytes per tile row
@@ -327,7 +332,8 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
     static_assert(IH * ROWP <= 65536, "conv_mfma_h: input tile exceeds the static LDS window");
     __shared__ __attribute__((aligned(256))) unsigned char tile[IH * ROWP];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, p = lane & 31, h = lane >> 5;
-    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = nb * NTB;
+    const int wm = wv / WN;                  // this wave's row group; its n-tiles start at nt0
+    const int b = blockIdx.z / a.nblk, nb = blockIdx.z - b * a.nblk, nt0 = (nb * WN + wv % WN) * NTB;
     const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * 16;
     const int Hc = POOL_IN ? a.Hi / PF : a.Hi, Wc = POOL_IN ? a.Wi / PF : a.Wi;
     const int iy0 = ty0 * S - PAD, ix0 = tx0 * S - PAD;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
     const uint4* wq = reinterpret_cast<const uint4*>(a.wp);      // [ntile][tap][chunk][kb][hi/lo][h][32] x 8 halves
     const size_t ntile_stride = (size_t)T * a.NCH * NKB * 4 * 32;
 
-    static_assert(!XC || (MT == 2 && S == 1 && !POOL_OUT), "conv_mfma_h: the extra channel maps one pixel of a 16x16 tile to each thread");
+    static_assert(!XC || (TH == 16 && S == 1 && !POOL_OUT), "conv_mfma_h: the extra channel maps one pixel of a 16x16 tile to each thread");
     __shared__ __attribute__((aligned(16))) float s_amax[4];       // the four waves' largest staged magnitude of the slab in flight
     float xacc = 0.0f;
     int e_cur = 24;              // exponent the accumulators' activation scale belongs to (workgroup-uniform)
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                 cm_h8 Ah[MT][NKB], Al[MT][NKB];
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    const int orow = 2 * (wv * MT + m) + (p >> 4);
+                    const int orow = 2 * (wm * MT + m) + (p >> 4);
                     const unsigned char* ap = &tile[(orow * S + ky) * ROWP + (ocol * S + kx) * PITCH + h * KC * 2];
 #pragma unroll
                     for (int kb = 0; kb < NKB; ++kb) {
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                 }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                const int orow = 2 * (wv * MT + m) + (p >> 4);
+                const int orow = 2 * (wm * MT + m) + (p >> 4);
                 if constexpr (PRE) {
                     const int t = (orow + ky) * IW + ocol + kx, key = ((ocol + kx) >> 1) & 7;
                     const unsigned char* ap = &tile[t * 128];
@@ -565,7 +571,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
     // epilogue: as conv_mfma, per M tile; the accumulator carries the layer's weight scale x the activation scale of e_cur
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int trow = 2 * (wv * MT + m);          // first of the tile's two output rows inside the workgroup tile
+        const int trow = 2 * (wm * MT + m);          // first of the tile's two output rows inside the workgroup tile
 #pragma unroll
         for (int n = 0; n < NTB; ++n) {
             const int co = (nt0 + n) * 32 + p;

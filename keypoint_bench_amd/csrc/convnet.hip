@@ -729,7 +729,8 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
     hipStream_t st = ctx->stream;
     const bool x = xf != nullptr;
     const dim3 block(256);
-    if (conv_mfma_use_h16()) {     // split-f16 form: stride-1 layers take two M tiles per wave (16-row workgroup tiles)
+    if (conv_mfma_use_h16()) {     // split-f16 form: stride-1 layers on 16-row workgroup tiles; with two n-tiles per workgroup the waves
+                                   // form 2 row groups x 2 n-tiles (conv_mfma_h<.., WN = 2>: four M tiles and one n-tile per wave)
         a.unscale = 1.0f / (net->wscale.at(L.name + ".w"));
         const dim3 g2(cdiv(a.W, 16), cdiv(a.H, 16), B * a.nblk), g1(cdiv(a.W, 16), cdiv(a.H, 8), B * a.nblk);
         // one-tile layers (cout <= 32) are bound by per-workgroup latency: 8-row tiles (one M tile per wave, 28 KB of LDS, five
@@ -737,14 +738,22 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         if (pre) {      // the input arrives already split (ConvM::pre_amax): raw bytes land in the tile by LDS-DMA
             a.pre_amax = pre->amax; a.pre_l1 = pre->l1; a.pre_bmax = pre->bmax; a.pre_zero = pre->zero;
             if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2)
-                KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2, false, 2, false, true>), g2, block, 0, st, a);
+                KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, true, 2>), g2, block, 0, st, a);
             else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no pre-split instance for %s", L.name.c_str());
             return KPB_OK;
         }
         if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), g1, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 2, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
+        else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) {
+            // 129 = 4 x 32 + 1 (DISK up_3): four MFMA tiles (two workgroups of two: 64 accumulator registers, three waves per SIMD)
+            // and the score channel on the VALU of the first workgroup
+            a.nblk = 2; a.xw = net->wp((L.name + ".xw").c_str()); a.xb = net->wscale.at(L.name + ".xb"); a.xco = L.cout - 1;
+            KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 1, 4, true, 2, false, false, 2>), dim3(cdiv(a.W, 16), cdiv(a.H, 16), B * 2), block, 0, st, a);
+        }
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && l2_eps > 0.0f) {
             if (L.cout != 64 || L.ntb != 2) return kpb_fail(ctx, KPB_E_INVALID, "launch_mfma: the fused L2 norm needs a 64-channel layer");
             a.xb = l2_eps;
@@ -753,14 +762,6 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && unfold_w) KPB_LAUNCH(ctx, name, (gemm_h<2, 1, GE_PLAIN, true>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2, 1>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
-        else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 2, 2>), g2, block, 0, st, a);
-        else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) {
-            // 129 = 4 x 32 + 1 (DISK up_3): four MFMA tiles (two workgroups of two: 64 accumulator registers, three waves per SIMD,
-            // weight fragments reused by two M tiles) and the score channel on the VALU of the first workgroup
-            a.nblk = 2; a.xw = net->wp((L.name + ".xw").c_str()); a.xb = net->wscale.at(L.name + ".xb"); a.xco = L.cout - 1;
-            KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 2, 2, true>), dim3(cdiv(a.W, 16), cdiv(a.H, 16), B * 2), block, 0, st, a);
-        }
         else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no instance for ks=%d stride=%d cc=%d pool_in=%d pool_out=%d xf=%d", L.ks, S, CC, pool_in, pool_out, x);
         return KPB_OK;
     }
