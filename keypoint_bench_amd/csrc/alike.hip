@@ -1902,7 +1902,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
             // small layers are bound by per-workgroup latency: 8-row tiles (r02: b3c1 0.36 -> 0.32 ms, b3c2 0.58 -> 0.49 ms)
             if (prepooled && batch < 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1, false, 2, true>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
-            else if (prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+            else if (prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 1, 2, false, 2, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
             else if (batch >= 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 1, 4, false, 4, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk), dim3(256), 0, st, m);
             else {      // a handful of images (the drop-in path runs ONE): a 15 x 20 map in 16 x 16 tiles with two n-tiles each is 4 workgroups of
                         // pure latency (41 us); 8-row tiles with one n-tile each are 16 (same weights, same arithmetic per output)

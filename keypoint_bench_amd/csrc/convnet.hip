@@ -761,7 +761,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         }
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && unfold_w) KPB_LAUNCH(ctx, name, (gemm_h<2, 1, GE_PLAIN, true>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (gemm_h<2, 1>), dim3(cdiv(a.H * a.W, 128), 1, B * a.nblk), block, 0, st, a);
-        else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 2, 1>), g1, block, 0, st, a);
+        else if (L.ks == 3 && S == 2 && CC == 16 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 2, 16, false, false, false, 1, 2, false, 2, false, false, 2>), g1, block, 0, st, a);
         else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no instance for ks=%d stride=%d cc=%d pool_in=%d pool_out=%d xf=%d", L.ks, S, CC, pool_in, pool_out, x);
         return KPB_OK;
     }
