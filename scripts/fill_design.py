@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Fills the @@NAME@@ fields of a DESIGN.md template from the round's published evidence: scripts/fill_design.py TEMPLATE ROUND > DESIGN.md
+
+The prose of DESIGN.md is written by hand; the figures that belong to the evidence build come from profiles/<ROUND>_*.json so that the document
+and the records cannot disagree (figures of three builds side by side)."""
+import json
+import re
+import sys
+
+
+def line(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def main():
+    tmpl, rnd = sys.argv[1], sys.argv[2]
+    P = "profiles/%s_" % rnd
+    d = line(P + "bench_default.json")
+    k = d["roofline"]["kernels_ms_per_step"]
+    f = {}
+    f["VALUE"] = "{:,.0f}".format(d["value"]).replace(",", " ")
+    f["MS"] = "%.2f" % d["ms_per_step"]
+    f["SUST"] = "{:,.0f}".format(d["value_sustained"]).replace(",", " ")
+    f["SPARSE"] = "{:,.0f}".format(d["variant"]["value"]).replace(",", " ")
+    f["FP32"] = "{:,.0f}".format(d["variant_fp32"]["value"]).replace(",", " ")
+    f["CPU"] = "%.1f" % d["cpu_baseline"]["value"]
+    f["HEAD"] = "%.2f" % k["alike_head_dense"]
+    f["HEADFRAC"] = "%.2f" % d["roofline"]["frac"]
+    f["HEADGBS"] = "{:,.0f}".format(d["roofline"]["achieved"]).replace(",", " ")
+    f["B1"] = "%.2f" % k["alike_block1"]
+    f["B2"] = "%.2f" % k["alike_block2"]
+    f["NMS"] = "%.2f" % k["nms_sweep"]
+    for a, b in (("B3C1", "conv3x3_b3c1"), ("B3C2", "conv3x3_b3c2"), ("B4C1", "conv3x3_b4c1"), ("B4C2", "conv3x3_b4c2")):
+        f[a] = "%.2f" % k[b]
+    f["V500"] = "{:,.0f}".format(line(P + "bench_500_steps.json")["value"]).replace(",", " ")
+    f["SPAWN"] = "{:,.0f}".format(line(P + "bench_spawn_w1.json")["value"]).replace(",", " ")
+    sp = line(P + "bench_superpoint_brute_force.json")
+    f["SP"] = "{:,.0f}".format(sp["value"]).replace(",", " ")
+    f["CONV1B"] = "%.2f" % sp["roofline"]["kernels_ms_per_step"]["sp_conv1b"]
+    f["CONV1BFRAC"] = "%.2f" % sp["roofline"]["frac"]
+    dk = line(P + "bench_disk_brute_force.json")
+    f["DISK"] = "{:,.0f}".format(dk["value"]).replace(",", " ")
+    f["UP3"] = "%.1f" % dk["roofline"]["kernels_ms_per_step"]["disk_up3"]
+    f["UP3FRAC"] = "%.2f" % dk["roofline"]["frac"]
+    f["XF"] = "{:,.0f}".format(line(P + "bench_xfeat_brute_force.json")["value"]).replace(",", " ")
+    f["SPLG"] = "{:,.0f}".format(line(P + "bench_superpoint_lightglue.json")["value"]).replace(",", " ")
+    f["SPLGF16"] = "{:,.0f}".format(line(P + "bench_superpoint_lightglue_f16attn.json")["value"]).replace(",", " ")
+    f["DISKLG"] = "{:,.0f}".format(line(P + "bench_disk_lightglue.json")["value"]).replace(",", " ")
+    f["DISKLGF16"] = "{:,.0f}".format(line(P + "bench_disk_lightglue_f16attn.json")["value"]).replace(",", " ")
+    m = re.search(r"^dense ([0-9.]+) ms/pair", open(P + "single_pair_latency.txt").read(), re.M)
+    f["SINGLE"] = m.group(1) if m else "?"
+    text = open(tmpl).read()
+    missing = set(re.findall(r"@@([A-Z0-9]+)@@", text)) - set(f)
+    if missing:
+        raise SystemExit("no value for " + ", ".join(sorted(missing)))
+    sys.stdout.write(re.sub(r"@@([A-Z0-9]+)@@", lambda mm: f[mm.group(1)], text))
+
+
+if __name__ == "__main__":
+    main()
