@@ -278,26 +278,32 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     int neg = 0;
     // zero padding outside the image (extracter.py:54-60) and in the pad rows/columns
     if ((R % 2 == 0) && (a.W % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0)) {
-        // gx0 is a multiple of 4: whole float4s are inside or outside the image; all loads of a thread in flight
+        // gx0 is a multiple of 4: whole float4s are inside or outside the image.  All loads of a thread go out before the first is used,
+        // without a branch: a float4 outside the image is fetched from the image's first bytes and replaced by zeros (r05: the nine
+        // exec-masked blocks and 64-bit address chains of the branchy form were a fifth of the sweep's instructions).  The image base is
+        // wave-uniform, the offset 32 bits (an image has < 2^30 pixels: nms_open checks).
         constexpr int Q = PITCH / 4, NQ = ROWS * Q, PER = (NQ + NMS_THREADS - 1) / NMS_THREADS;
         float4 buf[PER];
+        bool okk[PER];
+        const unsigned char* inb = reinterpret_cast<const unsigned char*>(in);
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * NMS_THREADS;
             const int ly = i / Q, lx = (i - ly * Q) * 4;
             const int gy = gy0 + ly, gx = gx0 + lx;
-            buf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < NQ && ly < LH && lx < LW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                buf[k] = *reinterpret_cast<const float4*>(in + (size_t)gy * a.W + gx);
+            okk[k] = i < NQ && ly < LH && lx < LW && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+            const unsigned off = okk[k] ? ((unsigned)gy * (unsigned)a.W + (unsigned)gx) * 4u : 0u;
+            buf[k] = *reinterpret_cast<const float4*>(inb + off);
         }
+        float mn = 0.0f;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int i = tid + k * NMS_THREADS;
-            if (i < NQ) {
-                neg |= (buf[k].x < 0.0f) | (buf[k].y < 0.0f) | (buf[k].z < 0.0f) | (buf[k].w < 0.0f);
-                *reinterpret_cast<float4*>(t + 4 * i) = buf[k];
-            }
+            if (!okk[k]) buf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            mn = fminf(fminf(mn, fminf(buf[k].x, buf[k].y)), fminf(buf[k].z, buf[k].w));
+            if (i < NQ) *reinterpret_cast<float4*>(t + 4 * i) = buf[k];
         }
+        neg = mn < 0.0f;
     } else {
 #pragma unroll 8
         for (int i = tid; i < ROWS * PITCH; i += NMS_THREADS) {
@@ -1100,6 +1106,8 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
 // over, with every tile marked as changed).  Returns the number of sweeps the status check has to account for.
 int nms_open(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int batch, int H, int W, int r, int chunk, int& sweeps_run)
 {
+    if ((size_t)H * W >= ((size_t)1 << 30))       // nms_sweep_r addresses a pixel by a 32-bit BYTE offset from its image
+        return kpb_fail(ctx, KPB_E_UNSUPPORTED, "NMS: a %d x %d map is too large (2^30 pixels per image at most)", H, W);
     KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 4 * (size_t)batch * sizeof(int), ctx->stream));
     if (!p.ulist) {
         sweeps_run = chunk;
