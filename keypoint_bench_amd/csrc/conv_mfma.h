@@ -27,7 +27,9 @@ struct ConvM {
     float unscale = 1.0f;         // conv_mfma_h / gemm_h: 1 / (the layer's power-of-two weight scale)
     int relu_nt = 0;              // conv_mfma_h with relu == 2: only the first relu_nt 32-wide output tiles get the ReLU
     int rstride = 0;              // floats between consecutive pixels of `res` (0: COUT)
-    const float* xw = nullptr;    // conv_mfma_h<XC>: [tap][CIN] fp32 weights of ONE extra output channel (index xco) taken on the VALU
+    const float* xw = nullptr;    // conv_mfma_h<XC>: weights of ONE extra output channel (index xco) taken on the VALU: [tap][CIN / 2] x (hi pair, lo pair) of
+                                  // halves (pack_xc_pairs), scaled by 1 / xun
+    float xun = 1.0f;
     float xb = 0.0f;              // its bias
     int xco = 0;
     // gemm_h only (the LightGlue linears): rows >= rowcnt[b] are staged as zeros and never written -- what a padded row holds cannot
@@ -546,13 +548,22 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                     }
             if (XC && nb == 0) {       // the extra channel at pixel (tid / 16, tid % 16): hi + lo restores the staged activation, weights are wave-uniform
                 const unsigned char* xp = &tile[((tid >> 4) + ky) * ROWP + ((tid & 15) + kx) * PITCH];
-                const float* xw = a.xw + (size_t)tap * a.CIN + ch * CC;
+                // r05: as the matrix pipe takes its products -- x w = x_lo w_hi + x_hi w_lo + x_hi w_hi on halves, fp32 sums -- two channels per
+                // v_dot2c_f32_f16 with the weight pair in a scalar register: 1.5 instructions per product (it was two conversions, an add and
+                // an fma against fp32 weights: 7 % of DISK's up_3 in a knock-out)
+                typedef _Float16 cm_h2 __attribute__((ext_vector_type(2)));
+                const uint2* xwq = reinterpret_cast<const uint2*>(a.xw) + (((size_t)tap * a.CIN + ch * CC) >> 1);
 #pragma unroll
                 for (int q = 0; q < CC / 8; ++q) {
-                    const cm_h8 vh = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + 16 * q));
-                    const cm_h8 vl = __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(xp + LO + 16 * q));
+                    const uint4 vh = *reinterpret_cast<const uint4*>(xp + 16 * q), vl = *reinterpret_cast<const uint4*>(xp + LO + 16 * q);
+                    const unsigned hh[4] = {vh.x, vh.y, vh.z, vh.w}, ll[4] = {vl.x, vl.y, vl.z, vl.w};
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) xpart = fmaf((float)vh[e] + (float)vl[e], xw[8 * q + e], xpart);
+                    for (int j = 0; j < 4; ++j) {
+                        const uint2 w = xwq[4 * q + j];
+                        xpart = __builtin_amdgcn_fdot2(__builtin_bit_cast(cm_h2, ll[j]), __builtin_bit_cast(cm_h2, w.x), xpart, false);
+                        xpart = __builtin_amdgcn_fdot2(__builtin_bit_cast(cm_h2, hh[j]), __builtin_bit_cast(cm_h2, w.y), xpart, false);
+                        xpart = __builtin_amdgcn_fdot2(__builtin_bit_cast(cm_h2, hh[j]), __builtin_bit_cast(cm_h2, w.x), xpart, false);
+                    }
                 }
             }
         }
@@ -561,7 +572,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
     if (XC && nb == 0) {
         const int gy = ty0 + (tid >> 4), gx = tx0 + (tid & 15);
         if (gy < a.H && gx < a.W) {
-            float o = xacc + a.xb;
+            float o = fmaf(xacc, a.xun, a.xb);
             if (a.relu) o = relu(o);
             a.out[(size_t)b * a.H * a.W * a.ostride + a.ooff + ((size_t)gy * a.W + gx) * a.ostride + a.xco] = o;
         }
@@ -892,6 +903,24 @@ std::vector<float> pack_mfma_h(const float* w, int COUT, int CIN, int KS, int CC
                                 out[((base + (0 + h) * 32 + j) * 8) + e] = hi;
                                 out[((base + (2 + h) * 32 + j) * 8) + e] = lo;
                             }
+    std::vector<float> f(out.size() / 2);
+    std::memcpy(f.data(), out.data(), out.size() * 2);
+    return f;
+}
+
+// One output channel's weights OIHW-row [CIN][KS][KS] -> [tap][CIN / 2] x (hi pair, lo pair) of halves, scaled: what conv_mfma_h<XC> multiplies
+// two channels at a time (v_dot2c_f32_f16)
+inline std::vector<float> pack_xc_pairs(const float* w1, int CIN, int T, float scale)
+{
+    std::vector<uint16_t> out((size_t)T * CIN * 2, 0);
+    for (int t = 0; t < T; ++t)
+        for (int c = 0; c < CIN; ++c) {
+            const float x = w1[(size_t)c * T + t] * scale;
+            const uint16_t hi = f16_bits_rtn(x), lo = f16_bits_rtn(x - f16_bits_to_float(hi));
+            const size_t pair = ((size_t)t * CIN + c) >> 1;
+            out[pair * 4 + (c & 1)] = hi;
+            out[pair * 4 + 2 + (c & 1)] = lo;
+        }
     std::vector<float> f(out.size() / 2);
     std::memcpy(f.data(), out.data(), out.size() * 2);
     return f;

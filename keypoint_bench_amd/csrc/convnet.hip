@@ -751,7 +751,7 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) {
             // 129 = 4 x 32 + 1 (DISK up_3): four MFMA tiles (two workgroups of two: 64 accumulator registers, three waves per SIMD)
             // and the score channel on the VALU of the first workgroup
-            a.nblk = 2; a.xw = net->wp((L.name + ".xw").c_str()); a.xb = net->wscale.at(L.name + ".xb"); a.xco = L.cout - 1;
+            a.nblk = 2; a.xw = net->wp((L.name + ".xw").c_str()); a.xb = net->wscale.at(L.name + ".xb"); a.xun = 1.0f / net->wscale.at(L.name + ".xs"); a.xco = L.cout - 1;
             KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 1, 4, true, 2, false, false, 2>), dim3(cdiv(a.W, 16), cdiv(a.H, 16), B * 2), block, 0, st, a);
         }
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && l2_eps > 0.0f) {
@@ -817,10 +817,9 @@ void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b
             const float sc = weight_scale_h(w, (size_t)co * L.cin * T);
             ws.put(L.name + ".w", pack_mfma_h(w, co, L.cin, L.ks, L.cc, 2, sc));
             ws.wscale[L.name + ".w"] = sc;
-            std::vector<float> xw((size_t)T * L.cin);
-            for (int c = 0; c < L.cin; ++c)
-                for (int t = 0; t < T; ++t) xw[(size_t)t * L.cin + c] = w[((size_t)co * L.cin + c) * T + t];
-            ws.put(L.name + ".xw", xw);
+            const float xs = weight_scale_h(w + (size_t)co * L.cin * T, (size_t)L.cin * T);
+            ws.put(L.name + ".xw", pack_xc_pairs(w + (size_t)co * L.cin * T, L.cin, T, xs));
+            ws.wscale[L.name + ".xs"] = xs;
             ws.wscale[L.name + ".xb"] = b ? b[co] : 0.0f;     // a host-side scalar, carried with the scales
         } else if (conv_mfma_use_h16()) {
             const float sc = weight_scale_h(w, (size_t)L.cout * L.cin * L.ks * L.ks);
