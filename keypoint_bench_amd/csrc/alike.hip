@@ -325,9 +325,44 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         // pair of every row goes to two extra groups (rows 0..15 and 16..17)
         const uint4* inq = reinterpret_cast<const uint4*>(inh);       // a piece = two adjacent positions = 16 bytes (even column)
         uint2* midh = reinterpret_cast<uint2*>(mid);
+        static_assert((MH + 2) % 4 == 0 && MH % 4 == 2, "alike_block1_h: waves 2 and 3 take the two extra groups");
+        // r05: the MH regular groups walk down the tile with everything that depends on the lane alone taken out of the loop -- the two piece
+        // addresses (+ IW / 2 slots per row; the empty pieces 6, 7 of lane groups 2, 3 stay on the zero piece), the slot written, the column test,
+        // and the intermediate scale folded into the unscale factor and the bias (a power of two: the same bits).  54 -> 30 vector
+        // instructions per group of six MFMAs; the general form below is kept for the two extra groups.
+        {
+            const int gxl = tx0 - 1 + 2 * pr + sN;
+            const bool xin = gxl >= 0 && gxl < a.W;
+            const float unm = xin ? un1 * sc_mid : 0.0f;               // a column outside the image: relu(0 acc + 0) = 0, conv2's zero padding
+            const float4 bm = xin ? make_float4(bias1.x * sc_mid, bias1.y * sc_mid, bias1.z * sc_mid, bias1.w * sc_mid) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool has1 = g < 2;                                   // second k-block: pieces 4, 5 = (ky 2, half g); 6, 7 are empty
+            int at0 = (wv + (g >> 1)) * (IW / 2) + pr + (g & 1);
+            int at1 = has1 ? (wv + 2) * (IW / 2) + pr + g : NIN;
+            const int st1 = has1 ? 4 * (IW / 2) : 0, lo1 = has1 ? NIN / 2 : 0;
+            int h8 = ((sN * PLANE + wv * HW + pr) << 1) + (g & 1);
 #pragma unroll 1
-        for (int gi = wv; gi < MH + 2; gi += 4) {
-            const bool extra = gi >= MH;
+            for (int y = wv; y < MH; y += 4, at0 += 4 * (IW / 2), at1 += st1, h8 += 8 * HW) {
+                f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+                const h8v i0h = __builtin_bit_cast(h8v, inq[at0]), i0l = __builtin_bit_cast(h8v, inq[at0 + NIN / 2]);
+                const h8v i1h = __builtin_bit_cast(h8v, inq[at1]), i1l = __builtin_bit_cast(h8v, inq[at1 + lo1]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1hi[0], i0l, acc, 0, 0, 0);      // small terms first
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1lo[0], i0h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1hi[0], i0h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1hi[1], i1l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1lo[1], i1h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1hi[1], i1h, acc, 0, 0, 0);
+                const bool yin = (unsigned)(ty0 - 1 + y) < (unsigned)a.H;       // wave-uniform
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yin) v = make_float4(relu(fmaf(acc[0], unm, bm.x)), relu(fmaf(acc[1], unm, bm.y)), relu(fmaf(acc[2], unm, bm.z)), relu(fmaf(acc[3], unm, bm.w)));
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                midh[h8] = hi;
+                midh[h8 + 2 * REGION] = lo;
+            }
+        }
+        if (wv >= 2) {
+            const int gi = MH + wv - 2;
+            const bool extra = true;
             const int y = extra ? 16 * (gi - MH) + pr : gi, pc = extra ? 16 : pr;
             const int my = min(y, MH - 1);
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
@@ -607,7 +642,10 @@ struct Block2Args {
 };
 
 
-__global__ __launch_bounds__(256) void alike_block2(Block2Args a)
+#ifndef B2_C1_UNROLL
+#define B2_C1_UNROLL 1
+#endif
+__global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.7 KB of LDS = four workgroups per CU: the allocator stays at 128 registers
 {
     // All three products are taken transposed (weights as the MFMA's A operand, the input pieces as B: see alike_block1_h): the
     // accumulator has the pixel on the LANE and channels 4 g .. 4 g + 3 in the registers of lane group g, so a lane owns one
@@ -680,14 +718,51 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
         float4 bias1 = b1v;
         bias1.x *= sc1; bias1.y *= sc1; bias1.z *= sc1; bias1.w *= sc1;       // conv1's output is split at the scale of its input: the scale rides on the bias
         uint2* midh = reinterpret_cast<uint2*>(mid);
-        // fixed trip count (the last round is empty for waves 2 and 3) so that two groups can be in flight per wave
-#pragma unroll 2
-        for (int it = 0; it < (2 * MH + 2 + 3) / 4; ++it) {
-            const int gi = wv + 4 * it;
-            if (gi >= 2 * MH + 2) break;
-            const bool extra = gi >= 2 * MH;
-            const int k = extra ? 16 * (gi - 2 * MH) + px : 0;
-            const int y = extra ? k >> 1 : gi >> 1, x = extra ? 32 + (k & 1) : 16 * (gi & 1) + px;
+        static_assert((2 * MH) % 4 == 0, "alike_block2: the regular conv1 groups split evenly over the four waves");
+        // r05 (as alike_block1_h): the 2 MH regular groups walk down the tile with everything that depends on the lane alone taken out of
+        // the loop -- the three piece addresses (+ 2 PW slots per step; the empty taps 9..11 of lane groups 1..3 stay on the zero slot), the
+        // slot written, the column test -- 53 -> 30 vector instructions per group of nine MFMAs; the general form is kept for the two
+        // extra groups (waves 0 and 1).
+        {
+            const int xl = 16 * (wv & 1) + px, y0 = wv >> 1;
+            const int gxl = tx0 - 1 + xl;
+            const bool xin = gxl >= 0 && gxl < a.W;
+            const float unm = xin ? un_c1s : 0.0f;                    // a column outside the image: relu(0 acc + 0) = 0, conv2's zero padding
+            const float4 bm = xin ? bias1 : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool has2 = 8 + g < 9;
+            const uint4* q0 = &pin[(y0 + g / 3) * PW + xl + g % 3];
+            const uint4* q1 = &pin[(y0 + (4 + g) / 3) * PW + xl + (4 + g) % 3];
+            const uint4* q2 = has2 ? &pin[(y0 + 2) * PW + xl + 2] : zp;
+            const int st2 = has2 ? 2 * PW : 0, lo2 = has2 ? NP : 0;
+            int h8 = (((g >> 1) * NM + y0 * MW + xl) << 1) + (g & 1);
+#pragma unroll B2_C1_UNROLL
+            for (int it = 0; it < 2 * MH / 4; ++it, q0 += 2 * PW, q1 += 2 * PW, q2 += st2, h8 += 4 * MW) {
+                f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+                const h8v i0h = __builtin_bit_cast(h8v, q0[0]), i0l = __builtin_bit_cast(h8v, q0[NP]);
+                const h8v i1h = __builtin_bit_cast(h8v, q1[0]), i1l = __builtin_bit_cast(h8v, q1[NP]);
+                const h8v i2h = __builtin_bit_cast(h8v, q2[0]), i2l = __builtin_bit_cast(h8v, q2[lo2]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[0], i0l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[0], i0h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[0], i0h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[1], i1l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[1], i1h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[1], i1h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2], i2l, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[2], i2h, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2], i2h, acc, 0, 0, 0);
+                const bool yin = (unsigned)(ty0 - 1 + y0 + 2 * it) < (unsigned)a.H;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (yin) v = make_float4(relu(fmaf(acc[0], unm, bm.x)), relu(fmaf(acc[1], unm, bm.y)), relu(fmaf(acc[2], unm, bm.z)), relu(fmaf(acc[3], unm, bm.w)));
+                uint2 hi, lo;
+                split4(v, hi, lo);
+                midh[h8] = hi;
+                midh[h8 + 4 * NM] = lo;                                                // lo half: 2 NM slots = 4 NM 8-byte units further
+            }
+        }
+        if (wv < 2) {
+            const int gi = 2 * MH + wv;
+            const int k = 16 * (gi - 2 * MH) + px;
+            const int y = k >> 1, x = 32 + (k & 1);
             const int my = min(y, MH - 1);
             f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -710,7 +785,7 @@ __global__ __launch_bounds__(256) void alike_block2(Block2Args a)
             if (y < MH) {
                 const int h8 = (((g >> 1) * NM + y * MW + x) << 1) + (g & 1);         // 8-byte half (channels 4 g ..) of (octet g / 2, position)
                 midh[h8] = hi;
-                midh[h8 + 4 * NM] = lo;                                                // lo half: 2 NM slots = 4 NM 8-byte units further
+                midh[h8 + 4 * NM] = lo;
             }
         }
     }
