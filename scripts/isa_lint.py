@@ -23,6 +23,10 @@ and the sources under csrc/ for
   E3  a vector, matrix, LDS-return or memory-return instruction inside an inline-asm string (the compiler neither pads nor counts those);
       allowed in asm here: s_waitcnt, s_nop, s_mov_b32 to / from M0, global_load_lds_dwordx4 (no register result), s_memtime (stamps build).
 
+  E4  (code-object metadata) a kernel that spills vector registers to scratch beyond the KNOWN_SPILLS list below: a spill inside a hot loop is the
+      silent way a restructuring loses (r05: a block-1 variant at 96 registers spilled 39 dwords and ran 2x slower; ADVICE r04 asked for the check).
+      Kernels with private ARRAYS but no spills (the RANSAC solvers) are not findings.
+
 Informational (no failure): MFMAs whose 16-register destination overlaps their own A / B fragment (legal: A and B are read before the
 first result is written; counted because VERDICT r04 asked), packed-fp32 instruction counts.
 Exit status 1 on any E finding.  tests/test_isa_lint.py runs it on the built library in the CPU suite.
@@ -49,6 +53,9 @@ NO_DEST = ("s_waitcnt", "s_nop", "s_barrier", "s_branch", "s_cbranch", "s_endpgm
            "flat_store", "scratch_store", "s_setprio", "s_sleep", "global_load_lds", "s_setreg", "s_sendmsg", "s_code_end", "s_setpc", "s_icache",
            "s_dcache", "buffer_wbl2", "buffer_inv", "s_trap", "s_waitcnt_", "ds_nop", "s_endpgm_saved", "s_set_gpr", "v_nop", "s_wakeup", "s_getpc_dummy")
 TWO_DEST = ("v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_subbrev_co", "v_div_scale", "v_mad_u64", "v_mad_i64")
+# kernels known to spill, with the most dwords they may: gemm_h's one-tile epilogue forms at four waves per SIMD (three without spills measured
+# slower, conv_mfma.h), the rarely used radius-7 / 8 forms of the sparse NMS tail (1024 threads: 128 registers)
+KNOWN_SPILLS = {"gemm_hILi2ELi1ELi0ELb1E": 3, "gemm_hILi2ELi1ELi1ELb0E": 1, "gemm_hILi2ELi1ELi2ELb0E": 10, "nms_tailILi7E": 2, "nms_tailILi8E": 215}
 ASM_ALLOWED = re.compile(r"^(s_waitcnt|s_nop|s_mov_b32|s_mov_b64|global_load_lds_dwordx4|global_load_lds_dword|s_memtime|s_sleep|s_setprio)\b")
 
 
@@ -250,6 +257,22 @@ def disassemble(path, workdir):
     return texts
 
 
+def spill_counts(path, workdir):
+    """{kernel: vector registers spilled} from the code objects' metadata (llvm-readelf --notes) or a .s file's amdhsa.kernels section."""
+    if path.endswith(".s"):
+        metas = [open(path).read()]
+    else:
+        tools = llvm_bin()
+        local = os.path.join(workdir, os.path.basename(path))
+        cos = sorted(glob.glob(local + ".*gfx950*")) or [local]        # disassemble() has extracted them
+        metas = [subprocess.run([os.path.join(tools, "llvm-readelf"), "--notes", co], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True).stdout for co in cos]
+    out = {}
+    for meta in metas:
+        for m in re.finditer(r"\.name:\s+(\S+)(?:(?!\.name:).)*?\.vgpr_spill_count:\s+(\d+)", meta, re.S):
+            out[m.group(1)] = max(out.get(m.group(1), 0), int(m.group(2)))
+    return out
+
+
 def lint(paths, check_sources=True, verbose=True):
     all_errors, totals, nk = [], {"mfma_dst_overlaps_ab": 0, "packed_fp32": 0}, 0
     with tempfile.TemporaryDirectory() as wd:
@@ -261,6 +284,10 @@ def lint(paths, check_sources=True, verbose=True):
                     for k in totals:
                         totals[k] += info[k]
                     all_errors += [(e[0], name, e[1], e[2]) for e in errs]
+            for name, n in spill_counts(p, wd).items():
+                allowed = max([v for k, v in KNOWN_SPILLS.items() if k in name] or [0])
+                if n > allowed:
+                    all_errors.append(("E4", name, "%d vector registers spilled to scratch (allowed: %d)" % (n, allowed), os.path.basename(p)))
     if check_sources:
         all_errors += [(e[0], "-", e[1], e[2]) for e in lint_sources(os.path.join(ROOT, "keypoint_bench_amd", "csrc"))]
     if verbose:

@@ -118,3 +118,16 @@ def test_no_vector_instruction_hides_in_an_inline_asm_string(tmp_path):
                                     '__device__ void g() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }\n')
     errors = isa_lint.lint_sources(str(tmp_path))
     assert len(errors) == 1 and errors[0][0] == "E3" and "v_fma_mix_f32" in errors[0][2]
+
+
+def test_a_kernel_that_spills_vector_registers_is_a_finding(tmp_path):
+    """E4 reads the code object's metadata: vector registers spilled to scratch beyond the short list of kernels known to.  The text is what
+    hipcc -S appends to a translation unit (amdhsa.kernels); the shipped library's count is part of test_the_shipped_library_is_clean."""
+    meta = ("\n\t.amdgpu_metadata\n---\namdhsa.kernels:\n  - .name:           probe\n    .private_segment_fixed_size: %d\n    .vgpr_count:     96\n"
+            "    .vgpr_spill_count: %d\n...\n\t.end_amdgpu_metadata\n")
+    s = tmp_path / "spill.s"
+    s.write_text(_KERNEL % "\tv_mov_b32_e32 v40, v41" + meta % (160, 40))
+    errors, _, _ = isa_lint.lint([str(s)], check_sources=False, verbose=False)
+    assert [e[0] for e in errors] == ["E4"] and "40 vector registers" in errors[0][2], errors
+    s.write_text(_KERNEL % "\tv_mov_b32_e32 v40, v41" + meta % (3872, 0))          # private arrays without spills (the RANSAC solvers) are fine
+    assert not isa_lint.lint([str(s)], check_sources=False, verbose=False)[0]
