@@ -27,7 +27,8 @@ for net in ("superpoint", "disk_lightglue", "xfeat"):
         if os.path.exists(os.path.join(d, "traffic.json")):
             shutil.copy(os.path.join(d, "traffic.json"), os.path.join(dst, "%s_pmc_traffic_%s.json" % (R, net)))
 for f in (glob.glob(os.path.join(src, R, "runner_rate*.json")) + glob.glob(os.path.join(src, R, "parity_sweep*.json")) +
-          glob.glob(os.path.join(src, R, "bench_500_steps.json")) + glob.glob(os.path.join(src, R, "rates_build.txt"))):
+          glob.glob(os.path.join(src, R, "bench_500_steps.json")) + glob.glob(os.path.join(src, R, "rates_build.txt")) +
+          glob.glob(os.path.join(src, R, "soak_*.txt")) + glob.glob(os.path.join(src, R, "soak_*.json"))):      # scripts/soak.sh
     if os.path.getsize(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (R, os.path.basename(f))))
 # which library every bench line of the round came from (config.build of bench.py's JSON line): one build, or the README must say so
