@@ -1750,6 +1750,7 @@ struct LinArgs {
     const float* wsc;                      // [64]      score row; entries 0..15 belong to f1
     float* score;
     int H, W;
+    float sy2, sx2, sy3, sx3, sy4, sx4;    // (Hs - 1) / (H - 1), (Ws - 1) / (W - 1) of the three coarse score maps: the same float divisions, taken once on the host
 };
 
 __device__ __forceinline__ float lerp_scalar(const float* m, int Hs, int Ws, float sy, float sx, int y, int x)
@@ -1772,20 +1773,27 @@ __global__ __launch_bounds__(256) void alike_score_lin(LinArgs a)
     const float* px = a.x1 + ((size_t)b * P + pix) * 8;
     const float4 lo = *reinterpret_cast<const float4*>(px), hi = *reinterpret_cast<const float4*>(px + 4);
     const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    float f[16];
+    // r05: the kernel is bound by vector issue (9.5e8 instructions per launch: more than block 1).  agg1's 128 FMAs go two output channels at a
+    // time (v_pk_fma_f32 against a pair of scalar weights: the same fused operations in the same order, 64 instructions), the six scale
+    // divisions -- wave-uniform, 8 instructions each -- come from the host.
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    f2v f[8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) f[j] = 0.0f;
+    for (int j = 0; j < 8; ++j) f[j] = (f2v){0.0f, 0.0f};
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) f[j] = fmaf(v[c], a.agg1[c * 16 + j], f[j]);
+        for (int j = 0; j < 8; ++j) {
+            const f2v w = {a.agg1[c * 16 + 2 * j], a.agg1[c * 16 + 2 * j + 1]};
+            f[j] = __builtin_elementwise_fma((f2v){v[c], v[c]}, w, f[j]);
+        }
     float sc = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) sc = fmaf(relu(f[j]), a.wsc[j], sc);
+    for (int j = 0; j < 16; ++j) sc = fmaf(relu(f[j >> 1][j & 1]), a.wsc[j], sc);
     const int H2 = a.H / 2, W2 = a.W / 2, H8 = a.H / 8, W8 = a.W / 8, H32 = a.H / 32, W32 = a.W / 32;
-    sc += lerp_scalar(a.S2 + (size_t)b * H2 * W2, H2, W2, (float)(H2 - 1) / (float)(a.H - 1), (float)(W2 - 1) / (float)(a.W - 1), y, x);
-    sc += lerp_scalar(a.S3 + (size_t)b * H8 * W8, H8, W8, (float)(H8 - 1) / (float)(a.H - 1), (float)(W8 - 1) / (float)(a.W - 1), y, x);
-    sc += lerp_scalar(a.S4 + (size_t)b * H32 * W32, H32, W32, (float)(H32 - 1) / (float)(a.H - 1), (float)(W32 - 1) / (float)(a.W - 1), y, x);
+    sc += lerp_scalar(a.S2 + (size_t)b * H2 * W2, H2, W2, a.sy2, a.sx2, y, x);
+    sc += lerp_scalar(a.S3 + (size_t)b * H8 * W8, H8, W8, a.sy3, a.sx3, y, x);
+    sc += lerp_scalar(a.S4 + (size_t)b * H32 * W32, H32, W32, a.sy4, a.sx4, y, x);
     a.score[(size_t)b * P + pix] = __fdiv_rn(1.0f, 1.0f + expf(-sc));   // torch.sigmoid (ALike.py:162)
 }
 
@@ -2059,7 +2067,9 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
         } else
             KPB_LAUNCH(ctx, "alike_head_dense", alike_head_hyb, dim3(work4, batch), dim3(256), 0, st, hy);
     } else {
-        LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W};
+        LinArgs la{x1, S2, S3, S4, wp("agg1.w"), wp("head.ws"), score_out_dev, H, W,
+                   (float)(H / 2 - 1) / (float)(H - 1), (float)(W / 2 - 1) / (float)(W - 1), (float)(H / 8 - 1) / (float)(H - 1), (float)(W / 8 - 1) / (float)(W - 1),
+                   (float)(H / 32 - 1) / (float)(H - 1), (float)(W / 32 - 1) / (float)(W - 1)};
         KPB_LAUNCH(ctx, "alike_head_score", alike_score_lin, dim3(cdiv(H * W, 256), batch), dim3(256), 0, st, la);
     }
     KPB_HIP(ctx, hipGetLastError());
