@@ -49,6 +49,14 @@ def main():
     f["DISKLGF16"] = "{:,.0f}".format(line(P + "bench_disk_lightglue_f16attn.json")["value"]).replace(",", " ")
     m = re.search(r"^dense ([0-9.]+) ms/pair", open(P + "single_pair_latency.txt").read(), re.M)
     f["SINGLE"] = m.group(1) if m else "?"
+    num = lambda v: "{:,.0f}".format(v["pairs_per_s"] if isinstance(v, dict) else v).replace(",", " ")
+    rr = json.load(open(P + "runner_rate.json"))
+    f.update(RRMS=num(rr["match_stats"]), RRREP=num(rr["repeatability"]), RRMHA=num(rr["MHA"]), RRAUC=num(rr["AUC"]))
+    sq, sx = json.load(open(P + "runner_rate_seq.json")), json.load(open(P + "runner_rate_seq_xfeat.json"))
+    f.update(SEQFM=num(sq["FundamentalMatrix"]), SEQFMXF=num(sx["FundamentalMatrix"]), SEQVO=num(sq["visual_odometer"]), SEQVOXF=num(sx["visual_odometer"]))
+    f.update(HOSTF32=num(json.load(open(P + "runner_rate_host.json"))["match_stats"]), HOSTU8=num(json.load(open(P + "runner_rate_u8.json"))["match_stats"]))
+    png, jpg = json.load(open(P + "runner_rate_files_png.json")), json.load(open(P + "runner_rate_files_jpeg.json"))
+    f.update(PNG=num(png["match_stats"]), JPEG=num(jpg["match_stats"]), PNGPOOL=num(png["decode_pool_alone_pairs_per_s"]), JPEGPOOL=num(jpg["decode_pool_alone_pairs_per_s"]))
     text = open(tmpl).read()
     missing = set(re.findall(r"@@([A-Z0-9]+)@@", text)) - set(f)
     if missing:
