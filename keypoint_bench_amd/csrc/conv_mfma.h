@@ -30,6 +30,9 @@ struct ConvM {
     const float* xw = nullptr;    // conv_mfma_h<XC>: weights of ONE extra output channel (index xco) taken on the VALU: [tap][CIN / 2] x (hi pair, lo pair) of
                                   // halves (pack_xc_pairs), scaled by 1 / xun
     float xun = 1.0f;
+    // conv_mfma_h<.., PRE, .., GEN> (r05): the input is GENERATED while the tile is staged -- `in` is a one-channel image and the slab's 32 channels are
+    // relu(3 x 3 convolution + bias) of it (SuperPoint conv1a: gen_w [9][64] tap-major, gen_b [64]), scaled and split as the pre-split hand-off would be
+    const float* gen_w = nullptr; const float* gen_b = nullptr;
     float xb = 0.0f;              // its bias
     int xco = 0;
     // gemm_h only (the LightGlue linears): rows >= rowcnt[b] are staged as zeros and never written -- what a padded row holds cannot
@@ -321,10 +324,11 @@ constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
 // workgroup -- the four waves request the same weight fragments, 4 x the bytes through the CU's vector L1 (64 B/clk), and a knock-out
 // put 18 % of SuperPoint's conv1b there (profiles/r05_presplit_conv1b_ab.txt).  WN = 2: a wave takes twice the rows and half the
 // n-tiles: the same 64 accumulator registers and products, half the weight bytes, twice the activation reads -- which come from LDS.
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false, int WN = 1>
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false, int WN = 1, bool GEN = false>
 __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
     static_assert(WN == 1 || (WN == 2 && MT % 2 == 0 && !WPRE), "conv_mfma_h: waves split the n-tiles two ways at most");
+    static_assert(!GEN || (PRE && KS == 3), "conv_mfma_h: the generated input is a 3 x 3 layer in front of a pre-split one");
     static_assert(!PRE || (CC == 32 && S == 1 && !POOL_IN && !XF && !XC && !WPRE), "conv_mfma_h: the pre-split input form exists for plain stride-1 32-channel slabs");
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT / WN;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
@@ -389,6 +393,58 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
             constexpr int NPIX = IH * IW, NU = (NPIX + 7) / 8;
             static_assert(NU * 1024 <= IH * ROWP, "conv_mfma_h<PRE>: the dense tile must fit the padded one's LDS");
             if (ch == 0) e_cur = cm_exp_of(fmaf(__uint_as_float(a.pre_amax[b]), a.pre_l1, a.pre_bmax));
+            if constexpr (GEN) {
+                // conv1a inside conv1b (r05): the producer's 64 channels are never written -- its 3 x 3 window of the one-channel image sits in a
+                // (IH + 2) x (IW + 2) tile behind the slab and a thread computes pixel t's 32 channels of this slab, eight at a time against
+                // scalar weights (the same fused chain per channel as conv1a_c64: taps in column order), scales, splits and writes the two
+                // 16-byte slots where the DMA would have put them.  2.5 GB written and read back per 32 images, and conv1a's launch, are gone.
+                constexpr int GW = IW + 2, GH = IH + 2;
+                static_assert(NU * 1024 + GH * GW * 4 <= IH * ROWP, "conv_mfma_h<GEN>: the image tile lives behind the dense slab");
+                float* gt = reinterpret_cast<float*>(tile + NU * 1024);
+                if (ch == 0) {
+                    for (int i = tid; i < GH * GW; i += 256) {
+                        const int yy = i / GW, gy = iy0 - 1 + yy, gx = ix0 - 1 + (i - yy * GW);
+                        gt[i] = (gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) ? in[(size_t)gy * a.Wi + gx] : 0.0f;
+                    }
+                }
+                __syncthreads();                // the previous slab's taps are done with the tile (ch == 0: the image tile is complete)
+                const float sc = cm_scale_of(e_cur);
+#pragma unroll 1
+                for (int t0 = 0; t0 < NPIX; t0 += 256) {
+                    const int t = t0 + tid, tc = min(t, NPIX - 1);
+                    const int y = tc / IW, x = tc - y * IW;
+                    const int gy = iy0 + y, gx = ix0 + x;
+                    const bool inimg = gy >= 0 && gy < Hc && gx >= 0 && gx < Wc;      // the consumer pads ITS input with zeros
+                    float g[9];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) g[k] = gt[(y + k / 3) * GW + x + k % 3];
+                    const int key = (x >> 1) & 7;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float* w = a.gen_w + ch * 32 + 8 * s;
+                        float acc[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = a.gen_b[ch * 32 + 8 * s + e];
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                acc[e] = fmaf(g[kx], w[kx * 64 + e], acc[e]);
+                                acc[e] = fmaf(g[3 + kx], w[(3 + kx) * 64 + e], acc[e]);
+                                acc[e] = fmaf(g[6 + kx], w[(6 + kx) * 64 + e], acc[e]);
+                            }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = inimg ? relu(acc[e]) * sc : 0.0f;
+                        uint2 h0, l0, h1, l1;
+                        cm_split4(make_float4(acc[0], acc[1], acc[2], acc[3]), h0, l0);
+                        cm_split4(make_float4(acc[4], acc[5], acc[6], acc[7]), h1, l1);
+                        if (t < NPIX) {
+                            *reinterpret_cast<uint4*>(tile + t * 128 + 16 * (s ^ key)) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                            *reinterpret_cast<uint4*>(tile + t * 128 + 16 * ((4 + s) ^ key)) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                        }
+                    }
+                }
+            } else {
             __syncthreads();                    // the previous slab's taps are done with the tile
             const unsigned char* src0 = reinterpret_cast<const unsigned char*>(in) + (size_t)ch * 128;
             const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.pre_zero) + (lane & 7) * 16;
@@ -403,6 +459,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                 cm_dma16(src, tile + u * 1024);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }       // !GEN
         } else {
         float4 buf[NLD];
         float amax = 0.0f;

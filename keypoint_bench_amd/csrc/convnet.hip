@@ -710,7 +710,7 @@ struct Layer {      // one convolution of a network plan
     int ntb = 2;    // 32-wide output tiles per workgroup
 };
 
-struct PreSplit { const unsigned* amax = nullptr; float l1 = 0.0f, bmax = 0.0f; const void* zero = nullptr; };     // ConvM::pre_*
+struct PreSplit { const unsigned* amax = nullptr; float l1 = 0.0f, bmax = 0.0f; const void* zero = nullptr; const float* gen_w = nullptr; const float* gen_b = nullptr; };     // ConvM::pre_*, gen_*
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
                 bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f, const float2* unfold_mr = nullptr,
@@ -737,7 +737,11 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         // workgroups per CU) measured 8-16 % faster; layers with two output tiles lose the fragment reuse that way (+8 % time)
         if (pre) {      // the input arrives already split (ConvM::pre_amax): raw bytes land in the tile by LDS-DMA
             a.pre_amax = pre->amax; a.pre_l1 = pre->l1; a.pre_bmax = pre->bmax; a.pre_zero = pre->zero;
-            if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2)
+            if (pre->gen_w && L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2) {
+                a.gen_w = pre->gen_w; a.gen_b = pre->gen_b; a.istride = 1;         // `in` is the one-channel image the layer in front reads
+                KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, true, 2, true>), g2, block, 0, st, a);
+            }
+            else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2)
                 KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, true, 2>), g2, block, 0, st, a);
             else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no pre-split instance for %s", L.name.c_str());
             return KPB_OK;
@@ -871,8 +875,10 @@ struct SuperPointNet : kpb_net {
         int rc;
         // r05: conv1a hands conv1b its 64 channels ALREADY SPLIT (ConvM::pre_amax), at the scale of the bound amax(gray) l1 + bmax of its
         // own output -- known before it stores, so conv1b's tile is filled by LDS-DMA with no staging arithmetic (KPB_PRESPLIT=0: the r04 path)
-        static const int presplit = kpb_env_int("KPB_PRESPLIT", 1);
-        const bool pre = presplit && conv_mfma_use_h16() && (W % 4) == 0;
+        // KPB_PRESPLIT=2 (r05, default): conv1a is not launched at all -- conv1b computes its channels from the gray image while it stages its tile
+        static const int presplit = kpb_env_int("KPB_PRESPLIT", 2);
+        const bool fused = presplit == 2 && conv_mfma_use_h16();
+        const bool pre = fused || (presplit && conv_mfma_use_h16() && (W % 4) == 0);
         PreSplit ps;
         if (pre) {
             if ((rc = kpb_reserve(ctx, aux, (size_t)batch * sizeof(unsigned) + 256))) return rc;
@@ -882,9 +888,10 @@ struct SuperPointNet : kpb_net {
             KPB_LAUNCH(ctx, "sp_gray_amax", plane_abs_max, dim3(batch), dim3(1024), 0, st, gray, P, amax_gray);
             ps.amax = amax_gray; ps.l1 = wscale.at("conv1a.l1"); ps.bmax = wscale.at("conv1a.bmax"); ps.zero = zero;
         }
-        KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32,
-                   ps.amax, ps.l1, ps.bmax);   // :44
-        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], x1a, x1b, batch, H, W, false, true, true, nullptr, 0, 0.0f, nullptr, pre ? &ps : nullptr))) return rc;      // :45-46 (+pool)
+        if (fused) { ps.gen_w = wp("conv1a.w"); ps.gen_b = wp("conv1a.b"); }
+        else KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32,
+                        ps.amax, ps.l1, ps.bmax);   // :44
+        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], fused ? gray : x1a, x1b, batch, H, W, false, true, true, nullptr, 0, 0.0f, nullptr, pre ? &ps : nullptr))) return rc;      // :45-46 (+pool)
         if ((rc = launch_mfma(ctx, "sp_conv2a", this, L["conv2a"], x1b, x2a, batch, H / 2, W / 2, false, false, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv2b", this, L["conv2b"], x2a, x2b, batch, H / 2, W / 2, false, true, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv3a", this, L["conv3a"], x2b, x3a, batch, H / 4, W / 4, false, false, true))) return rc;

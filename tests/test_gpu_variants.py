@@ -11,7 +11,8 @@ of this GPU-initialised process):
   KPB_MATCH_PREFILTER=2  the MFMA prefilter + exact refinement for ANY number of pairs: the single-pair match goldens and the fuzz
                          then run on the path the batched pipelines take from 8 pairs up.
 
-  KPB_PRESPLIT=0         SuperPoint's conv1a -> conv1b hand-off as plain fp32 (r04) instead of pre-split halves landed by LDS-DMA (r05)
+  KPB_PRESPLIT=0 / 1     SuperPoint's conv1a as its own kernel, handing conv1b plain fp32 (0: r04) or pre-split halves landed by LDS-DMA (1: r05's
+                         first form) instead of conv1b computing conv1a's channels itself while it stages its tile (2: the default)
 Experiment knobs of r02 (KPB_HEAD_MAP / PIPE / WPS / PF, KPB_*_MT1, KPB_GEMM_*, KPB_BLOCK*_H16, KPB_CONV_H16) lost their
 non-default branches: the measured choice is the code."""
 import os
@@ -61,10 +62,11 @@ def test_prefilter_forced_on_single_pairs_passes_the_goldens():
 
 
 @pytest.mark.timeout(900)
-def test_superpoint_without_the_presplit_handoff_passes_the_goldens():
-    """KPB_PRESPLIT=0: conv1a hands conv1b plain fp32 activations again (r04's path: staged through registers, split per slab); the default
-    since r05 is the pre-split hand-off landed by LDS-DMA (conv_mfma_h<.., PRE>)."""
-    _child({"KPB_PRESPLIT": "0"}, ["tests/test_gpu_superpoint.py", "tests/test_gpu_range.py", "tests/test_gpu_shapes.py"])
+@pytest.mark.parametrize("mode", ["0", "1"])
+def test_superpoint_with_conv1a_as_its_own_kernel_passes_the_goldens(mode):
+    """KPB_PRESPLIT=0: conv1a hands conv1b plain fp32 activations (r04's path: staged through registers, split per slab); 1: pre-split halves
+    landed by LDS-DMA (conv_mfma_h<.., PRE>); the default (2) has no conv1a launch -- conv_mfma_h<.., GEN> computes its channels in the staging."""
+    _child({"KPB_PRESPLIT": mode}, ["tests/test_gpu_superpoint.py", "tests/test_gpu_range.py", "tests/test_gpu_shapes.py"])
 
 
 def test_no_other_environment_knob_selects_a_kernel():
