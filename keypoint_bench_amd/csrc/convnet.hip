@@ -589,6 +589,9 @@ __global__ __launch_bounds__(256) void l2norm_nhwc(float* desc, int C, size_t np
 
 // ------------------------------------------------------------------------------------------------ XFeat pieces
 // XFeat.py:121-123: x.mean(dim=1) then InstanceNorm2d(1): (x - mean) / sqrt(var + 1e-5), biased variance per image.
+// r05: every block leaves its partial (sum, sum of squares) in stats[image][block]; instnorm_params adds the XF_STAT_BLOCKS pairs in block order --
+// the same fp64 sums every run (they were fp64 atomics in arrival order).
+constexpr int XF_STAT_BLOCKS = 64;
 __global__ __launch_bounds__(256) void gray_mean_stats(const float* img, float* gray, double* stats, size_t P)
 {
     __shared__ double s1[4], s2[4];
@@ -619,18 +622,16 @@ __global__ __launch_bounds__(256) void gray_mean_stats(const float* img, float* 
     if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&stats[2 * b], s1[0] + s1[1] + s1[2] + s1[3]);
-        atomicAdd(&stats[2 * b + 1], s2[0] + s2[1] + s2[2] + s2[3]);
+        stats[(b * gridDim.x + blockIdx.x) * 2] = s1[0] + s1[1] + s1[2] + s1[3];
+        stats[(b * gridDim.x + blockIdx.x) * 2 + 1] = s2[0] + s2[1] + s2[2] + s2[3];
     }
 }
 
-__global__ void instnorm_apply(float* gray, const double* stats, size_t P)       // four pixels per thread (P is a multiple of 1024: H and W are multiples of 32)
+__global__ void instnorm_apply(float* gray, const float2* mr, size_t P)       // four pixels per thread (P is a multiple of 1024: H and W are multiples of 32)
 {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4, b = blockIdx.y;
     if (i >= P) return;
-    const double mean = stats[2 * b] / (double)P;
-    const double var = fmax(stats[2 * b + 1] / (double)P - mean * mean, 0.0);
-    const float m = (float)mean, r = 1.0f / sqrtf((float)var + 1e-5f);
+    const float m = mr[b].x, r = mr[b].y;        // instnorm_params' (mean, 1 / std)
     float4* g = reinterpret_cast<float4*>(gray + b * P + i);
     float4 v = *g;
     v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
@@ -644,8 +645,10 @@ __global__ void instnorm_params(const double* stats, size_t P, float2* mr, int B
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
-    const double mean = stats[2 * b] / (double)P;
-    const double var = fmax(stats[2 * b + 1] / (double)P - mean * mean, 0.0);
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < XF_STAT_BLOCKS; ++k) { s += stats[((size_t)b * XF_STAT_BLOCKS + k) * 2]; q += stats[((size_t)b * XF_STAT_BLOCKS + k) * 2 + 1]; }
+    const double mean = s / (double)P;
+    const double var = fmax(q / (double)P - mean * mean, 0.0);
     mr[b] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
 }
 
@@ -981,9 +984,9 @@ struct XFeatNet : kpb_net {
         const size_t n_gray = P, n_a = P * 4, n_b = P / 4 * 8, n_c = P / 4 * 8, n_x1 = P / 16 * 32, n_t = P / 16 * 32, n_x2 = P / 16 * 32,
                      n_8 = P / 64 * 64, n_16 = P / 256 * 64, n_32a = P / 1024 * 128, n_semi = P / 64 * 65;
         const size_t total = B * (n_gray + n_a + n_b + n_c + n_x1 + n_t + n_x2 + 6 * n_8 + 3 * n_16 + 3 * n_32a + n_semi) + 64;
-        if (int rc = kpb_reserve(ctx, act, total * sizeof(float) + 16 * B + 8 * B)) return rc;
+        if (int rc = kpb_reserve(ctx, act, total * sizeof(float) + 16 * XF_STAT_BLOCKS * B + 8 * B)) return rc;
         float* p = static_cast<float*>(act.p);
-        double* stats = reinterpret_cast<double*>(p); p += 2 * ((2 * B + 1) / 2 * 2);     // 2 doubles per image
+        double* stats = reinterpret_cast<double*>(p); p += 4 * XF_STAT_BLOCKS * B;          // [B][XF_STAT_BLOCKS] pairs of doubles
         float* mrbuf = p; p += 2 * B;                                                      // (mean, 1 / std) per image
         float* gray = p; p += B * n_gray;
         float* a1 = p; p += B * n_a; float* b1 = p; p += B * n_b; float* c1 = p; p += B * n_c;
@@ -994,16 +997,15 @@ struct XFeatNet : kpb_net {
         float* semi = p; p += B * n_semi;
         this->B = batch; this->H = H; this->W = W;
         hipStream_t st = ctx->stream;
-        KPB_HIP(ctx, hipMemsetAsync(stats, 0, 2 * B * sizeof(double), st));
-        KPB_LAUNCH(ctx, "xf_gray_stats", gray_mean_stats, dim3(64, batch), dim3(256), 0, st, img, gray, stats, P);
+        KPB_LAUNCH(ctx, "xf_gray_stats", gray_mean_stats, dim3(XF_STAT_BLOCKS, batch), dim3(256), 0, st, img, gray, stats, P);
         // the split-f16 form normalises the grey image where it is read (three consumers) from per-image (mean, 1 / std)
         const bool fold_norm = conv_mfma_use_h16() && L.at("keypoint_head.0").mfma && W % 8 == 0;
-        float2* mr = nullptr;
-        if (fold_norm) {
-            mr = reinterpret_cast<float2*>(mrbuf);
-            KPB_LAUNCH(ctx, "xf_instnorm_params", instnorm_params, dim3(cdiv(batch, 256)), dim3(256), 0, st, stats, P, mr, batch);
-        } else
-            KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P / 4 + 255) / 256), batch), dim3(256), 0, st, gray, stats, P);
+        float2* mr = reinterpret_cast<float2*>(mrbuf);
+        KPB_LAUNCH(ctx, "xf_instnorm_params", instnorm_params, dim3(cdiv(batch, 256)), dim3(256), 0, st, stats, P, mr, batch);
+        if (!fold_norm) {
+            KPB_LAUNCH(ctx, "xf_instnorm", instnorm_apply, dim3((unsigned)((P / 4 + 255) / 256), batch), dim3(256), 0, st, gray, mr, P);
+            mr = nullptr;
+        }
         int rc;
         // block1 (XFeat.py:30-35) and the skip connection (27-28, 127)
         {   // block1.0 + block1.1 fused: the 4-channel full-resolution map never reaches HBM (r04)
@@ -1188,8 +1190,10 @@ __global__ void upsample2_concat(const float* bot, const float* hor, float* out,
     *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * C + c) = v;
 }
 
-// per (image, channel) sum and sum of squares over the pixels of an NHWC tensor; block = (C, R) threads
-__global__ void chan_sums(const float* in, double* sums, size_t P, int C)
+// per (image, channel) sum and sum of squares over the pixels of an NHWC tensor; block = (C, R) threads.  Every block leaves ITS partial pair in
+// part[image][block][channel] and make_xf adds the blocks up in index order: the sums are the same bits every run (r05: they were accumulated by
+// fp64 atomics in arrival order -- within rounding of the float parameters they feed, but not a fixed sequence of operations).
+__global__ void chan_sums(const float* in, double* part, size_t P, int C)
 {
     extern __shared__ double sh[];   // [R][C][2]
     const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
@@ -1212,18 +1216,21 @@ __global__ void chan_sums(const float* in, double* sums, size_t P, int C)
     __syncthreads();
     if (r == 0) {
         for (int k = 1; k < R; ++k) { s += sh[(k * C + c) * 2]; q += sh[(k * C + c) * 2 + 1]; }
-        atomicAdd(&sums[(b * C + c) * 2], s);
-        atomicAdd(&sums[(b * C + c) * 2 + 1], q);
+        double* o = part + ((b * gridDim.x + blockIdx.x) * C + c) * 2;
+        o[0] = s; o[1] = q;
     }
 }
 
 // InstanceNorm2d (biased variance, eps 1e-5, no affine) folded with the PReLU slope into the conv's input transform
-__global__ void make_xf(const double* sums, const float* slope, float* xf, size_t P, int C, int n)
+__global__ void make_xf(const double* part, int nblk, const float* slope, float* xf, size_t P, int C, int n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double mean = sums[2 * i] / (double)P;
-    const double var = fmax(sums[2 * i + 1] / (double)P - mean * mean, 0.0);
+    const int b = i / C, c = i - b * C;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < nblk; ++k) { const double* o = part + (((size_t)b * nblk + k) * C + c) * 2; s += o[0]; q += o[1]; }      // block order: the same sum every run
+    const double mean = s / (double)P;
+    const double var = fmax(q / (double)P - mean * mean, 0.0);
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
     xf[4 * i] = rstd; xf[4 * i + 1] = -(float)mean * rstd; xf[4 * i + 2] = slope[i % C]; xf[4 * i + 3] = 0.0f;
 }
@@ -1258,13 +1265,13 @@ __global__ __launch_bounds__(256) void disk_head(const float* __restrict__ feat,
 
 struct DiskNet : kpb_net {
     std::map<std::string, Layer> L;
+    static constexpr int SUM_BLOCKS = 128;
     int stats_xf(const float* t, size_t P, int C, const char* slope_name, double* sums, float* xf, int batch)
     {
         hipStream_t st = ctx->stream;
-        KPB_HIP(ctx, hipMemsetAsync(sums, 0, (size_t)batch * C * 2 * sizeof(double), st));
         const int R = 512 / C > 0 ? 512 / C : 1;
-        KPB_LAUNCH(ctx, "disk_chan_sums", chan_sums, dim3(128, batch), dim3(C, R), (size_t)R * C * 2 * sizeof(double), st, t, sums, P, C);
-        KPB_LAUNCH(ctx, "disk_make_xf", make_xf, dim3(cdiv(batch * C, 256)), dim3(256), 0, st, sums, wp(slope_name), xf, P, C, batch * C);
+        KPB_LAUNCH(ctx, "disk_chan_sums", chan_sums, dim3(SUM_BLOCKS, batch), dim3(C, R), (size_t)R * C * 2 * sizeof(double), st, t, sums, P, C);
+        KPB_LAUNCH(ctx, "disk_make_xf", make_xf, dim3(cdiv(batch * C, 256)), dim3(256), 0, st, sums, SUM_BLOCKS, wp(slope_name), xf, P, C, batch * C);
         return KPB_OK;
     }
     int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
@@ -1278,10 +1285,10 @@ struct DiskNet : kpb_net {
                      n_f4 = P / 64 * 64, n_p4 = P / 256 * 64, n_f5 = P / 256 * 64, n_c0 = P / 64 * 128, n_u0 = P / 64 * 64, n_c1 = P / 16 * 128,
                      n_u1 = P / 16 * 64, n_c2 = P / 4 * 96, n_u2 = P / 4 * 64, n_c3 = P * 80, n_lg = P * 129;
         const size_t total = B * (n_in + n_f1 + n_p1 + n_f2 + n_p2 + n_f3 + n_p3 + n_f4 + n_p4 + n_f5 + n_c0 + n_u0 + n_c1 + n_u1 + n_c2 + n_u2 + n_c3 + n_lg)
-                             + B * 128 * 4 + B * 128 * 4 + 64;
+                             + B * SUM_BLOCKS * 128 * 4 + B * 128 * 4 + 64;
         if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
         float* p = static_cast<float*>(act.p);
-        double* sums = reinterpret_cast<double*>(p); p += B * 128 * 4;     // B*128*2 doubles
+        double* sums = reinterpret_cast<double*>(p); p += B * SUM_BLOCKS * 128 * 4;     // [B][SUM_BLOCKS][<= 128 channels] pairs of doubles: per-block partial sums
         float* xf = p; p += B * 128 * 4;
         auto take = [&](size_t n) { float* q = p; p += B * n; return q; };
         float *in4 = take(n_in), *f1 = take(n_f1), *p1 = take(n_p1), *f2 = take(n_f2), *p2 = take(n_p2), *f3 = take(n_f3), *p3 = take(n_p3),
