@@ -217,6 +217,9 @@ struct ValArgs {
     int32_t* cnt;                       // [batch][max_m] mutual cells per row, then their exclusive scan
     int32_t* pairs; float* dist; int cap;
     float* errors; int32_t* counts;     // [batch][max_m], [batch][2]
+    float* dm;                          // [batch][max_m][max_n] or null (r05): the cells, written by the row pass and READ by the three later passes instead of
+                                        // being evaluated four times (two correctly rounded square roots each: the passes were arithmetic-bound, 2.8 ms per 256
+                                        // pairs of 1000 x 1000; 1 GB per such batch -- what 288 GB of HBM are for); null above 4 GB: every pass evaluates its cells
 };
 
 __device__ __forceinline__ float kp_dist(float ax, float ay, float bx, float by)
@@ -249,8 +252,10 @@ __global__ __launch_bounds__(256) void covis_stats(ValArgs a)
         const int i = w;
         const float2 a0 = k0[i], a01 = k01[i];
         float lo = INFINITY, hi = 0.f;
+        float* row = a.dm ? a.dm + ((size_t)b * a.max_m + i) * a.max_n : nullptr;
         for (int j = lane; j < N; j += 64) {
             const float d = dm_cell(a0, a01, k1[j], k10[j], i, j, nd);
+            if (row) row[j] = d;
             lo = fminf(lo, d); hi = fmaxf(hi, d);
         }
         lo = wave_min(lo); hi = wave_max(hi);
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void covis_stats(ValArgs a)
             a.errors[(size_t)b * a.max_m + i] = lo * a.scale[2 * b + 1];          // 79/81 then 85: min commutes with the positive scale
             atomicMax(a.dmax + b, __float_as_uint(hi));
         }
-    } else {
+    } else if (!a.dm) {
         const int j = w - M;
         const float2 b1 = k1[j], b10 = k10[j];
         float lo = INFINITY;
@@ -267,6 +272,20 @@ __global__ __launch_bounds__(256) void covis_stats(ValArgs a)
         lo = wave_min(lo);
         if (lane == 0) a.cmin[(size_t)b * a.max_n + j] = lo;
     }
+}
+
+// column minima from the stored cells: a wave takes 64 adjacent columns and walks down the rows (256 contiguous bytes per load)
+__global__ __launch_bounds__(256) void covis_colmin(ValArgs a)
+{
+    const int b = blockIdx.y;
+    const int M = a.m_dev ? min(a.m_dev[b], a.max_m) : a.max_m, N = a.n_dev ? min(a.n_dev[b], a.max_n) : a.max_n;
+    const int j = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + (threadIdx.x & 63);
+    if (j >= N || M == 0) return;
+    const float* col = a.dm + (size_t)b * a.max_m * a.max_n + j;
+    float lo = INFINITY;
+#pragma unroll 8
+    for (int i = 0; i < M; ++i) lo = fminf(lo, col[(size_t)i * a.max_n]);
+    a.cmin[(size_t)b * a.max_n + j] = lo;
 }
 
 // value = (-dm) - min(-dm) (18, 36) is a monotone rounding of dm, so a row's maximum of `value` is the image of the
@@ -293,7 +312,7 @@ __global__ __launch_bounds__(256) void covis_mutual(ValArgs a)
         bool hit = false;
         float d = 0.f;
         if (j < N) {
-            d = dm_cell(a0, a01, k1[j], k10[j], i, j, nd);
+            d = a.dm ? a.dm[((size_t)b * a.max_m + i) * a.max_n + j] : dm_cell(a0, a01, k1[j], k10[j], i, j, nd);
             const float v = (-d) - c;
             hit = v == vr && v == (-cmin[j]) - c;
         }
@@ -380,16 +399,20 @@ extern "C" __attribute__((visibility("default"))) int kpb_val_keypoints(
     if (max_m == 0 || max_n == 0) return KPB_OK;
     if (!k0_dev || !k01_dev || !k1_dev || !k10_dev || !out_errors_dev || (cap && (!out_pairs_dev || !out_dist_dev)))
         return kpb_fail(ctx, KPB_E_INVALID, "kpb_val_keypoints: null buffer");
-    const size_t words = (size_t)batch * (2 * (size_t)max_m + max_n + 1);
+    const size_t cells = (size_t)batch * max_m * max_n;
+    const bool store = cells * 4 <= ((size_t)4 << 30);             // the cells are kept when they fit 4 GB (256 pairs of 2000 x 2000)
+    const size_t words = (size_t)batch * (2 * (size_t)max_m + max_n + 1) + (store ? cells + 64 : 0);
     if (int rc = kpb_reserve(ctx, ctx->ws_misc, words * 4)) return rc;
     float* rmin = (float*)ctx->ws_misc.p;
     float* cmin = rmin + (size_t)batch * max_m;
     int32_t* cnt = (int32_t*)(cmin + (size_t)batch * max_n);
     unsigned* dmax = (unsigned*)(cnt + (size_t)batch * max_m);
     KPB_HIP(ctx, hipMemsetAsync(dmax, 0, (size_t)batch * 4, ctx->stream));
+    float* dm = store ? reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(dmax + batch) + 255) & ~(uintptr_t)255) : nullptr;
     ValArgs a{k0_dev, k01_dev, k1_dev, k10_dev, max_m, max_n, m_dev, n_dev, scale_dev, th, rmin, cmin, dmax, cnt,
-              out_pairs_dev, out_dist_dev, cap, out_errors_dev, out_counts_dev};
-    KPB_LAUNCH(ctx, "covis_stats", covis_stats, dim3(cdiv(max_m + max_n, 4), batch), dim3(256), 0, ctx->stream, a);
+              out_pairs_dev, out_dist_dev, cap, out_errors_dev, out_counts_dev, dm};
+    KPB_LAUNCH(ctx, "covis_stats", covis_stats, dim3(cdiv(max_m + (store ? 0 : max_n), 4), batch), dim3(256), 0, ctx->stream, a);
+    if (store) KPB_LAUNCH(ctx, "covis_colmin", covis_colmin, dim3(cdiv(max_n, 256), batch), dim3(256), 0, ctx->stream, a);
     KPB_LAUNCH(ctx, "covis_count", covis_mutual<false>, dim3(cdiv(max_m, 4), batch), dim3(256), 0, ctx->stream, a);
     KPB_LAUNCH(ctx, "covis_scan", covis_scan, dim3(batch), dim3(1024), 0, ctx->stream, a);
     KPB_LAUNCH(ctx, "covis_emit", covis_mutual<true>, dim3(cdiv(max_m, 4), batch), dim3(256), 0, ctx->stream, a);
