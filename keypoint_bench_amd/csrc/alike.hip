@@ -642,9 +642,6 @@ struct Block2Args {
 };
 
 
-#ifndef B2_C1_UNROLL
-#define B2_C1_UNROLL 1
-#endif
 __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.7 KB of LDS = four workgroups per CU: the allocator stays at 128 registers
 {
     // All three products are taken transposed (weights as the MFMA's A operand, the input pieces as B: see alike_block1_h): the
@@ -735,7 +732,7 @@ __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.
             const uint4* q2 = has2 ? &pin[(y0 + 2) * PW + xl + 2] : zp;
             const int st2 = has2 ? 2 * PW : 0, lo2 = has2 ? NP : 0;
             int h8 = (((g >> 1) * NM + y0 * MW + xl) << 1) + (g & 1);
-#pragma unroll B2_C1_UNROLL
+#pragma unroll 1      // (unrolled by two the allocator needs 142 registers, or 128 and 48 bytes of scratch: 2.02 -> 2.60 ms)
             for (int it = 0; it < 2 * MH / 4; ++it, q0 += 2 * PW, q1 += 2 * PW, q2 += st2, h8 += 4 * MW) {
                 f32x4v acc = {0.f, 0.f, 0.f, 0.f};
                 const h8v i0h = __builtin_bit_cast(h8v, q0[0]), i0l = __builtin_bit_cast(h8v, q0[NP]);
