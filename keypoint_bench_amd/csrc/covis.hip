@@ -253,6 +253,7 @@ __global__ __launch_bounds__(256) void covis_stats(ValArgs a)
         const float2 a0 = k0[i], a01 = k01[i];
         float lo = INFINITY, hi = 0.f;
         float* row = a.dm ? a.dm + ((size_t)b * a.max_m + i) * a.max_n : nullptr;
+#pragma unroll 4            // four column blocks' coordinates in flight (rolled, every block of 64 cells waited for its own two loads)
         for (int j = lane; j < N; j += 64) {
             const float d = dm_cell(a0, a01, k1[j], k10[j], i, j, nd);
             if (row) row[j] = d;
