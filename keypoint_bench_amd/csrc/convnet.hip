@@ -646,7 +646,14 @@ __global__ void instnorm_params(const double* stats, size_t P, float2* mr, int B
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= B) return;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < XF_STAT_BLOCKS; ++k) { s += stats[((size_t)b * XF_STAT_BLOCKS + k) * 2]; q += stats[((size_t)b * XF_STAT_BLOCKS + k) * 2 + 1]; }
+    for (int k0 = 0; k0 < XF_STAT_BLOCKS; k0 += 16) {      // block order, sixteen partial pairs in flight
+        double2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const double2*>(stats + ((size_t)b * XF_STAT_BLOCKS + k0 + k) * 2);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s += v[k].x; q += v[k].y; }
+    }
+    static_assert(XF_STAT_BLOCKS % 16 == 0, "instnorm_params folds sixteen partials at a time");
     const double mean = s / (double)P;
     const double var = fmax(q / (double)P - mean * mean, 0.0);
     mr[b] = make_float2((float)mean, 1.0f / sqrtf((float)var + 1e-5f));
@@ -1228,7 +1235,13 @@ __global__ void make_xf(const double* part, int nblk, const float* slope, float*
     if (i >= n) return;
     const int b = i / C, c = i - b * C;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < nblk; ++k) { const double* o = part + (((size_t)b * nblk + k) * C + c) * 2; s += o[0]; q += o[1]; }      // block order: the same sum every run
+    for (int k0 = 0; k0 < nblk; k0 += 16) {          // block order: the same sum every run; sixteen partial pairs requested before the first is added
+        double2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = k0 + k < nblk ? *reinterpret_cast<const double2*>(part + (((size_t)b * nblk + k0 + k) * C + c) * 2) : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { s += v[k].x; q += v[k].y; }
+    }
     const double mean = s / (double)P;
     const double var = fmax(q / (double)P - mean * mean, 0.0);
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
