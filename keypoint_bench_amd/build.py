@@ -27,8 +27,11 @@ SOURCES = ["api.hip", "detect.hip", "match.hip", "net_api.hip", "alike.hip", "co
 # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary vector registers.  gfx950's register file is unified, so accumulation
 # registers buy no occupancy, and every value that crosses between them and the vector ALUs costs a v_accvgpr_read / _write: 240 of
 # them in lg_flash_h (192 -> 145 registers without), 24 in alike_block2, 8 in alike_block1_h (r03, found in the ISA).
+# -ffile-prefix-map: the objects record the sources as ./keypoint_bench_amd/csrc/..., not by absolute path -- the library's hash (config.build.lib_sha256
+# of every bench line) is then the same wherever the commit is checked out and built (r05)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-result", "-fvisibility=hidden", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+         "-Wall", "-Wno-unused-result", "-fvisibility=hidden", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
+         "-ffile-prefix-map=%s=." % os.path.dirname(HERE)]
 ARCH = "gfx950"
 
 
@@ -77,6 +80,9 @@ def compile_unit(src, obj, flags=FLAGS, verbose=False, fixup=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
+    # -cuid: the compilation-unit id clang derives from the ABSOLUTE source path by default (it names the module's registration symbols) -- a fixed
+    # one per translation unit keeps the library's hash independent of where the tree is checked out; device and host halves must agree on it
+    flags = list(flags) + ["-cuid=kpb_" + os.path.splitext(os.path.basename(src))[0]]
     run(["hipcc"] + flags + ["-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", stem + ".s", src])
     with open(stem + ".s") as f:
         text = f.read()

@@ -414,7 +414,10 @@ __global__ __launch_bounds__(256) void alike_block1_h(Block1HArgs ha)
         const int gy = ty0 + row;
         const float4 v = make_float4(relu(fmaf(acc[0], un2, bias2.x)), relu(fmaf(acc[1], un2, bias2.y)), relu(fmaf(acc[2], un2, bias2.z)), relu(fmaf(acc[3], un2, bias2.w)));
         if (gy < a.H && gx < a.W) {
-            *reinterpret_cast<float4*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8 + c0) = v;
+            {   // non-temporal: x1 is read again only by the head, four kernels later (r05: 2.21 -> 2.16 ms; the same hint on block 2's a2 stores changes nothing)
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(a.x1 + ((size_t)b * P + (size_t)gy * a.W + gx) * 8 + c0));
+            }
             xmax = kpb_pmax(kpb_pmax(xmax, kpb_pmax(v.x, v.y)), kpb_pmax(v.z, v.w));      // (x1 >= 0: integer maxima)
         }
         if ((rr & 1) == 0) {
