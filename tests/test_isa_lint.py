@@ -131,3 +131,15 @@ def test_a_kernel_that_spills_vector_registers_is_a_finding(tmp_path):
     assert [e[0] for e in errors] == ["E4"] and "40 vector registers" in errors[0][2], errors
     s.write_text(_KERNEL % "\tv_mov_b32_e32 v40, v41" + meta % (3872, 0))          # private arrays without spills (the RANSAC solvers) are fine
     assert not isa_lint.lint([str(s)], check_sources=False, verbose=False)[0]
+
+
+def test_the_library_hash_does_not_depend_on_the_checkout_path():
+    """config.build.lib_sha256 names a COMMIT: build.py maps the sources' absolute paths away and gives every translation unit a fixed compilation-unit
+    id (clang derives one from the absolute path otherwise).  Building the tree twice at two paths is a minute of hipcc -- profiles/README.md records
+    that it was done; here the two flags are pinned and the shipped library is checked to carry no absolute path of this checkout."""
+    assert any(f.startswith("-ffile-prefix-map=") and f.endswith("=.") for f in build.FLAGS)
+    import inspect
+    assert '"-cuid=kpb_"' in inspect.getsource(build.compile_unit)
+    so = build.build()
+    blob = open(so, "rb").read()
+    assert os.path.join(ROOT, "keypoint_bench_amd", "csrc").encode() not in blob
