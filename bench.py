@@ -124,8 +124,10 @@ def build_identity():
     box has no .git) and, where git is at hand, the tree's own HEAD."""
     import hashlib
     import subprocess
-    so = os.path.join(ROOT, "keypoint_bench_amd", "libkpb.so")
+    so = os.environ.get("KPB_LIB_PATH") or os.path.join(ROOT, "keypoint_bench_amd", "libkpb.so")      # the library _lib.load() takes
     out = {"lib_sha256": None, "lib_mtime": None, "built_from": None, "tree_head": None}
+    if os.environ.get("KPB_LIB_PATH"):
+        out["lib_path_override"] = so        # a measurement build, not the tree's library: built_from below does not describe it
     try:
         out["lib_sha256"] = hashlib.sha256(open(so, "rb").read()).hexdigest()[:12]
         out["lib_mtime"] = time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(so)))
@@ -134,6 +136,12 @@ def build_identity():
     try:
         out["built_from"] = json.load(open(os.path.join(ROOT, "keypoint_bench_amd", "_obj", "build_info.json")))
     except (OSError, ValueError):
+        pass
+    try:        # do the sources in this tree hash to what the library says it was built from?  (build.source_hash: csrc/ + kpb.h + build.py + isa_fixup.py)
+        from keypoint_bench_amd import build as kbuild
+        out["src_sha256_tree"] = kbuild.source_hash()
+        out["lib_matches_sources"] = bool(out["built_from"]) and out["built_from"].get("src_sha256") == out["src_sha256_tree"]
+    except Exception:
         pass
     try:
         r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=10)
@@ -145,7 +153,8 @@ def build_identity():
 
 def timed_steps(run, steps, warmup, dev, use_dist, dist=None):
     """The contract's timed region: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by synchronize + barrier on both sides,
-    MAX over ranks.  Returns (seconds, seconds of the last half or None): the second figure comes from two events on the launch stream
+    MAX over ranks.  Returns (seconds, seconds of the last half or None, THIS rank's own seconds -- its steps up to its own synchronisation,
+    before the barrier: the MAX hides which rank is slow, `per_rank_figures` gathers these); the second figure comes from two events on the launch stream
     (no extra synchronisation inside the region) and is what the chip SUSTAINS -- a 20-step run right after an idle period reads ~3 %
     faster than the state an uninterrupted stream settles into.  `run()` performs one step; on a CPU device (the
     gloo test) the events are perf_counter stamps."""
@@ -177,6 +186,9 @@ def timed_steps(run, steps, warmup, dev, use_dist, dist=None):
     if ev:
         ev[1].record(torch.cuda.current_stream(dev))
     t_own = time.perf_counter()         # this rank's own end (the CPU stand-in of the second event)
+    if cuda:
+        torch.cuda.synchronize(dev)
+    own = time.perf_counter() - t0      # this rank alone: its K steps to its own synchronisation, no barrier
     barrier()
     elapsed = time.perf_counter() - t0
     tail = None
@@ -186,7 +198,21 @@ def timed_steps(run, steps, warmup, dev, use_dist, dist=None):
         t = torch.tensor([elapsed, tail if tail is not None else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, tail = float(t[0].item()), (float(t[1].item()) if tail is not None else None)
-    return elapsed, tail
+    return elapsed, tail, own
+
+
+def per_rank_figures(own_ms_per_step, kernel_ms, world, use_dist, dist=None, dev=None):
+    """[{rank, ms_per_step, dominant_kernel_ms}] of every rank, on every rank: one all-gather of two floats per rank (outside the timed region).
+    `value` is computed from the MAX over ranks; this says which rank that was and whether its dominant kernel or something else was slow."""
+    import torch
+    if not use_dist:
+        return [{"rank": 0, "ms_per_step": round(own_ms_per_step, 3), "dominant_kernel_ms": round(kernel_ms, 4) if kernel_ms else None}]
+    mine = torch.tensor([own_ms_per_step, kernel_ms or 0.0], dtype=torch.float64, device=dev)
+    allv = torch.empty((world * 2,), dtype=torch.float64, device=dev)      # flat: rank r's two figures at [2 r, 2 r + 2) (the concatenating form gloo takes too)
+    dist.all_gather_into_tensor(allv, mine)
+    allv = allv.view(world, 2)
+    return [{"rank": r, "ms_per_step": round(float(allv[r, 0]), 3), "dominant_kernel_ms": round(float(allv[r, 1]), 4) if float(allv[r, 1]) else None}
+            for r in range(world)]
 
 
 def exchange_rows(rows, world, use_dist, dist=None):
@@ -430,7 +456,7 @@ def main():
     sel = [i % nd for i in range(B)]
     images = torch.from_numpy(np.stack([v0s[i] for i in sel] + [v1s[i] for i in sel])).to(dev).contiguous()
 
-    elapsed, tail = timed_steps(lambda: pipe.run(images), args.steps, args.warmup, dev, use_dist, dist)
+    elapsed, tail, own = timed_steps(lambda: pipe.run(images), args.steps, args.warmup, dev, use_dist, dist)
     value = world * B * args.steps / elapsed
     value_sustained = (world * B * (args.steps - args.steps // 2) / tail) if tail else None
 
@@ -444,7 +470,7 @@ def main():
     variant = None
     if args.model == "alike" and not args.sparse and args.matcher == "brute_force" and not args.no_variants:
         pipe2 = PairPipeline(alike_t(dense_descriptors=False).eval(), EXTRACTOR, BRUTE_FORCE, B, H, W, device=dev)
-        e2, _ = timed_steps(lambda: pipe2.run(images), args.steps, args.warmup, dev, use_dist, dist)
+        e2, _, _ = timed_steps(lambda: pipe2.run(images), args.steps, args.warmup, dev, use_dist, dist)
         same = bool(torch.equal(pipe2.k, pipe.k) and torch.equal(pipe2.pairs[:, :16], pipe.pairs[:, :16]))
         variant = {"descriptors": "keypoint-only", "value": round(world * B * args.steps / e2, 2), "unit": "pairs/s",
                    "ms_per_step": round(1e3 * e2 / args.steps, 3), "same_matches_as_dense": same}
@@ -453,12 +479,20 @@ def main():
     # roofline leg: per-kernel durations from HIP events on the launch stream, same workload
     roof = None
     ctx = pipe.ctx
+    # r06: two untimed steps first, then ten profiled ones.  The first step after the host-side pause that precedes this leg (row exchange, the
+    # variant's set-up) runs its big kernels 5-7 % slower (kernel trace: the head 9.89 ms, then 9.21, 9.24) -- with r05's three profiled steps and no
+    # warm-up that one launch put `avg_ms` 2.4 % above the kernel-trace average of the same process (profiles/r06_head_modes.txt)
+    for _ in range(2):
+        pipe.run(images)
     ctx.prof_enable(True)
-    prof_steps = 3
+    prof_steps = 10
     for _ in range(prof_steps):
         pipe.run(images)
     prof = ctx.prof_report()
     ctx.prof_enable(False)
+    # every rank's own step time and the average of ITS dominant kernel: gathered, reported under quality.per_rank
+    dom = max(prof, key=lambda k: prof[k][1]) if prof else None
+    per_rank = per_rank_figures(1e3 * own / args.steps, (prof[dom][1] / prof[dom][0]) if dom else None, world, use_dist, dist, dev)
     if rank == 0 and prof:
         sweeps = prof.get("nms_sweep", (1, 0))[0] / prof_steps
         costs = kernel_costs(2 * B, B, EXTRACTOR["top_k"], net.dim, not args.sparse, sweeps)
@@ -497,12 +531,15 @@ def main():
                        "matcher": args.matcher, "lightglue_attention": (args.lg_attention if args.matcher == "lightglue" else None), "pairs_per_step_per_gpu": B, "descriptors": "keypoint-only" if args.sparse else "dense-map",
                        "weights": "alike-t (reference checkpoint, BN folded)" if args.model == "alike" else args.model + ", seeded random (checkpoint absent from the reference tree)", "parallelism": "pairs sharded, dp%d" % world,
                        "nms_reruns": pipe.reruns, "build": build_identity(), "world_size_seen": world_seen,
+                       # where the descriptor map lives was chosen by measurement (PairPipeline._place_map): the forward's time into each candidate allocation
+                       "placement": pipe.placement,
                        "arithmetic": ("strict fp32 (KPB_FP32_MATRIX=1): fp32 MFMA / fp32 vector ALUs, fp64 match" if strict_fp32() else
                                       "fp32 results; matrix products as split-f16 MFMA triples with fp32 accumulation (2^-22 per product), operands "
                                       "scaled per tile to the f16 window (no fixed range), fp64 match")},
             "quality": {"mean_kps": round(float(allrows[:, :2].mean()), 1), "mean_matches": round(float(allrows[:, 2].mean()), 1),
                         "pairs_gathered": int(allrows.shape[0]),
-                        "pairs_gathered_per_rank": [int((allrows[r * B:(r + 1) * B, 0] > 0).sum()) for r in range(world)]},
+                        "pairs_gathered_per_rank": [int((allrows[r * B:(r + 1) * B, 0] > 0).sum()) for r in range(world)],
+                        "per_rank": per_rank},
             "roofline": roof, "roofline_step": step_roofline(args.model, args.matcher, args.sparse, value / world),
             "cpu_baseline": cpu, "variant": variant, "variant_fp32": fp32,
         }

@@ -72,6 +72,14 @@ int kpb_ctx_set_stream(kpb_ctx* ctx, void* stream);
 void kpb_ctx_destroy(kpb_ctx* ctx);
 int kpb_sync(kpb_ctx* ctx);
 
+/* Limits of a context a caller may move (the reference has no counterpart: its tensors live wherever torch puts them).
+ *   KPB_OPT_COVIS_STORE_BYTES  kpb_val_keypoints keeps its M x N distance cells (4 bytes each) in the context's workspace when they fit
+ *                              this many bytes (default 4 GiB) and re-evaluates them in every pass when they do not -- or when the
+ *                              workspace cannot grow; both forms give the same bits (tests/test_gpu_covis.py runs both).  0 = never keep.
+ * Returns KPB_E_INVALID for an unknown option or a negative value. */
+#define KPB_OPT_COVIS_STORE_BYTES 1
+int kpb_ctx_set_option(kpb_ctx* ctx, int option, int64_t value);
+
 /* Per-kernel timing for bench.py's roofline leg: when enabled every kernel launch is bracketed by two
  * HIP events on the context's stream.  kpb_prof_report synchronises, writes one text line per kernel
  * ("<name> <launches> <total_ms>\n") into buf and clears the records. */

@@ -4,7 +4,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libkpb.so")
+# KPB_LIB_PATH: another build of the library (the measurement-only knock-out builds of scripts/hack_build.py, an A/B partner) WITHOUT copying it over
+# the tree's own -- an interrupted script then cannot leave a hack build where the evidence runs look for the product
+SO_PATH = os.environ.get("KPB_LIB_PATH") or os.path.join(_HERE, "libkpb.so")
 
 c_int, c_float, c_double, c_void_p, c_int64, c_size_t = (ctypes.c_int, ctypes.c_float, ctypes.c_double,
                                                        ctypes.c_void_p, ctypes.c_int64, ctypes.c_size_t)
@@ -40,6 +42,7 @@ SIGNATURES = {
     "kpb_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "kpb_ctx_destroy": (None, [c_void_p]),
     "kpb_sync": (c_int, [c_void_p]),
+    "kpb_ctx_set_option": (c_int, [c_void_p, c_int, c_int64]),
     "kpb_prof_enable": (c_int, [c_void_p, c_int]),
     "kpb_prof_report": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
     "kpb_fast_nms": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -156,6 +159,12 @@ class Context:
 
     def sync(self):
         self.check(self.lib.kpb_sync(self.handle))
+
+    OPT_COVIS_STORE_BYTES = 1       # KPB_OPT_COVIS_STORE_BYTES
+
+    def set_option(self, option: int, value: int):
+        """kpb_ctx_set_option (include/kpb.h): a limit of this context, e.g. OPT_COVIS_STORE_BYTES."""
+        self.check(self.lib.kpb_ctx_set_option(self.handle, int(option), int(value)))
 
     def prof_enable(self, on: bool):
         self.check(self.lib.kpb_prof_enable(self.handle, 1 if on else 0))

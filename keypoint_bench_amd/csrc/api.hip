@@ -53,6 +53,16 @@ extern "C" __attribute__((visibility("default"))) int kpb_ctx_set_stream(kpb_ctx
     return KPB_OK;
 }
 
+extern "C" __attribute__((visibility("default"))) int kpb_ctx_set_option(kpb_ctx* ctx, int option, int64_t value)
+{
+    if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_ctx_set_option: null context");
+    if (value < 0) return kpb_fail(ctx, KPB_E_INVALID, "kpb_ctx_set_option: negative value");
+    switch (option) {
+    case KPB_OPT_COVIS_STORE_BYTES: ctx->covis_store_bytes = (size_t)value; return KPB_OK;
+    default: return kpb_fail(ctx, KPB_E_INVALID, "kpb_ctx_set_option: unknown option %d", option);
+    }
+}
+
 extern "C" __attribute__((visibility("default"))) int kpb_sync(kpb_ctx* ctx)
 {
     if (!ctx) return kpb_fail(nullptr, KPB_E_INVALID, "kpb_sync: null context");

@@ -42,12 +42,12 @@ struct ConvM {
     const float* aux1 = nullptr;
     float* out1 = nullptr;
     float* out2 = nullptr;
-    // conv_mfma_h<.., PRE> (r05): `in` holds the activations ALREADY SPLIT by the producing kernel -- per pixel and 32-channel slab 128 bytes
-    // = [4 x 16 B of hi halves | 4 x 16 B of lo halves], taken at the per-image power-of-two scale of cm_exp_of(amax_in l1 + bmax), a rigorous
-    // bound of the producer's output (amax_in: the producer's INPUT maximum, measured; l1 / bmax: its largest row L1 norm / |bias|), so the
-    // scale is known before the producer stores and the consumer lands raw bytes in its tile by LDS-DMA: no staging registers, no maximum
-    // pass, no split, one barrier per slab.  pre_zero: 128 zero bytes (the source of pixels outside the image).
-    const unsigned* pre_amax = nullptr; float pre_l1 = 0.0f, pre_bmax = 0.0f; const void* pre_zero = nullptr;
+    // conv_mfma_h<.., PRE, .., GEN>: the tile holds the generated activations ALREADY SPLIT -- per pixel and 32-channel slab 128 bytes = [4 x 16 B of hi
+    // halves | 4 x 16 B of lo halves], taken at the per-image power-of-two scale of cm_exp_of(amax_in l1 + bmax), a rigorous bound of the generated
+    // layer's output (amax_in: the maximum of ITS input, measured; l1 / bmax: its largest row L1 norm / |bias|): no maximum pass over the slab, one
+    // barrier per slab.  (r05 also had the producer as its own kernel writing this format to HBM and the consumer landing it by LDS-DMA: 2.10 -> 2.07 ms,
+    // profiles/r05_presplit_conv1b_ab.txt -- superseded by GEN and removed in r06, together with KPB_PRESPLIT.)
+    const unsigned* pre_amax = nullptr; float pre_l1 = 0.0f, pre_bmax = 0.0f;
     int unfold_w = 0;             // gemm_h<.., UNFOLD>: `in` is a single-channel [B][8 H][unfold_w] image and row r, channel c stand for pixel
                                   // (8 (r / W) + c / 8, 8 (r % W) + c % 8): XFeat's _unfold2d(x, 8) read in place (XFeat.py:96-103, 138)
 };
@@ -328,7 +328,7 @@ template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB =
 __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
     static_assert(WN == 1 || (WN == 2 && MT % 2 == 0 && !WPRE), "conv_mfma_h: waves split the n-tiles two ways at most");
-    static_assert(!GEN || (PRE && KS == 3), "conv_mfma_h: the generated input is a 3 x 3 layer in front of a pre-split one");
+    static_assert(PRE == GEN && (!GEN || KS == 3), "conv_mfma_h: the pre-split tile exists as the generated one (a 3 x 3 one-channel layer computed while staging); r05's DMA-landed form was measured, superseded and removed in r06");
     static_assert(!PRE || (CC == 32 && S == 1 && !POOL_IN && !XF && !XC && !WPRE), "conv_mfma_h: the pre-split input form exists for plain stride-1 32-channel slabs");
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT / WN;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
@@ -444,22 +444,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                         }
                     }
                 }
-            } else {
-            __syncthreads();                    // the previous slab's taps are done with the tile
-            const unsigned char* src0 = reinterpret_cast<const unsigned char*>(in) + (size_t)ch * 128;
-            const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(a.pre_zero) + (lane & 7) * 16;
-#pragma unroll 2
-            for (int u = wv; u < NU; u += 4) {
-                const int t = 8 * u + (lane >> 3);
-                const int y = t / IW, x = t - y * IW;
-                const int gy = iy0 + y, gx = ix0 + x;
-                const bool ok = t < NPIX && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc;
-                const int slot = (lane & 7) ^ ((x >> 1) & 7);
-                const unsigned char* src = ok ? src0 + ((size_t)gy * a.Wi + gx) * (size_t)(a.istride * 4) + slot * 16 : zsrc;
-                cm_dma16(src, tile + u * 1024);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }       // !GEN
         } else {
         float4 buf[NLD];
         float amax = 0.0f;

@@ -440,11 +440,9 @@ std::vector<float> pack_xf_s2(const float* w, int cout, float scale)
 
 // SuperPoint conv1a (1 -> 64, 3x3, ReLU; SuperPoint.py:44): 16 lanes share a pixel, each lane keeps the 9 taps of its
 // 4 output channels in registers and walks down a column of pixels, so a wave store is 4 whole 256-byte pixels.
-// pre (r05): when pre_amax is given the 64 channels leave ALREADY SPLIT for conv_mfma_h<.., PRE> -- per pixel two 128-byte slabs of
-// [4 x 16 B hi halves | 4 x 16 B lo halves] -- at the power-of-two scale of cm_exp_of(amax(gray) l1 + bmax), the bound of this layer's output
-// (ConvM::pre_amax); a thread's four channels are 8 bytes of a hi slot and 8 of the matching lo slot.
-__global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block,
-                                                  const unsigned* pre_amax, float pre_l1, float pre_bmax)
+// (The split-f16 path never launches it: conv1b generates these channels while it stages its tile, conv_mfma_h<.., GEN>; this kernel is the
+// strict-fp32 path's conv1a.)
+__global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out, const float* w /*[9][64]*/, const float* bias, int H, int W, int rows_per_block)
 {
     const int b = blockIdx.z, lane16 = threadIdx.x & 15, c4 = lane16 * 4;
     const int x = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -476,16 +474,6 @@ __global__ __launch_bounds__(256) void conv1a_c64(const float* gray, float* out,
                 acc[j] = fmaf(r1[k], wr[3 + k][j], acc[j]);
                 acc[j] = fmaf(r2[k], wr[6 + k][j], acc[j]);
             }
-        if (pre_amax) {
-            const float sc = cm_scale_of(cm_exp_of(fmaf(__uint_as_float(pre_amax[b]), pre_l1, pre_bmax)));
-            uint2 hi, lo;
-            cm_split4(make_float4(relu(acc[0]) * sc, relu(acc[1]) * sc, relu(acc[2]) * sc, relu(acc[3]) * sc), hi, lo);
-            unsigned char* px = reinterpret_cast<unsigned char*>(out + (((size_t)b * H + y) * W + x) * 64);
-            const int slab = c4 >> 5, c = c4 & 31;
-            unsigned char* d = px + slab * 128 + (c >> 3) * 16 + ((c >> 2) & 1) * 8;
-            *reinterpret_cast<uint2*>(d) = hi;
-            *reinterpret_cast<uint2*>(d + 64) = lo;
-        } else
         *reinterpret_cast<float4*>(out + (((size_t)b * H + y) * W + x) * 64 + c4) = make_float4(relu(acc[0]), relu(acc[1]), relu(acc[2]), relu(acc[3]));
 #pragma unroll
         for (int k = 0; k < 3; ++k) { r0[k] = r1[k]; r1[k] = r2[k]; r2[k] = r3[k]; }
@@ -720,7 +708,7 @@ struct Layer {      // one convolution of a network plan
     int ntb = 2;    // 32-wide output tiles per workgroup
 };
 
-struct PreSplit { const unsigned* amax = nullptr; float l1 = 0.0f, bmax = 0.0f; const void* zero = nullptr; const float* gen_w = nullptr; const float* gen_b = nullptr; };     // ConvM::pre_*, gen_*
+struct PreSplit { const unsigned* amax = nullptr; float l1 = 0.0f, bmax = 0.0f; const float* gen_w = nullptr; const float* gen_b = nullptr; };     // ConvM::pre_*, gen_*
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
                 bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f, const float2* unfold_mr = nullptr,
@@ -746,14 +734,12 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         // one-tile layers (cout <= 32) are bound by per-workgroup latency: 8-row tiles (one M tile per wave, 28 KB of LDS, five
         // workgroups per CU) measured 8-16 % faster; layers with two output tiles lose the fragment reuse that way (+8 % time)
         if (pre) {      // the input arrives already split (ConvM::pre_amax): raw bytes land in the tile by LDS-DMA
-            a.pre_amax = pre->amax; a.pre_l1 = pre->l1; a.pre_bmax = pre->bmax; a.pre_zero = pre->zero;
+            a.pre_amax = pre->amax; a.pre_l1 = pre->l1; a.pre_bmax = pre->bmax;
             if (pre->gen_w && L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2) {
                 a.gen_w = pre->gen_w; a.gen_b = pre->gen_b; a.istride = 1;         // `in` is the one-channel image the layer in front reads
                 KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, true, 2, true>), g2, block, 0, st, a);
             }
-            else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x && L.ntb == 2)
-                KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, true, 2>), g2, block, 0, st, a);
-            else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no pre-split instance for %s", L.name.c_str());
+            else return kpb_fail(ctx, KPB_E_INVALID, "conv_mfma_h: no generated-input instance for %s", L.name.c_str());
             return KPB_OK;
         }
         if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && L.ntb == 1) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 1>), g1, block, 0, st, a);
@@ -852,8 +838,7 @@ void stage_layer(WeightStage& ws, const Layer& L, const float* w, const float* b
 // ================================================================================================ SuperPoint
 struct SuperPointNet : kpb_net {
     std::map<std::string, Layer> L;
-    kpb_buf aux;                    // per-image maxima of the grey image + 128 zero bytes (the pre-split path)
-    const void* aux_zeroed = nullptr;
+    kpb_buf aux;                    // per-image maxima of the grey image (the scale conv1b's generated input is split at)
     ~SuperPointNet() override { if (aux.p) (void)hipFree(aux.p); }
     int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
     {
@@ -883,25 +868,20 @@ struct SuperPointNet : kpb_net {
         hipStream_t st = ctx->stream;
         KPB_LAUNCH(ctx, "sp_rgb_sum", rgb_sum, dim3((unsigned)((P + 255) / 256), batch), dim3(256), 0, st, img, gray, P);
         int rc;
-        // r05: conv1a hands conv1b its 64 channels ALREADY SPLIT (ConvM::pre_amax), at the scale of the bound amax(gray) l1 + bmax of its
-        // own output -- known before it stores, so conv1b's tile is filled by LDS-DMA with no staging arithmetic (KPB_PRESPLIT=0: the r04 path)
-        // KPB_PRESPLIT=2 (r05, default): conv1a is not launched at all -- conv1b computes its channels from the gray image while it stages its tile
-        static const int presplit = kpb_env_int("KPB_PRESPLIT", 2);
-        const bool fused = presplit == 2 && conv_mfma_use_h16();
-        const bool pre = fused || (presplit && conv_mfma_use_h16() && (W % 4) == 0);
+        // conv1a (:44) is not launched on the split-f16 path: conv1b computes its channels from the gray image while it stages its tile
+        // (conv_mfma_h<.., GEN>, r05), split at the scale of the bound amax(gray) l1 + bmax of conv1a's output.  r05's two earlier forms -- conv1a as
+        // its own kernel handing over fp32 or pre-split halves, KPB_PRESPLIT=0 / 1 -- were measured, superseded and removed (r06).
+        const bool fused = conv_mfma_use_h16();
         PreSplit ps;
-        if (pre) {
-            if ((rc = kpb_reserve(ctx, aux, (size_t)batch * sizeof(unsigned) + 256))) return rc;
+        if (fused) {
+            if ((rc = kpb_reserve(ctx, aux, (size_t)batch * sizeof(unsigned)))) return rc;
             unsigned* amax_gray = static_cast<unsigned*>(aux.p);
-            unsigned char* zero = reinterpret_cast<unsigned char*>(aux.p) + (((size_t)batch * sizeof(unsigned) + 127) / 128) * 128;
-            if (aux_zeroed != aux.p) { KPB_HIP(ctx, hipMemsetAsync(aux.p, 0, aux.cap, st)); aux_zeroed = aux.p; }     // (re-)allocated: the zero pixel must be zero
             KPB_LAUNCH(ctx, "sp_gray_amax", plane_abs_max, dim3(batch), dim3(1024), 0, st, gray, P, amax_gray);
-            ps.amax = amax_gray; ps.l1 = wscale.at("conv1a.l1"); ps.bmax = wscale.at("conv1a.bmax"); ps.zero = zero;
-        }
-        if (fused) { ps.gen_w = wp("conv1a.w"); ps.gen_b = wp("conv1a.b"); }
-        else KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32,
-                        ps.amax, ps.l1, ps.bmax);   // :44
-        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], fused ? gray : x1a, x1b, batch, H, W, false, true, true, nullptr, 0, 0.0f, nullptr, pre ? &ps : nullptr))) return rc;      // :45-46 (+pool)
+            ps.amax = amax_gray; ps.l1 = wscale.at("conv1a.l1"); ps.bmax = wscale.at("conv1a.bmax");
+            ps.gen_w = wp("conv1a.w"); ps.gen_b = wp("conv1a.b");
+        } else
+            KPB_LAUNCH(ctx, "sp_conv1a", conv1a_c64, dim3(cdiv(W, 16), cdiv(H, 32), batch), dim3(256), 0, st, gray, x1a, wp("conv1a.w"), wp("conv1a.b"), H, W, 32);   // :44
+        if ((rc = launch_mfma(ctx, "sp_conv1b", this, L["conv1b"], fused ? gray : x1a, x1b, batch, H, W, false, true, true, nullptr, 0, 0.0f, nullptr, fused ? &ps : nullptr))) return rc;      // :45-46 (+pool)
         if ((rc = launch_mfma(ctx, "sp_conv2a", this, L["conv2a"], x1b, x2a, batch, H / 2, W / 2, false, false, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv2b", this, L["conv2b"], x2a, x2b, batch, H / 2, W / 2, false, true, true))) return rc;
         if ((rc = launch_mfma(ctx, "sp_conv3a", this, L["conv3a"], x2b, x3a, batch, H / 4, W / 4, false, false, true))) return rc;

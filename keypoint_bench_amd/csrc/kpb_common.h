@@ -160,6 +160,7 @@ struct kpb_ctx {
     // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to the (function, device) pair: remembered per CONTEXT (= per device),
     // not in a process-wide static that a second device would find already set
     unsigned lds_attr_done = 0;
+    size_t covis_store_bytes = (size_t)4 << 30;     // KPB_OPT_COVIS_STORE_BYTES (kpb_ctx_set_option)
 };
 enum { KPB_ATTR_NMS = 1u, KPB_ATTR_HOMOGRAPHY = 2u, KPB_ATTR_ESSENTIAL = 4u, KPB_ATTR_FUNDAMENTAL = 8u };
 
@@ -220,6 +221,9 @@ inline int kpb_reserve(kpb_ctx* ctx, kpb_buf& b, size_t bytes)
         return kpb_fail(ctx, KPB_E_NOMEM, "workspace allocation of %zu bytes failed", want);
     }
     b.cap = want;
+    // KPB_LOG_ALLOC=1: where each workspace landed (scripts/head_modes.py reads these lines: placement against the caller's buffers)
+    static const bool log_alloc = getenv("KPB_LOG_ALLOC") && *getenv("KPB_LOG_ALLOC") == '1';
+    if (log_alloc) fprintf(stderr, "kpb_alloc %p %zu\n", b.p, want);
     return KPB_OK;
 }
 

@@ -65,6 +65,17 @@ def parse_packed(line):
     return indent, mnem, ops, mods, other, (sep + comment if sep else "")
 
 
+_PK_LOOSE = re.compile(r"^\s*v_pk_(?:mul|add|fma)_f32\b")
+
+
+def is_unparsed(line):
+    """True for a line that IS one of the three instructions but that parse_packed cannot take apart (another assembler's modifier spelling,
+    an operand count other than 2 or 3): neither the rewrite nor the lint may pass such a line silently -- the library's determinism must not
+    hang on the disassembler's text syntax staying what it is."""
+    code = line.partition(";")[0]
+    return bool(_PK_LOOSE.match(code)) and parse_packed(line) is None
+
+
 def is_affected(line):
     p = parse_packed(line)
     return bool(p) and p[3]["op_sel"][0] == 0 and p[3]["op_sel"][1] == 1
@@ -94,6 +105,8 @@ def fix_text(asm_text):
     """(fixed text, number of instructions rewritten)."""
     out, n = [], 0
     for line in asm_text.split("\n"):
+        if is_unparsed(line):
+            raise ValueError("isa_fixup: cannot parse the packed-fp32 instruction %r -- refusing to pass it through unchecked" % line.strip())
         new = fix_line(line)
         n += new is not line and new != line
         out.append(new)

@@ -14,9 +14,19 @@ import torch
 from ._lib import Context, DetectParams, MatchParams, ptr
 
 
+PLACE_MIN_BYTES = 4 << 30       # descriptor maps below this are not worth placing (their forward is not bound by the map's stores)
+PLACE_CANDIDATES = 4            # allocations compared (the first included), as far as free memory allows
+PLACE_HEADROOM = 12 << 30       # bytes that must stay free while the candidates exist (workspaces of the first forward, the caller's tensors)
+
+
 class PairPipeline:
-    def __init__(self, net, extractor_params, brute_force_params, batch, H, W, device="cuda:0", lightglue=None, match=True):
-        """match=False stops after detection (the repeatability task never matches: tasks/repeatability.py:95-122)."""
+    def __init__(self, net, extractor_params, brute_force_params, batch, H, W, device="cuda:0", lightglue=None, match=True, place_map=None):
+        """match=False stops after detection (the repeatability task never matches: tasks/repeatability.py:95-122).
+        place_map: choose WHERE the dense descriptor map lives by measurement at the first run (`_place_map`); None = on unless
+        KPB_PLACE_MAP=0 (a host-side knob of this class: the library allocates nothing of the caller's)."""
+        import os
+        self.place_map = (os.environ.get("KPB_PLACE_MAP", "1") != "0") if place_map is None else bool(place_map)
+        self.placement = None       # the record of that choice (bench.py prints it in config.placement)
         self.net, self.B, self.H, self.W = net, int(batch), int(H), int(W)
         self.match = bool(match)
         self.device = torch.device(device)
@@ -58,6 +68,54 @@ class PairPipeline:
             self.lg_stop = torch.empty((self.B,), dtype=i32, device=dev)
         net._ensure(self.device)
 
+    def _place_map(self, images):
+        """Where the descriptor map's pages are decides how fast the dense head stores it -- a property of the ALLOCATION, found in r06
+        (profiles/r06_head_modes.txt): on one box, one library, the head takes 9.12 / 9.40 / 9.65 ms per 512 images depending on which
+        40 GB allocation it writes, the same figure every time for the same allocation, whatever the process does otherwise (RCCL
+        initialised or not, under rocprofv3 or not, any offset inside the allocation, any virtual alignment), while plain streaming
+        fills and reads of those buffers run at equal rates -- it is the head's pattern (768 workgroups, each storing 16 KB row pieces
+        160 KB apart) against the physical placement the driver chose.  Successive processes alternate between regions, which is
+        what r05 read as "two time modes".  The pipeline owns this buffer, so it chooses: up to PLACE_CANDIDATES allocations side by
+        side (as far as free memory allows), the network's own forward timed into each (what the map is for; two forwards after one
+        warm-up, events on the launch stream), the fastest kept, the others returned to the driver.  Costs about 0.3 s once per
+        pipeline; results are untouched (the same kernels write the same values wherever the buffer is)."""
+        self.place_map = False
+        if self.desc is None or self.desc.numel() * 4 < PLACE_MIN_BYTES:
+            return
+        ctx, L, net = self.ctx, self.ctx.lib, self.net
+        nbytes = self.desc.numel() * 4
+        B2, H, W = 2 * self.B, self.H, self.W
+
+        def forward_ms(buf):
+            best = None
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.device))
+                ctx.check(L.kpb_net_forward(net._handle, ptr(images), B2, H, W, ptr(self.score), ptr(buf)))
+                e1.record(torch.cuda.current_stream(self.device))
+                e1.synchronize()
+                if rep:
+                    t = e0.elapsed_time(e1)
+                    best = t if best is None else min(best, t)
+            return best
+
+        cands, times, c = [self.desc], [], None
+        times.append(forward_ms(self.desc))          # the first forward also allocates the network's workspaces: measure free memory after it
+        while len(cands) < PLACE_CANDIDATES and torch.cuda.mem_get_info(self.device)[0] >= nbytes + PLACE_HEADROOM:
+            try:
+                c = torch.empty_like(self.desc)
+            except torch.OutOfMemoryError:
+                break
+            cands.append(c)
+            times.append(forward_ms(c))
+        best = min(range(len(cands)), key=lambda i: times[i])
+        self.desc = cands[best]
+        self.placement = {"candidates": len(cands), "forward_ms": [round(t, 3) for t in times], "chosen": best,
+                          "map_bytes": nbytes, "ptr_mod_2MiB": self.desc.data_ptr() % (2 << 20)}
+        del cands, c
+        torch.cuda.synchronize(self.device)
+        torch.cuda.empty_cache()                     # the losers go back to the driver, not into torch's cache
+
     def enqueue(self, images, covis=None):
         """images [2B, 3, H, W]: rows 0..B-1 are image0 of each pair, rows B..2B-1 image1.
         covis = (hmat [2B, 9], wh [2B, 2] int32): the MHA flow (tasks/MHA.py:30-39) -- keypoints are filtered by the
@@ -68,6 +126,8 @@ class PairPipeline:
         B, B2, K, C, H, W = self.B, 2 * self.B, self.top_k, self.C, self.H, self.W
         assert images.shape == (B2, 3, H, W) and images.is_contiguous() and images.dtype == torch.float32
         self._covis = covis
+        if self.place_map:
+            self._place_map(images)
         ctx.check(L.kpb_net_forward(net._handle, ptr(images), B2, H, W, ptr(self.score), ptr(self.desc)))
         net._forward_count += 1
         ctx.check(L.kpb_detect(ctx.handle, ptr(self.score), B2, H, W, ctypes.byref(self.dprm), ptr(self.kps),

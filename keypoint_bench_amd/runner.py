@@ -184,7 +184,10 @@ def is_decoded_u8(v):
 def as_image(v, device):
     """Dataset items hold numpy arrays [C,H,W] (datasets/hpatches.py:74-83: no DataLoader collation here) or tensors;
     a uint8 [H,W,3] array is a decoded image and gets the datasets' transform (RGB order kept, / 255, HWC -> CHW:
-    megadepth.py:312-313 ToTensor) on the device."""
+    megadepth.py:312-313 ToTensor) on the device.  A datasets.RawImage (a located, unread .ppm) is read here."""
+    from .datasets import RawImage
+    if isinstance(v, RawImage):
+        v = np.asarray(v)
     if is_decoded_u8(v):
         from .utils.preprocess import to_tensor_resized
         return to_tensor_resized(v, device=device)[0]
@@ -195,8 +198,10 @@ def as_image(v, device):
 
 
 def _host_array(v):
-    """numpy view of a host-resident image (numpy array or CPU tensor), None for anything already on a device."""
-    if isinstance(v, np.ndarray):
+    """numpy view of a host-resident image (numpy array or CPU tensor; a datasets.RawImage stands for the uint8 array it will be read
+    as), None for anything already on a device."""
+    from .datasets import RawImage
+    if isinstance(v, (np.ndarray, RawImage)):
         return v
     if torch.is_tensor(v) and not v.is_cuda:
         return v.detach().numpy()
@@ -207,6 +212,8 @@ def crop32_host(a):
     """crop32 for host arrays: float [.., H, W] or decoded uint8 [H, W, 3]."""
     if is_decoded_u8(a):
         H, W = a.shape[:2]
+        if hasattr(a, "read_into"):         # datasets.RawImage: the crop is remembered and applied by the read
+            return a.crop(H - H % 32, W - W % 32)
         return a[: H - H % 32, : W - W % 32]
     return crop32(a)
 
@@ -254,9 +261,17 @@ class HostStager:
             warnings.warn("HostStager.release() with no slot out: slot accounting error in the caller", RuntimeWarning, stacklevel=2)
 
     def fill(self, pinned, arrays):
-        """pinned[j] <- arrays[j] for every j, in parallel."""
+        """pinned[j] <- arrays[j] for every j, in parallel.  A datasets.RawImage (HPatches' .ppm, located but unread) is READ into its
+        row: the file's bytes land in pinned memory with no array in between."""
         dst = pinned.numpy()
-        list(self.pool.map(lambda ja: np.copyto(dst[ja[0]], ja[1].reshape(dst.shape[1:])), enumerate(arrays)))
+
+        def one(ja):
+            j, a = ja
+            if hasattr(a, "read_into"):
+                a.read_into(dst[j])
+            else:
+                np.copyto(dst[j], a.reshape(dst.shape[1:]))
+        list(self.pool.map(one, enumerate(arrays)))
 
     def close(self):
         self.pool.shutdown(wait=True)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of two BUILDS of libkpb.so on one box: scripts/ab_lib.sh base.so new.so [bench args] (three interleaved runs each)
+# A/B of two BUILDS of libkpb.so on one box: scripts/ab_lib.sh base.so new.so [bench args] (three interleaved runs each; loaded through KPB_LIB_PATH, the tree's library is never overwritten)
 base=$1; new=$2; shift 2
 for rep in 1 2 3; do
   for v in base new; do
-    if [ $v = base ]; then cp $base keypoint_bench_amd/libkpb.so; else cp $new keypoint_bench_amd/libkpb.so; fi
-    python bench.py --no-cpu-baseline --no-variants --distinct 32 "$@" > gpurun_out/abl_${v}_$rep.json 2> gpurun_out/abl_${v}_$rep.err || { echo "run failed: $v"; tail -5 gpurun_out/abl_${v}_$rep.err; exit 1; }
+    if [ $v = base ]; then lib=$base; else lib=$new; fi
+    KPB_LIB_PATH=$(realpath $lib) python bench.py --no-cpu-baseline --no-variants --distinct 32 "$@" > gpurun_out/abl_${v}_$rep.json 2> gpurun_out/abl_${v}_$rep.err || { echo "run failed: $v"; tail -5 gpurun_out/abl_${v}_$rep.err; exit 1; }
     python - "$v" gpurun_out/abl_${v}_$rep.json <<'PY'
 import json, sys
 r = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
@@ -13,4 +13,3 @@ print(sys.argv[1], "value %.0f ms/step %.3f |" % (r["value"], r["ms_per_step"]),
 PY
   done
 done
-cp $new keypoint_bench_amd/libkpb.so

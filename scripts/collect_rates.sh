@@ -20,6 +20,7 @@ run runner_rate_seq --sequence
 run runner_rate_seq_xfeat --sequence --model XFeat
 run runner_rate_files_png --files png --pairs 512
 run runner_rate_files_jpeg --files jpeg --pairs 512
+run runner_rate_files_ppm --files ppm --pairs 2048
 timeout -k 10 600 python3 scripts/parity_sweep.py 256 gpurun_out/$R/parity_sweep_256.json --also-fp32 > gpurun_out/$R/parity_sweep_256.txt 2>&1 || echo "parity sweep failed"
 tail -3 gpurun_out/$R/parity_sweep_256.txt
 timeout -k 10 300 python3 bench.py --steps 500 --no-cpu-baseline --no-variants > gpurun_out/$R/bench_500_steps.json 2> gpurun_out/$R/bench_500_steps.err || echo "500-step run failed"

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--host", action="store_true")
     ap.add_argument("--u8", action="store_true", help="with --host: items are decoded uint8 [H,W,3] images (a quarter of the PCIe bytes)")
-    ap.add_argument("--files", choices=["png", "jpeg"], default=None,
+    ap.add_argument("--files", choices=["png", "jpeg", "ppm"], default=None,
                     help="items are image FILES, decoded by PIL on the runner's prefetch pool (keypoint_bench_amd/datasets.py: SURVEY 8(f)2's decode stage)")
     ap.add_argument("--decode-workers", type=int, default=None)
     ap.add_argument("--dense", action="store_true")
@@ -69,8 +69,8 @@ def main():
             paths.append(pp)
         recs = [dict(it, image0=paths[i % args.distinct][0], image1=paths[i % args.distinct][1]) for i, it in enumerate(ds)]
         ds = datasets.ImagePairFiles(recs)
-        t0 = time.perf_counter()        # what the decode pool alone delivers (no device work)
-        with datasets.Prefetcher(ds, range(args.pairs), workers=args.decode_workers) as pf:
+        t0 = time.perf_counter()        # what the decode pool alone delivers (no device work); .ppm: the files READ into arrays (lazy_raw=False)
+        with datasets.Prefetcher(datasets.ImagePairFiles(recs, lazy_raw=False), range(args.pairs), workers=args.decode_workers) as pf:
             n = sum(1 for _ in pf)
         decode_only = round(n / (time.perf_counter() - t0), 1)
     if args.sequence:
@@ -86,7 +86,7 @@ def main():
                        "last_ground_truth": np.array([0.05 * max(i - 1, 0), 0, 0, 0, 0, 0, 1], np.float32)})
         if args.tasks == ["match_stats", "repeatability", "MHA", "AUC"]:
             args.tasks = ["FundamentalMatrix", "visual_odometer"]
-    out = {"pairs": args.pairs, "batch": args.batch, "items": ("%s files decoded by PIL (%s threads)" % (args.files, args.decode_workers or "one per core, <= 16")) if args.files else
+    out = {"pairs": args.pairs, "batch": args.batch, "items": ("%s files %s (%s threads)" % (args.files, "read straight into the pinned staging ring (datasets.RawImage; HPatches' own format, hpatches.py:36)" if args.files == "ppm" else "decoded by PIL", args.decode_workers or "one per core, <= 16")) if args.files else
            ("host uint8 HWC" if args.u8 else "host numpy fp32 CHW") if args.host else "device tensors",
            "decode_pool_alone_pairs_per_s": decode_only,
            "descriptors": "dense-map" if args.dense else "keypoint-only"}

@@ -44,6 +44,79 @@ def test_jpeg_decodes_to_what_pil_gives_and_close_to_the_source():
     assert out.shape == a.shape and np.abs(out.astype(int) - a.astype(int)).mean() < 12
 
 
+def test_binary_ppm_is_its_own_raster_from_path_bytes_and_lazily(tmp_path):
+    """HPatches' format (datasets/hpatches.py:36: `.ppm`, read with cv2.imread + BGR2RGB at 47-56): the P6 raster is the decoded image.
+    The fast path must give exactly what PIL gives, for every header spelling netpbm allows, and hand a file over unread when asked."""
+    from PIL import Image
+    a = _img(11, 45, 70)
+    p = tmp_path / "a.ppm"
+    Image.fromarray(a).save(p)
+    want = np.array(Image.open(p).convert("RGB"))
+    assert np.array_equal(want, a)
+    for src in (str(p), p, p.read_bytes(), io.BytesIO(p.read_bytes())):
+        out = datasets.decode_rgb(src)
+        assert isinstance(out, np.ndarray) and out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and np.array_equal(out, a)
+    raw = datasets.decode_rgb(str(p), lazy=True)
+    assert isinstance(raw, datasets.RawImage) and raw.shape == a.shape and raw.dtype == np.uint8 and raw.ndim == 3
+    assert np.array_equal(np.asarray(raw), a)
+    dst = np.zeros((3,) + a.shape, np.uint8)            # a row of a staging buffer
+    raw.read_into(dst[1])
+    assert np.array_equal(dst[1], a) and not dst[0].any() and not dst[2].any()
+    c = raw.crop(32, 64)                                # the x32 crop cuts rows AND columns: row-wise reads
+    assert c.shape == (32, 64, 3) and np.array_equal(np.asarray(c), a[:32, :64])
+    c = raw.crop(32, 70)                                # rows only: one read
+    assert np.array_equal(np.asarray(c), a[:32])
+    with pytest.raises(ValueError):
+        raw.read_into(np.zeros((45, 70, 4), np.uint8))
+    with pytest.raises(ValueError):
+        raw.crop(46, 70)
+    for hdr in (b"P6 70 45 255\n", b"P6\n# made by hand\n70 45\n#x\n255\n", b"P6\r\n70\t45\r\n255 "):
+        data = hdr + a.tobytes()
+        assert np.array_equal(datasets.decode_rgb(data), a)
+        q = tmp_path / "h.ppm"
+        q.write_bytes(data)
+        assert np.array_equal(np.asarray(datasets.decode_rgb(str(q), lazy=True)), a)
+
+
+def test_gray_pgm_becomes_three_equal_channels_and_odd_pnm_goes_to_pil(tmp_path):
+    from PIL import Image
+    g = _img(12, 33, 40)[..., 0].copy()
+    p = tmp_path / "g.pgm"
+    Image.fromarray(g).save(p)
+    want = np.array(Image.open(p).convert("RGB"))
+    assert np.array_equal(datasets.decode_rgb(str(p)), want) and np.array_equal(datasets.decode_rgb(p.read_bytes()), want)
+    lazy = datasets.decode_rgb(str(p), lazy=True)
+    assert isinstance(lazy, datasets.RawImage) and np.array_equal(np.asarray(lazy.crop(32, 32)), want[:32, :32])
+    # not the fast path's business: ASCII PNM, 16-bit samples, a maxval the decoders rescale, a truncated raster -> PIL decides
+    assert datasets.parse_pnm_header(b"P3\n2 2\n255\n" + b"0 " * 12) is None
+    assert datasets.parse_pnm_header(b"P6\n2 2\n65535\n" + bytes(24)) is None
+    assert datasets.parse_pnm_header(b"P6\n2 2\n100\n" + bytes(12)) is None
+    assert datasets.parse_pnm_header(b"P6\n2 2\n255") is None and datasets.parse_pnm_header(b"P6\n2 2\n255x" + bytes(12)) is None
+    a = _img(13, 6, 5)
+    asc = b"P3\n5 6\n255\n" + b" ".join(str(int(v)).encode() for v in a.reshape(-1)) + b"\n"
+    assert np.array_equal(datasets.decode_rgb(asc), a)
+    q = tmp_path / "t.ppm"
+    q.write_bytes(b"P6\n5 6\n255\n" + a.tobytes()[:-7])
+    try:                                                # a raster that ends early is never handed over as a RawImage: PIL raises or pads
+        out = datasets.decode_rgb(str(q), lazy=True)
+    except Exception:
+        out = None
+    assert not isinstance(out, datasets.RawImage)
+
+
+def test_pair_dataset_hands_ppm_files_over_unread_unless_told_otherwise(tmp_path):
+    from PIL import Image
+    a, b = _img(14, 64, 96), _img(15, 64, 96)
+    Image.fromarray(a).save(tmp_path / "a.ppm")
+    Image.fromarray(b).save(tmp_path / "b.png")
+    recs = [{"image0": "a.ppm", "image1": "b.png", "tag": 5}]
+    it = datasets.ImagePairFiles(recs, root=str(tmp_path))[0]
+    assert isinstance(it["image0"], datasets.RawImage) and isinstance(it["image1"], np.ndarray) and it["tag"] == 5
+    assert np.array_equal(np.asarray(it["image0"]), a) and np.array_equal(it["image1"], b)
+    it = datasets.ImagePairFiles(recs, root=str(tmp_path), lazy_raw=False)[0]
+    assert isinstance(it["image0"], np.ndarray) and np.array_equal(it["image0"], a)
+
+
 @pytest.mark.parametrize("mode", ["L", "RGBA", "P"])
 def test_other_modes_are_converted_to_rgb_like_the_reference(mode):
     """megadepth.py:150-151: `if image.mode != 'RGB': image = image.convert('RGB')`."""

@@ -54,7 +54,7 @@ def test_warp_homography(c):
 
 
 @pytest.mark.parametrize("c", CASES)
-def test_val_key_points(c):
+def test_val_key_points(c, covis_form):
     from keypoint_bench_amd.tasks.repeatability import val_key_points
     p, w01, w10 = warps(c, DEV)
     _, o01, o10 = warps(c)
@@ -74,8 +74,30 @@ def test_val_key_points(c):
         assert np.float32(got["repeatability"]) == G[p + "repeatability"]
 
 
+@pytest.fixture(params=["cells stored", "cells evaluated in place"])
+def covis_form(request):
+    """kpb_val_keypoints has two forms: the M x N cells written once by the row pass (the default when they fit
+    KPB_OPT_COVIS_STORE_BYTES, 4 GiB) and every pass evaluating its own cells (beyond that, or when the workspace cannot grow).
+    Default shapes only ever reach the first: the limit is an option of the context (include/kpb.h), so the
+    second runs here on the same fixtures with the limit at 0 -- and must give the same bits."""
+    from keypoint_bench_amd._lib import Context
+    ctx = Context.get(torch.device(DEV))
+    ctx.set_option(Context.OPT_COVIS_STORE_BYTES, (4 << 30) if request.param == "cells stored" else 0)
+    yield request.param
+    ctx.set_option(Context.OPT_COVIS_STORE_BYTES, 4 << 30)
+
+
+def test_context_options_refuse_what_they_do_not_know():
+    from keypoint_bench_amd._lib import Context, KpbError
+    ctx = Context.get(torch.device(DEV))
+    for opt, val in ((99, 1), (Context.OPT_COVIS_STORE_BYTES, -1)):
+        with pytest.raises(KpbError) as e:
+            ctx.set_option(opt, val)
+        assert e.value.code == -1       # KPB_E_INVALID
+
+
 @pytest.mark.parametrize("c", CASES)
-def test_gt_mutual_pairs(c):
+def test_gt_mutual_pairs(c, covis_form):
     from keypoint_bench_amd.tasks.repeatability import gt_mutual
     p = "c%d_" % c
     t = lambda k: torch.from_numpy(G[p + k]).to(DEV)
@@ -89,7 +111,7 @@ def test_gt_mutual_pairs(c):
     assert gt == int((G[p + "dist"] <= 3).sum())
 
 
-def test_device_counts_and_batch_through_the_abi():
+def test_device_counts_and_batch_through_the_abi(covis_form):
     """Two pairs in one call, ragged by device-side counts, against the single-pair results."""
     from keypoint_bench_amd._lib import Context, ptr
     ctx = Context.get(torch.device(DEV))
@@ -174,3 +196,30 @@ def test_full_size_properties():
     swapped = p10[:, [1, 0]]
     order = torch.argsort(swapped[:, 0] * 100000 + swapped[:, 1])
     assert torch.equal(swapped[order], p01)
+
+
+def test_stored_and_in_place_forms_agree_bit_for_bit_at_full_size():
+    """2 048 x 2 048 cells (beyond every fixture's size), ties included (keypoints on a coarse grid): pairs, distances, errors and the
+    count within th of the evaluate-in-place form equal those of the stored-cells form."""
+    from keypoint_bench_amd._lib import Context
+    from keypoint_bench_amd.utils.projection import warp
+    from keypoint_bench_amd.tasks.repeatability import gt_mutual
+    ctx = Context.get(torch.device(DEV))
+    rng = np.random.default_rng(11)
+    n = 2048
+    grid = lambda: torch.from_numpy((rng.integers(0, 200, (n, 2)).astype(np.float32) + 0.5) / 200.0).to(DEV)      # many exact ties
+    hm = torch.tensor([[1.0, 0.0, 3.0], [0.0, 1.0, -2.0], [0.0, 0.0, 1.0]], device=DEV)
+    fwd = dict(mode="homo", homography_matrix=hm, width=640, height=480)
+    bwd = dict(mode="homo", homography_matrix=torch.linalg.inv(hm.double()).float(), width=640, height=480)
+    a, b, _, _ = warp(grid(), fwd)
+    a1, b1, _, _ = warp(grid(), bwd)
+    out = []
+    try:
+        for limit in (4 << 30, 0):
+            ctx.set_option(Context.OPT_COVIS_STORE_BYTES, limit)
+            out.append(gt_mutual(a, b, a1, b1, 512.0, 512.0))
+    finally:
+        ctx.set_option(Context.OPT_COVIS_STORE_BYTES, 4 << 30)
+    (p0, d0, e0, g0), (p1, d1, e1, g1) = out
+    assert len(p0) > 100 and g0 == g1
+    assert torch.equal(p0, p1) and torch.equal(d0.view(torch.int32), d1.view(torch.int32)) and torch.equal(e0.view(torch.int32), e1.view(torch.int32))

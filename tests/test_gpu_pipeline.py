@@ -65,3 +65,36 @@ def test_runner_rows_and_install_shim():
     np.testing.assert_array_equal(rows[:, :3].astype(np.int64), want)
     assert agg["mean_matches"] == pytest.approx(want[:, 2].mean())
     assert runner.install() == []     # no reference checkout on the path: nothing to swap, and no error
+
+
+def test_placing_the_descriptor_map_changes_where_it_lives_and_nothing_else(monkeypatch):
+    """PairPipeline._place_map (r06, profiles/r06_head_modes.txt): the dense map's allocation is chosen by timing the forward into a few candidates.
+    At a size where it would not bother (PLACE_MIN_BYTES lowered for the test) the placed pipeline must return exactly the rows of the unplaced one,
+    leave a record of its choice, hand the losing candidates back, and place only once."""
+    from keypoint_bench_amd import pipeline
+    from keypoint_bench_amd.models.ALike import alike_t
+    B = 2
+    i0, i1 = _pairs(B, 96, 128)
+    images = torch.from_numpy(np.concatenate([i0, i1])).to(DEV)
+    ep = dict(EP, top_k=200)
+    ref = pipeline.PairPipeline(alike_t(dense_descriptors=True).eval(), ep, BF, B, 96, 128, device=DEV, place_map=False)
+    ref.run(images)
+    assert ref.placement is None
+    monkeypatch.setattr(pipeline, "PLACE_MIN_BYTES", 0)
+    monkeypatch.setattr(pipeline, "PLACE_CANDIDATES", 3)
+    placed = pipeline.PairPipeline(alike_t(dense_descriptors=True).eval(), ep, BF, B, 96, 128, device=DEV, place_map=True)
+    before = torch.cuda.memory_allocated()
+    placed.run(images)
+    rec = placed.placement
+    assert rec["candidates"] == 3 and len(rec["forward_ms"]) == 3 and rec["forward_ms"][rec["chosen"]] == min(rec["forward_ms"])
+    assert torch.cuda.memory_allocated() <= before + (1 << 20)          # the two losers are gone
+    placed.run(images)
+    assert placed.placement is rec and placed.place_map is False        # once per pipeline
+    for a, b in ((placed.n, ref.n), (placed.kps, ref.kps), (placed.k, ref.k), (placed.desc, ref.desc), (placed.score, ref.score)):
+        assert torch.equal(a, b)
+    for b in range(B):
+        k = int(ref.k[b])
+        assert k > 10 and torch.equal(placed.pairs[b, :k], ref.pairs[b, :k]) and torch.equal(placed.dist[b, :k], ref.dist[b, :k])
+    sparse = pipeline.PairPipeline(alike_t(dense_descriptors=False).eval(), ep, BF, B, 96, 128, device=DEV, place_map=True)
+    sparse.run(images)
+    assert sparse.placement is None                                      # no dense map, nothing to place

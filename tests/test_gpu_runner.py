@@ -17,7 +17,7 @@ H01 = np.array([[1, 0, -3], [0, 1, -2], [0, 0, 1]], np.float32)
 def params(task):
     return {"model_type": "Alike", "task_type": task, "Alike_params": dict(c1=8, c2=16, c3=32, c4=64, dim=64), "extractor_params": EP,
             "matcher_params": {"type": "brute_force", "brute_force_params": BF}, "repeatability_params": {"th": 3},
-            "FundamentalMatrix_params": {"th": 3.0}}
+            "FundamentalMatrix_params": {"th": 3.0}, "MHA_params": {"th": [3, 5, 7]}}
 
 
 def pair_dataset(n, shapes=((96, 128),)):
@@ -260,3 +260,42 @@ def test_encoded_image_files_go_through_the_decode_pool_and_give_the_rows_of_the
     assert r_files.batched_pairs == 7 and r_files.staged_batches > 0
     assert np.array_equal(rows_files.view(np.uint64), rows_arr.view(np.uint64))
     assert rows_files[:, 0].min() > 20
+
+
+@pytest.mark.parametrize("task", ["repeatability", "MHA"])
+def test_hpatches_ppm_files_are_read_straight_into_the_staging_ring_and_give_the_rows_of_their_arrays(tmp_path, task):
+    """HPatches is `.ppm` (datasets/hpatches.py:36, cv2.imread + BGR2RGB at 47-56): a P6 raster is the decoded image, so
+    datasets.ImagePairFiles hands such files over as RawImages and HostStager.fill reads each into its pinned row.  Rows must be
+    those of the decoded arrays bit for bit -- equal shapes, a shape whose x32 crop cuts rows and columns (row-wise reads), a gray
+    .pgm view, a pair of unequal views (single-pair path, read by as_image) and a .ppm handed over as bytes."""
+    from PIL import Image
+    from keypoint_bench_amd import datasets
+    ds = pair_dataset(9, shapes=((96, 128), (96, 128), (96, 128), (107, 141), (96, 128)))
+    recs, arrays = [], []
+    for j, it in enumerate(ds):
+        views = []
+        for v, name in ((it["image0"], "a"), (it["image1"], "b")):
+            u8 = np.ascontiguousarray((v.transpose(1, 2, 0) * 255.0 + 0.5).astype(np.uint8))
+            if j == 2:                                   # a gray pair: P5 files, three equal channels after decoding
+                u8 = np.repeat(u8[..., 1:2], 3, axis=2)
+                path = tmp_path / ("%d%s.pgm" % (j, name))
+                Image.fromarray(u8[..., 0]).save(path)
+            else:
+                path = tmp_path / ("%d%s.ppm" % (j, name))
+                Image.fromarray(u8).save(path)
+            assert np.array_equal(datasets.decode_rgb(str(path)), u8)
+            views.append((str(path), u8))
+        recs.append(dict(it, image0=views[0][0], image1=views[1][0] if j != 1 else open(views[1][0], "rb").read()))
+        arrays.append(dict(it, image0=views[0][1], image1=views[1][1]))
+    files = datasets.ImagePairFiles(recs)
+    assert isinstance(files[0]["image0"], datasets.RawImage) and isinstance(files[1]["image1"], np.ndarray)
+    r_files = runner.PairRunner(params(task), device=DEV, batch=4)
+    r_files.decode_workers = 3
+    _, rows_files = r_files.run(files)
+    r_arr = runner.PairRunner(params(task), device=DEV, batch=4)
+    _, rows_arr = r_arr.run(arrays)
+    assert r_files.batched_pairs == r_arr.batched_pairs > 0 and r_files.staged_batches > 0
+    assert np.array_equal(rows_files.view(np.uint64), rows_arr.view(np.uint64))
+    single = runner.PairRunner(params(task), device=DEV, batch=1)        # every pair through test_step: as_image reads the RawImages
+    _, rows_single = single.run(files)
+    assert np.array_equal(rows_single.view(np.uint64), rows_arr.view(np.uint64))

@@ -52,6 +52,18 @@ def test_fixup_leaves_everything_else_alone():
     assert n == 1 and "op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,0]" in text and "; a comment" in text
 
 
+def test_a_packed_fp32_line_the_parser_cannot_read_is_refused_not_passed():
+    """the safety net must not depend on the assembler's text syntax staying what it is -- a v_pk_{mul,add,fma}_f32 line with an
+    unknown modifier spelling or operand count is an error for the rewrite (it raises) and for the lint (is_unparsed), never a silent pass."""
+    odd = ("\tv_pk_mul_f32 v[0:1], v[2:3]", "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[0,1,0]")
+    for line in odd:
+        assert isa_fixup.is_unparsed(line) and not isa_fixup.is_affected(line)
+        with pytest.raises(ValueError):
+            isa_fixup.fix_text("\ts_nop 0\n" + line + "\n")
+    for line in ("\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]", "\tv_pk_mov_b32 v[0:1], v[2:3], v[4:5]", "; v_pk_mul_f32 v[0:1], v[2:3]", "\tv_pk_fma_f16 v0, v1"):
+        assert not isa_fixup.is_unparsed(line)
+
+
 def test_the_shipped_library_is_clean():
     so = build.build()
     errors, totals, kernels = isa_lint.lint([so], verbose=False)

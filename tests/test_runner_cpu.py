@@ -152,11 +152,12 @@ def _bench_rank(rank, world, port, q):
         calls.append(1)
         _t.sleep(0.002 * (1 + 2 * rank))
 
-    elapsed, tail = bench.timed_steps(step, 100, 3, dev, True, dist)
+    elapsed, tail, own = bench.timed_steps(step, 100, 3, dev, True, dist)
     B = 5
     rows = torch.tensor([[100.0 * rank + i, 1.0 + rank, float(i)] for i in range(B)])
     allrows = bench.exchange_rows(rows, world, True, dist)
-    q.put((rank, len(calls), elapsed, tail, allrows.numpy().tolist(), dist.get_world_size()))
+    per_rank = bench.per_rank_figures(1e3 * own / 100, 7.0 + rank, world, True, dist, dev)      # each rank's own step time and "dominant kernel" figure
+    q.put((rank, len(calls), elapsed, tail, allrows.numpy().tolist(), dist.get_world_size(), own, per_rank))
     dist.destroy_process_group()
 
 
@@ -174,12 +175,17 @@ def test_bench_rank_logic_over_gloo():
     for p in ps:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, n0, e0, t0, rows0, w0), (r1, n1, e1, t1, rows1, w1) = res
+    (r0, n0, e0, t0, rows0, w0, own0, pr0), (r1, n1, e1, t1, rows1, w1, own1, pr1) = res
     assert n0 == n1 == 103 and w0 == w1 == 2
     assert e0 == e1 and t0 == t1                           # both ranks report the MAX
     assert e0 >= 100 * 0.006 and e0 < 100 * 0.006 * 3      # the slow rank's 6 ms steps, not the fast rank's 2 ms
     assert 0.4 * e0 < t0 < 0.6 * e0                        # the last 50 of 100 steps
     assert rows0 == rows1 and [r[0] for r in rows0] == [0, 1, 2, 3, 4, 100, 101, 102, 103, 104]
+    # r06: the MAX hides which rank is slow -- every rank's own figures are gathered and identical on both ranks
+    assert own0 < 0.6 * e0 and 0.9 * e0 < own1 <= e1       # rank 0 finished its 2 ms steps long before the barrier released it
+    assert pr0 == pr1 and [p["rank"] for p in pr0] == [0, 1]
+    assert abs(pr0[0]["ms_per_step"] - 10 * own0) < 0.01 and abs(pr0[1]["ms_per_step"] - 10 * own1) < 0.01      # 1e3 * own / 100 steps
+    assert pr0[1]["ms_per_step"] > 2 * pr0[0]["ms_per_step"] and [p["dominant_kernel_ms"] for p in pr0] == [7.0, 8.0]
 
 
 def test_generator_threads_share_the_cores():
