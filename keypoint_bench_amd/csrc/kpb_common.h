@@ -110,6 +110,18 @@ __device__ __forceinline__ float kpb_wave_fmin(float v)
     v = fminf(v, kpb_shfl_xor<4>(v)); v = fminf(v, kpb_shfl_xor<2>(v)); v = fminf(v, kpb_shfl_xor<1>(v));
     return v;
 }
+// inclusive prefix sum over the 64 lanes of a wave on the vector ALU (DPP row shifts inside the rows of 16, then the two row broadcasts): lane i
+// gets v[0] + ... + v[i]; lane 63's value is the wave total.  Twelve instructions, no LDS.
+__device__ __forceinline__ int kpb_wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);      // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ float kpb_max32(float v) { float a, b; kpb_halves32(v, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float kpb_min32(float v) { float a, b; kpb_halves32(v, a, b); return fminf(a, b); }
 __device__ __forceinline__ float kpb_sum32(float v) { float a, b; kpb_halves32(v, a, b); return a + b; }
