@@ -90,8 +90,11 @@ def test_placing_the_descriptor_map_changes_where_it_lives_and_nothing_else(monk
     assert torch.cuda.memory_allocated() <= before + (1 << 20)          # the two losers are gone
     placed.run(images)
     assert placed.placement is rec and placed.place_map is False        # once per pipeline
-    for a, b in ((placed.n, ref.n), (placed.kps, ref.kps), (placed.k, ref.k), (placed.desc, ref.desc), (placed.score, ref.score)):
+    for a, b in ((placed.n, ref.n), (placed.k, ref.k), (placed.desc, ref.desc), (placed.score, ref.score)):
         assert torch.equal(a, b)
+    for i in range(2 * B):          # rows beyond an image's count are whatever torch.empty left there
+        n = int(ref.n[i])
+        assert n > 50 and torch.equal(placed.kps[i, :n], ref.kps[i, :n])
     for b in range(B):
         k = int(ref.k[b])
         assert k > 10 and torch.equal(placed.pairs[b, :k], ref.pairs[b, :k]) and torch.equal(placed.dist[b, :k], ref.dist[b, :k])
