@@ -48,6 +48,10 @@ struct ConvM {
     // barrier per slab.  (r05 also had the producer as its own kernel writing this format to HBM and the consumer landing it by LDS-DMA: 2.10 -> 2.07 ms,
     // profiles/r05_presplit_conv1b_ab.txt -- superseded by GEN and removed in r06, together with KPB_PRESPLIT.)
     const unsigned* pre_amax = nullptr; float pre_l1 = 0.0f, pre_bmax = 0.0f;
+    // conv_mfma_h<.., UP> (r06, DISK's decoder): the first up_c input channels are NOT in `in` -- they are the 2 x bilinear upsampling (align_corners = False,
+    // disk.py:126-127) of up_src [B][Hi / 2][Wi / 2][up_c], evaluated while the tile is staged; `in` holds the remaining CIN - up_c channels (istride floats
+    // per pixel).  The concatenated map [up(bottom) | horizontal] is never written.
+    const float* up_src = nullptr; int up_c = 0;
     int unfold_w = 0;             // gemm_h<.., UNFOLD>: `in` is a single-channel [B][8 H][unfold_w] image and row r, channel c stand for pixel
                                   // (8 (r / W) + c / 8, 8 (r % W) + c % 8): XFeat's _unfold2d(x, 8) read in place (XFeat.py:96-103, 138)
 };
@@ -324,9 +328,33 @@ constexpr int conv_mfma_h_waves(int KS, int CC, bool POOL_IN, int NTB, int MT)
 // workgroup -- the four waves request the same weight fragments, 4 x the bytes through the CU's vector L1 (64 B/clk), and a knock-out
 // put 18 % of SuperPoint's conv1b there (profiles/r05_presplit_conv1b_ab.txt).  WN = 2: a wave takes twice the rows and half the
 // n-tiles: the same 64 accumulator registers and products, half the weight bytes, twice the activation reads -- which come from LDS.
-template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false, int WN = 1, bool GEN = false>
+// The taps of the 2 x bilinear upsampling torch's F.interpolate(scale_factor = 2, mode = 'bilinear', align_corners = False) reads for output coordinate o of
+// a source of n samples: source indices i0 <= i1, weight l of i1 (1 - l of i0).  Shared by upsample2_concat (the materialised form the strict-fp32 path keeps),
+// up_chan_sums (its statistics) and conv_mfma_h<UP> (the staging that evaluates it in place): the three compute the same floats.
+__device__ __forceinline__ void cm_up2_taps(int o, int n, int& i0, int& i1, float& l)
+{
+    const float f = fmaxf(((float)o + 0.5f) * 0.5f - 0.5f, 0.0f);
+    i0 = (int)f;
+    i1 = i0 + (i0 < n - 1 ? 1 : 0);
+    l = f - (float)i0;
+}
+__device__ __forceinline__ float4 cm_up2_mix(const float4 p00, const float4 p01, const float4 p10, const float4 p11, float ly, float lx)
+{
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    return make_float4(hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x), hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y),
+                       hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z), hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w));
+}
+
+// UP (r06): see ConvM::up_src.  DISK's up_3 read an 80-channel map [up(u2) | f1] that a kernel of its own had written (3.1 GB per 32 images, read once more
+// for the InstanceNorm statistics and then here with a 5 x 5 halo by both workgroups of a tile).  Here a slab of upsampled channels is staged from the
+// HALF-resolution source: its (IH / 2 + 2)^2 pixels land raw in 9 KB of LDS and every staged float4 is the four-tap mix of that -- the direct form (four global
+// taps per staged float4, r05) spilled 95 registers and lost 3 ms.  The staging has the room: a slab's taps are 750 MFMAs per wave.
+template <int KS, int S, int CC, bool POOL_IN, bool POOL_OUT, bool XF, int NTB = 2, int MT = 1, bool XC = false, int PF = 2, bool WPRE = false, bool PRE = false, int WN = 1, bool GEN = false,
+          bool UP = false>
 __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, NTB, MT)) void conv_mfma_h(ConvM a)
 {
+    static_assert(!UP || (S == 1 && !POOL_IN && !PRE && !WPRE && (((8 * MT / WN - 1) * S + KS) % 2 == 0) && ((15 * S + KS) % 2 == 0) && KS / 2 % 2 == 0),
+                  "conv_mfma_h<UP>: stride-1 layers whose input tile starts on an even row and column");
     static_assert(WN == 1 || (WN == 2 && MT % 2 == 0 && !WPRE), "conv_mfma_h: waves split the n-tiles two ways at most");
     static_assert(PRE == GEN && (!GEN || KS == 3), "conv_mfma_h: the pre-split tile exists as the generated one (a 3 x 3 one-channel layer computed while staging); r05's DMA-landed form was measured, superseded and removed in r06");
     static_assert(!PRE || (CC == 32 && S == 1 && !POOL_IN && !XF && !XC && !WPRE), "conv_mfma_h: the pre-split input form exists for plain stride-1 32-channel slabs");
@@ -445,6 +473,94 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                     }
                 }
             }
+        } else if constexpr (UP) {
+        // UP: ONE pass, no maximum taken over the staged tile -- the slab's scale comes from a rigorous bound of its transformed values over the whole image
+        // (ConvM::xf, fourth float per channel: make_xf from the channel's range, which bounds the upsampled values too -- they are convex combinations), so
+        // nothing is held across a barrier (the measured-maximum form needs the NLD staged float4s twice: held, 78 registers spilled at three waves per SIMD;
+        // evaluated twice, up_3 15.5 -> 17.0 ms).  A per-image bound instead of a per-tile maximum moves the f16 window up by the ratio of the two -- a few
+        // binary places out of the 2^-24 .. 2^15 the split's low halves have.
+        static_assert(XF && !POOL_IN, "conv_mfma_h<UP>: DISK's decoder layers (InstanceNorm + PReLU while staging)");
+        constexpr int RH = UP ? IH / 2 + 2 : 1, RWD = UP ? IW / 2 + 2 : 1;      // the half-resolution source tile of an upsampled slab
+        __shared__ __attribute__((aligned(16))) float4 rawbuf[RH * RWD * Q];
+        const int ry0 = UP ? iy0 / 2 - 1 : 0, rx0 = UP ? ix0 / 2 - 1 : 0;       // iy0, ix0 even (static_assert): source row of tile row 0 is iy0 / 2 - 1
+        const bool upslab = UP && ch * CC < a.up_c;
+        if constexpr (UP) {
+            if (upslab) {       // workgroup-uniform.  The previous slab's reads of rawbuf lie two barriers back.
+                constexpr int NR = RH * RWD * Q, PERR = (NR + 255) / 256;
+                const int Hb = a.Hi / 2, Wb = a.Wi / 2;
+                const float* src = a.up_src + (size_t)b * Hb * Wb * a.up_c + ch * CC;
+                float4 rv[PERR];
+#pragma unroll
+                for (int k = 0; k < PERR; ++k) {
+                    const int i = min(tid + k * 256, NR - 1);
+                    const int rp = i / Q, q = i - rp * Q, r = rp / RWD, c = rp - r * RWD;
+                    const int sy = min(max(ry0 + r, 0), Hb - 1), sx = min(max(rx0 + c, 0), Wb - 1);
+                    rv[k] = *reinterpret_cast<const float4*>(src + ((size_t)sy * Wb + sx) * a.up_c + 4 * q);
+                }
+#pragma unroll
+                for (int k = 0; k < PERR; ++k)
+                    if (tid + k * 256 < NR) rawbuf[tid + k * 256] = rv[k];
+            }
+        }
+        __syncthreads();        // the raw tile is in LDS, and the previous slab's taps are done with the tile
+        auto staged = [&](int idx, bool& live) -> float4 {
+            const int pix = idx / Q, q = idx - pix * Q;
+            const int y = pix / IW, x = pix - y * IW;
+            const int gy = iy0 + y, gx = ix0 + x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            live = idx < IH * IW * Q;
+            if (live && gy >= 0 && gy < Hc && gx >= 0 && gx < Wc) {
+                if (upslab) {
+                    int y0, y1, x0, x1;
+                    float ly, lx;
+                    cm_up2_taps(gy, a.Hi / 2, y0, y1, ly);
+                    cm_up2_taps(gx, a.Wi / 2, x0, x1, lx);
+                    const float4* r0 = rawbuf + ((y0 - ry0) * RWD - rx0) * Q + q;
+                    const float4* r1 = rawbuf + ((y1 - ry0) * RWD - rx0) * Q + q;
+                    v = cm_up2_mix(r0[x0 * Q], r0[x1 * Q], r1[x0 * Q], r1[x1 * Q], ly, lx);
+                } else
+                    v = *reinterpret_cast<const float4*>(in + ((size_t)gy * a.Wi + gx) * a.istride + (ch * CC - a.up_c) + 4 * q);
+                const float4* t4 = reinterpret_cast<const float4*>(a.xf + ((size_t)b * a.CIN + ch * CC + 4 * q) * 4);
+                const float4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+                v.x = fmaf(v.x, t0.x, t0.y); v.x = v.x >= 0.0f ? v.x : v.x * t0.z;
+                v.y = fmaf(v.y, t1.x, t1.y); v.y = v.y >= 0.0f ? v.y : v.y * t1.z;
+                v.z = fmaf(v.z, t2.x, t2.y); v.z = v.z >= 0.0f ? v.z : v.z * t2.z;
+                v.w = fmaf(v.w, t3.x, t3.y); v.w = v.w >= 0.0f ? v.w : v.w * t3.z;
+            }
+            return v;
+        };
+        {
+            float bnd = 0.0f;       // workgroup-uniform: sixteen scalar loads
+#pragma unroll
+            for (int c = 0; c < CC; ++c) bnd = fmaxf(bnd, a.xf[((size_t)b * a.CIN + ch * CC + c) * 4 + 3]);
+            const int e_new = cm_exp_of(bnd);
+            if (ch == 0) e_cur = e_new;
+            else if (e_new > e_cur) {           // this slab needs a smaller scale: bring what has been accumulated down to it (exact)
+                const float f = cm_pow2(e_cur - e_new);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTB; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] *= f;
+                e_cur = e_new;
+            }
+            const float sc = cm_scale_of(e_cur);
+#pragma unroll 2
+            for (int k = 0; k < NLD; ++k) {
+                const int idx = tid + k * 256;
+                bool live;
+                const float4 v = staged(idx, live);
+                if (live) {
+                    const int pix = idx / Q, q = idx - pix * Q;
+                    const int y = pix / IW, x = pix - y * IW;
+                    uint2 hi, lo;
+                    cm_split4(make_float4(v.x * sc, v.y * sc, v.z * sc, v.w * sc), hi, lo);
+                    *reinterpret_cast<uint2*>(&tile[y * ROWP + x * PITCH + 8 * q]) = hi;
+                    *reinterpret_cast<uint2*>(&tile[y * ROWP + x * PITCH + LO + 8 * q]) = lo;
+                }
+            }
+        }
         } else {
         float4 buf[NLD];
         float amax = 0.0f;

@@ -708,11 +708,12 @@ struct Layer {      // one convolution of a network plan
     int ntb = 2;    // 32-wide output tiles per workgroup
 };
 
+struct UpSrc { const float* src; int c; };      // ConvM::up_src, up_c
 struct PreSplit { const unsigned* amax = nullptr; float l1 = 0.0f, bmax = 0.0f; const float* gen_w = nullptr; const float* gen_b = nullptr; };     // ConvM::pre_*, gen_*
 
 int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, const float* in, float* out, int B, int Hi, int Wi,
                 bool pool_in, bool pool_out, bool relu_, const float* xf = nullptr, int unfold_w = 0, float l2_eps = 0.0f, const float2* unfold_mr = nullptr,
-                const PreSplit* pre = nullptr)
+                const PreSplit* pre = nullptr, const UpSrc* up = nullptr)
 {
     const int S = L.stride, CC = L.cc, PAD = L.ks / 2;
     const int Hc = pool_in ? Hi / 2 : Hi, Wc = pool_in ? Wi / 2 : Wi;
@@ -746,12 +747,22 @@ int launch_mfma(kpb_ctx* ctx, const char* name, kpb_net* net, const Layer& L, co
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, false, false, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && !pool_in && pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, false, true, false, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
         else if (L.ks == 3 && S == 1 && CC == 32 && pool_in && !pool_out && !x) KPB_LAUNCH(ctx, name, (conv_mfma_h<3, 1, 32, true, false, false, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
+        else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x && up) {     // [up(bottom) | horizontal] evaluated while staging (ConvM::up_src)
+            if (up->c % CC || up->c >= L.cin || (Hi % 2) || (Wi % 2)) return kpb_fail(ctx, KPB_E_INVALID, "launch_mfma: bad upsampled-input split for %s", L.name.c_str());
+            a.up_src = up->src; a.up_c = up->c; a.istride = L.cin - up->c;
+            KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 1, 4, false, 2, false, false, 2, false, true>), g2, block, 0, st, a);
+        }
         else if (L.ks == 5 && S == 1 && CC == 32 && !pool_in && !pool_out && x) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 32, false, false, true, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 2) KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 1, 4, false, 2, false, false, 2>), g2, block, 0, st, a);
         else if (L.ks == 5 && S == 1 && CC == 16 && !pool_in && !pool_out && x && L.ntb == 5) {
             // 129 = 4 x 32 + 1 (DISK up_3): four MFMA tiles (two workgroups of two: 64 accumulator registers, three waves per SIMD)
             // and the score channel on the VALU of the first workgroup
             a.nblk = 2; a.xw = net->wp((L.name + ".xw").c_str()); a.xb = net->wscale.at(L.name + ".xb"); a.xun = 1.0f / net->wscale.at(L.name + ".xs"); a.xco = L.cout - 1;
+            if (up) {       // `in` holds the channels behind the upsampled ones: cin - up->c floats per pixel
+                if (up->c % CC || up->c >= L.cin || (Hi % 2) || (Wi % 2)) return kpb_fail(ctx, KPB_E_INVALID, "launch_mfma: bad upsampled-input split for %s", L.name.c_str());
+                a.up_src = up->src; a.up_c = up->c; a.istride = L.cin - up->c;
+                KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 1, 4, true, 2, false, false, 2, false, true>), dim3(cdiv(a.W, 16), cdiv(a.H, 16), B * 2), block, 0, st, a);
+            } else
             KPB_LAUNCH(ctx, name, (conv_mfma_h<5, 1, 16, false, false, true, 1, 4, true, 2, false, false, 2>), dim3(cdiv(a.W, 16), cdiv(a.H, 16), B * 2), block, 0, st, a);
         }
         else if (L.ks == 1 && S == 1 && CC == 32 && !pool_in && !pool_out && !x && l2_eps > 0.0f) {
@@ -1162,15 +1173,14 @@ __global__ void upsample2_concat(const float* bot, const float* hor, float* out,
     const int y = (int)(pix / W), x = (int)(pix - (size_t)y * W);
     float4 v;
     if (c < Cb) {
-        const float fy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f), fx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < Hb - 1 ? 1 : 0), x1 = x0 + (x0 < Wb - 1 ? 1 : 0);
-        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.0f - ly, hx = 1.0f - lx;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        cm_up2_taps(y, Hb, y0, y1, ly);
+        cm_up2_taps(x, Wb, x0, x1, lx);
         const float* m = bot + (size_t)b * Hb * Wb * Cb + c;
         const float4 p00 = *reinterpret_cast<const float4*>(m + ((size_t)y0 * Wb + x0) * Cb), p01 = *reinterpret_cast<const float4*>(m + ((size_t)y0 * Wb + x1) * Cb);
         const float4 p10 = *reinterpret_cast<const float4*>(m + ((size_t)y1 * Wb + x0) * Cb), p11 = *reinterpret_cast<const float4*>(m + ((size_t)y1 * Wb + x1) * Cb);
-        v = make_float4(hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x), hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y),
-                        hy * (hx * p00.z + lx * p01.z) + ly * (hx * p10.z + lx * p11.z), hy * (hx * p00.w + lx * p01.w) + ly * (hx * p10.w + lx * p11.w));
+        v = cm_up2_mix(p00, p01, p10, p11, ly, lx);
     } else {
         v = *reinterpret_cast<const float4*>(hor + (((size_t)b * H + y) * W + x) * Ch + (c - Cb));
     }
@@ -1180,12 +1190,13 @@ __global__ void upsample2_concat(const float* bot, const float* hor, float* out,
 // per (image, channel) sum and sum of squares over the pixels of an NHWC tensor; block = (C, R) threads.  Every block leaves ITS partial pair in
 // part[image][block][channel] and make_xf adds the blocks up in index order: the sums are the same bits every run (r05: they were accumulated by
 // fp64 atomics in arrival order -- within rounding of the float parameters they feed, but not a fixed sequence of operations).
-__global__ void chan_sums(const float* in, double* part, size_t P, int C)
+__global__ void chan_sums(const float* in, double* part, size_t P, int C, int Ctot, int coff, float* mm)
 {
     extern __shared__ double sh[];   // [R][C][2]
     const int c = threadIdx.x, r = threadIdx.y, R = blockDim.y;
     const size_t b = blockIdx.y;
     double s = 0.0, q = 0.0;
+    float mn = INFINITY, mx = -INFINITY;        // mm (r06): the channel's smallest and largest value, for the bound conv_mfma_h<UP> scales its slabs by
     const size_t step = (size_t)gridDim.x * R;
     size_t pix = (size_t)blockIdx.x * R + r;
     for (; pix + 3 * step < P; pix += 4 * step) {        // four loads in flight, accumulated in the order of the plain loop
@@ -1193,23 +1204,101 @@ __global__ void chan_sums(const float* in, double* part, size_t P, int C)
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = in[(b * P + pix + k * step) * C + c];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s += (double)v[k]; q += (double)v[k] * (double)v[k]; }
+        for (int k = 0; k < 4; ++k) { s += (double)v[k]; q += (double)v[k] * (double)v[k]; mn = fminf(mn, v[k]); mx = fmaxf(mx, v[k]); }
     }
     for (; pix < P; pix += step) {
         const float v = in[(b * P + pix) * C + c];
-        s += (double)v; q += (double)v * (double)v;
+        s += (double)v; q += (double)v * (double)v; mn = fminf(mn, v); mx = fmaxf(mx, v);
     }
     sh[(r * C + c) * 2] = s; sh[(r * C + c) * 2 + 1] = q;
     __syncthreads();
     if (r == 0) {
         for (int k = 1; k < R; ++k) { s += sh[(k * C + c) * 2]; q += sh[(k * C + c) * 2 + 1]; }
-        double* o = part + ((b * gridDim.x + blockIdx.x) * C + c) * 2;
+        double* o = part + ((b * gridDim.x + blockIdx.x) * Ctot + coff + c) * 2;     // a row of Ctot channel pairs per block: this tensor's channels start at coff
         o[0] = s; o[1] = q;
+    }
+    if (mm) {       // kernel-uniform
+        __syncthreads();
+        sh[(r * C + c) * 2] = (double)mn; sh[(r * C + c) * 2 + 1] = (double)mx;
+        __syncthreads();
+        if (r == 0) {
+            for (int k = 1; k < R; ++k) { mn = fminf(mn, (float)sh[(k * C + c) * 2]); mx = fmaxf(mx, (float)sh[(k * C + c) * 2 + 1]); }
+            float* o = mm + ((b * gridDim.x + blockIdx.x) * Ctot + coff + c) * 2;
+            o[0] = mn; o[1] = mx;
+        }
+    }
+}
+
+// The same partial sums for a tensor that is never materialised (r06): the 2 x bilinear upsampling of `bot` [B][Hb][Wb][Cb] that conv_mfma_h<UP> evaluates
+// while it stages.  A thread owns four channels and walks source cells (i, j): the cell's 3 x 3 neighbourhood (edge-replicated: at the frame the interpolation's
+// clamped taps coincide) gives its four output pixels (2 i + dy, 2 j + dx) separably -- 1/4 : 3/4 mixes down the columns, then along the rows.  These are sums of
+// fp64 over 1.2 M values for a mean and a variance that are rounded to float: they need the map's values to a few ulp, not to the bit (the staging evaluates
+// torch's own expression, cm_up2_mix).  Fixed order: the same bits every run.  blockDim = (Cb / 4, 256 / (Cb / 4)).
+__global__ __launch_bounds__(256) void up_chan_sums(const float* __restrict__ bot, double* __restrict__ part, int Hb, int Wb, int Cb, int Ctot, int coff, float* __restrict__ mm)
+{
+    extern __shared__ double sh[];   // [R][Cb / 4][8]
+    const int cq = threadIdx.x, r = threadIdx.y, R = blockDim.y, CQ = blockDim.x;
+    const size_t b = blockIdx.y;
+    const float* m = bot + b * (size_t)Hb * Wb * Cb + 4 * cq;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    // (the upsampled values are convex combinations of source values: the source's range bounds theirs; every source pixel is the centre of one cell)
+    const int ncell = Hb * Wb;
+    auto mix = [](const float4 a, const float4 c) { return make_float4(0.25f * a.x + 0.75f * c.x, 0.25f * a.y + 0.75f * c.y, 0.25f * a.z + 0.75f * c.z, 0.25f * a.w + 0.75f * c.w); };
+    for (int cell = blockIdx.x * R + r; cell < ncell; cell += gridDim.x * R) {
+        const int i = cell / Wb, j = cell - i * Wb;
+        const int ym = max(i - 1, 0), yp = min(i + 1, Hb - 1), xm = max(j - 1, 0), xp = min(j + 1, Wb - 1);
+        float4 t0[3], t1[3];        // the two output rows of the cell at source columns j - 1, j, j + 1
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int xx = dx == 0 ? xm : (dx == 1 ? j : xp);
+            const float4 u0 = *reinterpret_cast<const float4*>(m + ((size_t)ym * Wb + xx) * Cb);
+            const float4 u1 = *reinterpret_cast<const float4*>(m + ((size_t)i * Wb + xx) * Cb);
+            const float4 u2 = *reinterpret_cast<const float4*>(m + ((size_t)yp * Wb + xx) * Cb);
+            t0[dx] = mix(u0, u1);
+            t1[dx] = mix(u2, u1);
+            if (dx == 1) {
+                mn = make_float4(fminf(mn.x, u1.x), fminf(mn.y, u1.y), fminf(mn.z, u1.z), fminf(mn.w, u1.w));
+                mx = make_float4(fmaxf(mx.x, u1.x), fmaxf(mx.y, u1.y), fmaxf(mx.z, u1.z), fmaxf(mx.w, u1.w));
+            }
+        }
+        const float4 o[4] = {mix(t0[0], t0[1]), mix(t0[2], t0[1]), mix(t1[0], t1[1]), mix(t1[2], t1[1])};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[0] += (double)o[k].x; q[0] += (double)o[k].x * (double)o[k].x;
+            s[1] += (double)o[k].y; q[1] += (double)o[k].y * (double)o[k].y;
+            s[2] += (double)o[k].z; q[2] += (double)o[k].z * (double)o[k].z;
+            s[3] += (double)o[k].w; q[3] += (double)o[k].w * (double)o[k].w;
+        }
+    }
+    double* me = sh + ((size_t)r * CQ + cq) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { me[2 * k] = s[k]; me[2 * k + 1] = q[k]; }
+    __syncthreads();
+    if (r == 0) {
+        for (int k = 1; k < R; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += sh[((size_t)k * CQ + cq) * 8 + 2 * e]; q[e] += sh[((size_t)k * CQ + cq) * 8 + 2 * e + 1]; }
+        double* o = part + ((b * gridDim.x + blockIdx.x) * Ctot + coff + 4 * cq) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[2 * e] = s[e]; o[2 * e + 1] = q[e]; }
+    }
+    __syncthreads();
+    me[0] = (double)mn.x; me[1] = (double)mx.x; me[2] = (double)mn.y; me[3] = (double)mx.y; me[4] = (double)mn.z; me[5] = (double)mx.z; me[6] = (double)mn.w; me[7] = (double)mx.w;
+    __syncthreads();
+    if (r == 0) {
+        float lo[4] = {mn.x, mn.y, mn.z, mn.w}, hi[4] = {mx.x, mx.y, mx.z, mx.w};
+        for (int k = 1; k < R; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = fminf(lo[e], (float)sh[((size_t)k * CQ + cq) * 8 + 2 * e]); hi[e] = fmaxf(hi[e], (float)sh[((size_t)k * CQ + cq) * 8 + 2 * e + 1]); }
+        float* o = mm + ((b * gridDim.x + blockIdx.x) * Ctot + coff + 4 * cq) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[2 * e] = lo[e]; o[2 * e + 1] = hi[e]; }
     }
 }
 
 // InstanceNorm2d (biased variance, eps 1e-5, no affine) folded with the PReLU slope into the conv's input transform
-__global__ void make_xf(const double* part, int nblk, const float* slope, float* xf, size_t P, int C, int n)
+__global__ void make_xf(const double* part, int nblk, const float* slope, float* xf, size_t P, int C, int n, const float* mm)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1225,7 +1314,19 @@ __global__ void make_xf(const double* part, int nblk, const float* slope, float*
     const double mean = s / (double)P;
     const double var = fmax(q / (double)P - mean * mean, 0.0);
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
-    xf[4 * i] = rstd; xf[4 * i + 1] = -(float)mean * rstd; xf[4 * i + 2] = slope[i % C]; xf[4 * i + 3] = 0.0f;
+    const float shift = -(float)mean * rstd, sl = slope[i % C];
+    // mm (r06): the channel's range over the image -> the largest magnitude its transformed values can take.  v -> prelu(v rstd + shift) is |.|-convex
+    // (V-shaped around the zero of the affine part), so the maximum over [lo, hi] sits at an end; conv_mfma_h<UP> scales a slab by the largest of its channels'
+    // bounds instead of measuring the staged tile.
+    float bound = 0.0f;
+    if (mm) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < nblk; ++k) { const float* p = mm + (((size_t)b * nblk + k) * C + c) * 2; lo = fminf(lo, p[0]); hi = fmaxf(hi, p[1]); }
+        float a0 = fmaf(lo, rstd, shift), a1 = fmaf(hi, rstd, shift);
+        a0 = a0 >= 0.0f ? a0 : a0 * sl; a1 = a1 >= 0.0f ? a1 : a1 * sl;
+        bound = fmaxf(fabsf(a0), fabsf(a1));
+    }
+    xf[4 * i] = rstd; xf[4 * i + 1] = shift; xf[4 * i + 2] = sl; xf[4 * i + 3] = bound;
 }
 
 // disk.py:311-312: desc = F.normalize(feature[:, :128], dim=1), score = sigmoid(feature[:, 128]); feature is [.., 129]
@@ -1263,8 +1364,20 @@ struct DiskNet : kpb_net {
     {
         hipStream_t st = ctx->stream;
         const int R = 512 / C > 0 ? 512 / C : 1;
-        KPB_LAUNCH(ctx, "disk_chan_sums", chan_sums, dim3(SUM_BLOCKS, batch), dim3(C, R), (size_t)R * C * 2 * sizeof(double), st, t, sums, P, C);
-        KPB_LAUNCH(ctx, "disk_make_xf", make_xf, dim3(cdiv(batch * C, 256)), dim3(256), 0, st, sums, SUM_BLOCKS, wp(slope_name), xf, P, C, batch * C);
+        KPB_LAUNCH(ctx, "disk_chan_sums", chan_sums, dim3(SUM_BLOCKS, batch), dim3(C, R), (size_t)R * C * 2 * sizeof(double), st, t, sums, P, C, C, 0, nullptr);
+        KPB_LAUNCH(ctx, "disk_make_xf", make_xf, dim3(cdiv(batch * C, 256)), dim3(256), 0, st, sums, SUM_BLOCKS, wp(slope_name), xf, P, C, batch * C, nullptr);
+        return KPB_OK;
+    }
+    // the statistics of [up2(bot) | hor] (Cb + Ch channels at 2 Hb x 2 Wb) without the map: the upsampled channels from the half-resolution source
+    // (up_chan_sums), the horizontal ones from their own tensor, into one row of partial pairs per block (r06)
+    int stats_xf_up(const float* bot, const float* hor, int Hb, int Wb, int Cb, int Ch, const char* slope_name, double* sums, float* mm, float* xf, int batch)
+    {
+        hipStream_t st = ctx->stream;
+        const int C = Cb + Ch, CQ = Cb / 4, RU = 256 / CQ, R = 512 / Ch > 0 ? 512 / Ch : 1;
+        const size_t P = (size_t)4 * Hb * Wb;
+        KPB_LAUNCH(ctx, "disk_up_chan_sums", up_chan_sums, dim3(SUM_BLOCKS, batch), dim3(CQ, RU), (size_t)RU * CQ * 8 * sizeof(double), st, bot, sums, Hb, Wb, Cb, C, 0, mm);
+        KPB_LAUNCH(ctx, "disk_chan_sums", chan_sums, dim3(SUM_BLOCKS, batch), dim3(Ch, R), (size_t)R * Ch * 2 * sizeof(double), st, hor, sums, P, Ch, C, Cb, mm);
+        KPB_LAUNCH(ctx, "disk_make_xf", make_xf, dim3(cdiv(batch * C, 256)), dim3(256), 0, st, sums, SUM_BLOCKS, wp(slope_name), xf, P, C, batch * C, mm);
         return KPB_OK;
     }
     int forward(const float* img, int batch, int H_, int W_, float* score_out, float* desc_out) override
@@ -1276,12 +1389,13 @@ struct DiskNet : kpb_net {
         // floats per image
         const size_t n_in = P * 4, n_f1 = P * 16, n_p1 = P / 4 * 16, n_f2 = P / 4 * 32, n_p2 = P / 16 * 32, n_f3 = P / 16 * 64, n_p3 = P / 64 * 64,
                      n_f4 = P / 64 * 64, n_p4 = P / 256 * 64, n_f5 = P / 256 * 64, n_c0 = P / 64 * 128, n_u0 = P / 64 * 64, n_c1 = P / 16 * 128,
-                     n_u1 = P / 16 * 64, n_c2 = P / 4 * 96, n_u2 = P / 4 * 64, n_c3 = P * 80, n_lg = P * 129;
+                     n_u1 = P / 16 * 64, n_c2 = P / 4 * 96, n_u2 = P / 4 * 64, n_c3 = conv_mfma_use_h16() ? 0 : P * 80 /* only the strict-fp32 path materialises [up(u2) | f1] */, n_lg = P * 129;
         const size_t total = B * (n_in + n_f1 + n_p1 + n_f2 + n_p2 + n_f3 + n_p3 + n_f4 + n_p4 + n_f5 + n_c0 + n_u0 + n_c1 + n_u1 + n_c2 + n_u2 + n_c3 + n_lg)
-                             + B * SUM_BLOCKS * 128 * 4 + B * 128 * 4 + 64;
+                             + B * SUM_BLOCKS * 128 * 4 + B * SUM_BLOCKS * 128 * 2 + B * 128 * 4 + 64;
         if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
         float* p = static_cast<float*>(act.p);
         double* sums = reinterpret_cast<double*>(p); p += B * SUM_BLOCKS * 128 * 4;     // [B][SUM_BLOCKS][<= 128 channels] pairs of doubles: per-block partial sums
+        float* mm = p; p += B * SUM_BLOCKS * 128 * 2;                                      // [B][SUM_BLOCKS][<= 128 channels] (min, max): per-block ranges (stats_xf_up)
         float* xf = p; p += B * 128 * 4;
         auto take = [&](size_t n) { float* q = p; p += B * n; return q; };
         float *in4 = take(n_in), *f1 = take(n_f1), *p1 = take(n_p1), *f2 = take(n_f2), *p2 = take(n_p2), *f3 = take(n_f3), *p3 = take(n_p3),
@@ -1323,12 +1437,25 @@ struct DiskNet : kpb_net {
         upcat(u0, f3, c1, H / 8, W / 8, 64, 64);
         if ((rc = stats_xf(c1, P / 16, 128, "up1.slope", sums, xf, batch))) return rc;
         if ((rc = launch_mfma(ctx, "disk_up1", this, L["up1"], c1, u1, batch, H / 4, W / 4, false, false, false, xf))) return rc;
-        upcat(u1, f2, c2, H / 4, W / 4, 64, 32);
-        if ((rc = stats_xf(c2, P / 4, 96, "up2.slope", sums, xf, batch))) return rc;
-        if ((rc = launch_mfma(ctx, "disk_up2", this, L["up2"], c2, u2, batch, H / 2, W / 2, false, false, false, xf))) return rc;
-        upcat(u2, f1, c3, H / 2, W / 2, 64, 16);
-        if ((rc = stats_xf(c3, P, 80, "up3.slope", sums, xf, batch))) return rc;
-        if ((rc = launch_mfma(ctx, "disk_up3", this, L["up3"], c3, lg, batch, H, W, false, false, false, xf))) return rc;
+        const bool fuse_up = conv_mfma_use_h16();        // r06: the concatenated decoder inputs of up_2 and up_3 are not written (profiles/r06_disk_fused_upsample_ab.txt)
+        if (fuse_up) {
+            if ((rc = stats_xf_up(u1, f2, H / 4, W / 4, 64, 32, "up2.slope", sums, mm, xf, batch))) return rc;
+            const UpSrc up{u1, 64};
+            if ((rc = launch_mfma(ctx, "disk_up2", this, L["up2"], f2, u2, batch, H / 2, W / 2, false, false, false, xf, 0, 0.0f, nullptr, nullptr, &up))) return rc;
+        } else {
+            upcat(u1, f2, c2, H / 4, W / 4, 64, 32);
+            if ((rc = stats_xf(c2, P / 4, 96, "up2.slope", sums, xf, batch))) return rc;
+            if ((rc = launch_mfma(ctx, "disk_up2", this, L["up2"], c2, u2, batch, H / 2, W / 2, false, false, false, xf))) return rc;
+        }
+        if (fuse_up) {      // r06: [up(u2) | f1] is not written -- up_3 evaluates the upsampling while it stages, the statistics come from u2 and f1
+            if ((rc = stats_xf_up(u2, f1, H / 2, W / 2, 64, 16, "up3.slope", sums, mm, xf, batch))) return rc;
+            const UpSrc up{u2, 64};
+            if ((rc = launch_mfma(ctx, "disk_up3", this, L["up3"], f1, lg, batch, H, W, false, false, false, xf, 0, 0.0f, nullptr, nullptr, &up))) return rc;
+        } else {
+            upcat(u2, f1, c3, H / 2, W / 2, 64, 16);
+            if ((rc = stats_xf(c3, P, 80, "up3.slope", sums, xf, batch))) return rc;
+            if ((rc = launch_mfma(ctx, "disk_up3", this, L["up3"], c3, lg, batch, H, W, false, false, false, xf))) return rc;
+        }
         KPB_LAUNCH(ctx, "disk_head", disk_head, dim3((unsigned)((B * P + 15) / 16)), dim3(256), 0, st, lg, desc_out, score_out, B * P);
         KPB_HIP(ctx, hipGetLastError());
         return KPB_OK;
