@@ -57,6 +57,19 @@ def main():
     f.update(HOSTF32=num(json.load(open(P + "runner_rate_host.json"))["match_stats"]), HOSTU8=num(json.load(open(P + "runner_rate_u8.json"))["match_stats"]))
     png, jpg = json.load(open(P + "runner_rate_files_png.json")), json.load(open(P + "runner_rate_files_jpeg.json"))
     f.update(PNG=num(png["match_stats"]), JPEG=num(jpg["match_stats"]), PNGPOOL=num(png["decode_pool_alone_pairs_per_s"]), JPEGPOOL=num(jpg["decode_pool_alone_pairs_per_s"]))
+    try:        # r06: HPatches' own format through the file path
+        ppm = json.load(open(P + "runner_rate_files_ppm.json"))
+        f.update(PPM=num(ppm["match_stats"]), PPMPOOL=num(ppm["decode_pool_alone_pairs_per_s"]))
+    except OSError:
+        pass
+    try:        # the head's kernel-trace average of the profiled run of the same command (must agree with the line's HIP-event average)
+        import csv
+        for row in csv.DictReader(open(P + "bench_default_kernel_stats.csv")):
+            if "alike_head_f16p" in row["Name"]:
+                f["HEADTRACE"] = "%.2f" % (float(row["AverageNs"]) / 1e6)
+                f["HEADCALLS"] = row["Calls"]
+    except OSError:
+        pass
     text = open(tmpl).read()
     missing = set(re.findall(r"@@([A-Z0-9]+)@@", text)) - set(f)
     if missing:
