@@ -1941,6 +1941,29 @@ void launch_conv(kpb_ctx* ctx, const char* name, hipStream_t st, const ConvArgs&
     KPB_LAUNCH(ctx, name, (conv3x3_k<CIN, COUT, POOL, RES, CDS, RPOOL, true, DSOUT, TW>), dim3(cdiv(a.W, TW), cdiv(a.H, TH), B), dim3(256), 0, st, a);
 }
 
+// max_pool2d(x, 4, 4) of an NHWC map (ALike.py:143, block 4's input): one thread per pooled pixel and channel quad.  At batch size block 4's conv1 reads this
+// (19.7 MB per 512 images) instead of max-pooling x3 itself while it stages: sixteen loads per staged value, by four workgroups per tile (r06: 0.26 -> ms).
+__global__ __launch_bounds__(256) void maxpool4_nhwc(const float* __restrict__ in, float* __restrict__ out, int Ho, int Wo, int C)
+{
+    const int C4 = C / 4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= (size_t)Ho * Wo * C4) return;
+    const int c = (int)(i % C4) * 4;
+    const size_t pix = i / C4;
+    const int y = (int)(pix / Wo), x = (int)(pix - (size_t)y * Wo);
+    const float* s = in + ((b * 4 * Ho + 4 * y) * (size_t)(4 * Wo) + 4 * x) * C + c;
+    float4 m = *reinterpret_cast<const float4*>(s);
+#pragma unroll
+    for (int py = 0; py < 4; ++py)
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            if (py == 0 && px == 0) continue;
+            const float4 v = *reinterpret_cast<const float4*>(s + ((size_t)py * 4 * Wo + px) * C);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    *reinterpret_cast<float4*>(out + ((b * Ho + y) * (size_t)Wo + x) * C + c) = m;
+}
+
 int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* score_out_dev, float* desc_out_dev)
 {
     if ((H_ % 32) || (W_ % 32))
@@ -1955,7 +1978,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     const size_t n_p1 = B * (P / 4) * 8;
     const int nw1 = cdiv(W, B1_TW) * cdiv(H, B1H_TH) * 4, nw2 = cdiv(W / 2, 32) * cdiv(H / 2, 8) * 4;      // per-wave maxima of blocks 1 / 2
     const size_t n_rng = (2 * B + B * (nw1 + nw2) + 63) / 64 * 64;
-    const size_t total = n_x1 + n_p1 + 3 * n_2 + 6 * n_3 + n_a3 + 5 * n_4 + n_a4 + n_s + n_e + n_rng;
+    const size_t total = n_x1 + n_p1 + 3 * n_2 + 6 * n_3 + n_a3 + 5 * n_4 + n_4 / 2 + n_a4 + n_s + n_e + n_rng;
     if (int rc = kpb_reserve(ctx, act, total * sizeof(float))) return rc;
     float* p = static_cast<float*>(act.p);
     x1 = p; p += n_x1;
@@ -1968,6 +1991,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
     float* t3r3 = p; p += 2 * n_3;      // conv_mfma_h form of blocks 3 / 4: conv1's output and the identity branch side by side per pixel
     float* t4r4 = p; p += 2 * n_4;
     float* p2 = p; p += n_3 / 2;        // max_pool2d(x2, 4): [B][H/8][W/8][16]
+    float* p3 = p; p += n_4 / 2;        // max_pool2d(x3, 4): [B][H/32][W/32][32] (batches: maxpool4_nhwc)
     S2 = p; p += B * (P / 4); S3 = p; p += B * (P / 64); S4 = p; p += B * (P / 1024) + 64;
     E3 = E4 = nullptr;
     if (desc_out_dev) { E3 = p; p += B * (P / 64) * ESTRIDE; E4 = p; p += B * (P / 1024) * ESTRIDE; }
@@ -2007,6 +2031,7 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             const std::string tag1 = std::string("conv3x3_") + n1, tag2 = std::string("conv3x3_") + n2;
             // small layers are bound by per-workgroup latency: 8-row tiles (r02: b3c1 0.36 -> 0.32 ms, b3c2 0.58 -> 0.49 ms)
             if (prepooled && batch < 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 2, 1, false, 2, true>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
+            else if (prepooled && cin == 32) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, false, false, false, 1, 4, false, 2, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk), dim3(256), 0, st, m);
             else if (prepooled) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 16, false, false, false, 1, 2, false, 2, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 8), batch * m.nblk), dim3(256), 0, st, m);
             else if (batch >= 16) KPB_LAUNCH(ctx, tag1.c_str(), (conv_mfma_h<3, 1, 32, true, false, false, 1, 4, false, 4, false, false, 2>), dim3(cdiv(m.W, 16), cdiv(m.H, 16), batch * m.nblk), dim3(256), 0, st, m);
             else {      // a handful of images (the drop-in path runs ONE): a 15 x 20 map in 16 x 16 tiles with two n-tiles each is 4 workgroups of
@@ -2029,7 +2054,11 @@ int AlikeNet::forward(const float* img_dev, int batch, int H_, int W_, float* sc
             }
         };
         block_h("b3c1", "b3c2", p2, t3r3, x3, 16, 32, H / 2, W / 2, true);
-        block_h("b4c1", "b4c2", x3, t4r4, x4, 32, 64, H / 8, W / 8, false);
+        if (batch >= 16) {      // block 4's input pooled once, by a kernel of its own (see maxpool4_nhwc); a handful of images keep the fused form (one launch fewer)
+            KPB_LAUNCH(ctx, "maxpool4_x3", maxpool4_nhwc, dim3((unsigned)(((size_t)(H / 32) * (W / 32) * 8 + 255) / 256), batch), dim3(256), 0, st, x3, p3, H / 32, W / 32, 32);
+            block_h("b4c1", "b4c2", p3, t4r4, x4, 32, 64, H / 8, W / 8, true);
+        } else
+            block_h("b4c1", "b4c2", x3, t4r4, x4, 32, 64, H / 8, W / 8, false);
     } else {
         // strict fp32: block 1 and the 3x3 convolutions on the fp32 vector ALUs, conv2 of blocks 3 / 4 on the fp32 MFMA
         KPB_LAUNCH(ctx, "alike_block1", alike_block1, dim3(cdiv(W, B1_TW), cdiv(H, B1_TH), batch), dim3(256), 0, st, b1);
