@@ -26,19 +26,33 @@ struct NmsArgs {
     int* tchg_cur;      // [B][ntiles] flags written by this sweep
     int* lastchg;       // [B] 1 + index of the last sweep that changed anything
     int* negflag;       // [B] set when a negative score is seen
-    int* ucount;        // [B] sweep 0 of nms_sweep_r: number of pixels it left undecided (alive, not confirmed) ...
-    int2* ulist;        // [B][2][ucap] ... as (raster index, -1) (null: not collected)
-    int ucap;
-    // top-K pruning (kpb_detect with top_k < H*W): sweep 0 also lists the scores of the maxima it CONFIRMED inside the border
-    // frame and above the output thresholds; if an image has more than top_k of them, nothing that scores below the
-    // (top_k+1)-th can reach the output, and nms_tail drops those undecided pixels unresolved
-    float* clist;       // [B][ccap] (null: no pruning)
-    int* ccount;        // [B]
-    int ccap, border;
+    // What sweep 0 of nms_sweep_r hands to nms_tail (r06; r03 .. r05 built two lists per image here -- the appends, two returning global atomics per
+    // tile and the list flush were 17 % of the kernel, profiles/r06_nms_knockouts.txt):
+    //   ubits  [B][H][wb] bytes (wb = W / 8 rounded up to a multiple of 4): bit (y, x) = pixel left undecided (alive, not confirmed); one byte = the
+    //          eight pixels an owner thread holds anyway.  nms_tail builds its watch list from them.  Null: not collected.
+    //   chist  [B][NMS_HBINS] counters, top-K pruning (kpb_detect with top_k < H*W; null: none): a histogram of the scores of the maxima sweep 0
+    //          CONFIRMED inside the border frame and above the output thresholds, one fire-and-forget atomic each.  If an image has more than top_k of
+    //          them, nothing that scores below the (top_k+1)-th can reach the output, and nms_tail drops those undecided pixels unresolved; the lower
+    //          edge of the bin that holds the (top_k+1)-th is such a bound (nms_score_bin).
+    unsigned char* ubits; int wb;
+    unsigned* chist;
+    int border;
     float cmin;         // a confirmed maximum counts when its score is > cmin (threshold / min_score of the detection)
     int H, W, r, tiles_y, tiles_x, sweep, max_local;
     int xcd_map;        // kpb_xcd_tile (nms_sweep_r)
 };
+
+// Bin of a positive score: 64 bins per octave (the six leading mantissa bits) over the 64 octaves [2^-62, 4); what lies outside goes to the end bins.
+// nms_bin_floor(b) <= every score of bin b (0 for bin 0: no bound).  Any T at or below the true (top_k+1)-th score prunes correctly; this one is at
+// most 1.6 % below it.
+constexpr int NMS_HBINS = 4096, NMS_HBASE = (129 << 6) - NMS_HBINS;
+__device__ __forceinline__ int nms_score_bin(float v)
+{
+    const int key = (int)(__float_as_uint(v) >> 17) - NMS_HBASE;
+    return min(max(key, 0), NMS_HBINS - 1);
+}
+__device__ __forceinline__ float nms_bin_floor(int b) { return b > 0 ? __uint_as_float((unsigned)(b + NMS_HBASE) << 17) : 0.0f; }
+
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_sweep(NmsArgs a)
 {
@@ -254,9 +268,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
     __shared__ unsigned hm[NHS * HMR / 4];
     __shared__ int maxlist[MAXLIST];
     __shared__ int s_n[2], s_changed, s_over;
-    constexpr int CLOCAL = 256;
-    __shared__ float clocal[CLOCAL];
-    __shared__ int s_nc, s_cbase;
 
     const kpb_tile3 wg = kpb_xcd_tile(a.xcd_map);      // neighbouring tiles (they re-read each other's 2R halo) on one XCD's L2
     const int img = wg.y, tile = wg.x, tid = threadIdx.x, lane = tid & 63;
@@ -478,69 +489,18 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 
     const int by = ty * TH, bx = tx * TW;
     int changed = 0;
-    if (first && (a.ulist || a.clist)) {     // the local rounds are over: maxlist and its counter are reused for the undecided pixels
-        __syncthreads();
-        if (tid == 0) { s_n[0] = 0; s_over = 0; s_nc = 0; }
-        __syncthreads();
-    }
-    // r06: the set bits of every lane's mask go to a list in LDS with ONE atomic per wave: an inclusive scan of the lanes' bit counts on the vector
-    // ALU gives each lane its offset.  (r03 .. r05: one LDS atomic per lane with any bit -- about a hundred adds to the same word per tile, serialised,
-    // in the write-back phase that the stamps put at 4.1 k of a workgroup's 24 k cycles.)  put(slot, k): store bit k's entry at `slot`.
-    auto append_scan = [&](unsigned mask, int* counter, auto&& put) {
-        const int c = __popc(mask);
-        const int incl = kpb_wave_incl_scan(c);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        if (total) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(counter, total);
-            int slot = __builtin_amdgcn_readfirstlane(base) + incl - c;
-            while (mask) {
-                const int k = __ffs((int)mask) - 1;
-                mask &= mask - 1;
-                put(slot, k);
-                ++slot;
-            }
-        }
-    };
-    // write-back: eight pixels per owner thread, 16-byte stores where the row allows them.  r06 order: the tile's pixels are read and classified and
-    // the two lists built in LDS FIRST; then the two global counters are bumped (returning atomics, one lane each) and the map stores go out UNDER
-    // their round trip; the lists follow once the bases are back.  (r05: stores, then lists, then the atomics with every wave waiting at the barrier
-    // for their return -- 1.7 k cycles at the end of every workgroup.)
+    // write-back: eight pixels per owner thread, 16-byte stores where the row allows them; in sweep 0 the owner's byte of the two hand-off bitmaps (NmsArgs::ubits)
     const int gy = by + oy, gx = bx + ox;
     const bool mine = owner && gy < a.H && gx < a.W;
     const bool whole = gx + 8 <= a.W;
-    unsigned umask = 0, cmask = 0, diff = 0;
-    float v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 0.0f;
     if (mine) {
+        unsigned umask = 0, cmask = 0, diff = 0;
+        float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = t[(oy + 2 * R) * PITCH + ox + 2 * R + k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) if ((whole || gx + k < a.W) && v[k] != orig[k]) diff |= 1u << k;
         if (diff) changed = 1;
-        if (first) {
-            const bool rows_in = gy >= a.border && gy < a.H - a.border;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const bool in = whole || gx + k < a.W;
-                if (in && v[k] > 0.0f) umask |= 1u << k;        // what this tile could not settle goes to nms_tail
-                // scores of the maxima confirmed here that the detection could output
-                if (in && v[k] < 0.0f && -v[k] > a.cmin && rows_in && gx + k >= a.border && gx + k < a.W - a.border) cmask |= 1u << k;
-            }
-        }
-    }
-    if (first && a.ulist) append_scan(umask, &s_n[0], [&](int slot, int k) { if (slot < MAXLIST) maxlist[slot] = gy * a.W + gx + k; else s_over = 1; });
-    if (first && a.clist) append_scan(cmask, &s_nc, [&](int slot, int k) { if (slot < CLOCAL) clocal[slot] = -v[k]; });
-    if (changed) s_changed = 1;
-    __syncthreads();
-    // both lists are flushed in one phase: their two global counters are bumped by two different waves, in flight together
-    const int cnt_c = (first && a.clist) ? s_nc : 0;
-    const int cnt_u = (first && a.ulist) ? min(s_n[0], MAXLIST) : 0;
-    int got = 0;
-    if (tid == 0 && cnt_c) got = atomicAdd(&a.ccount[img], cnt_c > CLOCAL ? a.ccap + cnt_c : cnt_c);      // overflow of the tile's list: poison the count
-    if (tid == 64 && cnt_u) got = atomicAdd(&a.ucount[img], s_over ? a.ucap + cnt_u : cnt_u);             // likewise
-    if (mine) {
         float* o = out + (size_t)gy * a.W + gx;
         if (first && whole && (a.W & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
             *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -549,21 +509,30 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 #pragma unroll
             for (int k = 0; k < 8; ++k) if ((whole || gx + k < a.W) && (first || ((diff >> k) & 1u))) o[k] = v[k];
         }
+        if (first && a.ubits) {
+            const bool rows_in = gy >= a.border && gy < a.H - a.border;
+            unsigned* hist = a.chist ? a.chist + (size_t)img * NMS_HBINS : nullptr;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool in = whole || gx + k < a.W;
+                if (in && v[k] > 0.0f) umask |= 1u << k;        // what this tile could not settle goes to nms_tail
+                // the maxima confirmed here that the detection could output: their scores bound what can reach the top_k
+                if (hist && in && v[k] < 0.0f && -v[k] > a.cmin && rows_in && gx + k >= a.border && gx + k < a.W - a.border) cmask |= 1u << k;
+            }
+            while (cmask) {         // few bits a thread (maxima lie more than R apart): a loop over them, the score re-read from the tile
+                const int k = __ffs((int)cmask) - 1;
+                cmask &= cmask - 1;
+                atomicAdd(&hist[nms_score_bin(-t[(oy + 2 * R) * PITCH + ox + 2 * R + k])], 1u);
+            }
+            a.ubits[((size_t)img * a.H + gy) * a.wb + (gx >> 3)] = (unsigned char)umask;
+        }
     }
+    if (changed) s_changed = 1;
+    __syncthreads();
     if (tid == 128) {
         const int flag = (s_changed || unconverged) ? 1 : 0;
         tcur[tile] = flag;
         if (flag) atomicMax(&a.lastchg[img], a.sweep + 1);
-    }
-    if (cnt_c || cnt_u) {
-        if (tid == 0 && cnt_c) s_cbase = got;
-        if (tid == 64 && cnt_u) s_n[1] = got;
-        __syncthreads();
-        const int cb = s_cbase, ub = s_n[1];
-        for (int i = tid; i < min(cnt_c, CLOCAL); i += NMS_THREADS)
-            if (cb + i < a.ccap) a.clist[(size_t)img * a.ccap + cb + i] = clocal[i];
-        for (int i = tid; i < cnt_u; i += NMS_THREADS)
-            if (ub + i < a.ucap) a.ulist[(size_t)img * 2 * a.ucap + ub + i] = make_int2(maxlist[i], -1);
     }
 }
 
@@ -578,9 +547,10 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
 // The best undecided pixel always has a settled blocker, so every round settles something; reads of a neighbour's
 // stale state only delay a decision.  If the round limit is hit, status = 1 sends the image back to the tiled sweeps.
 struct TailArgs {
-    float* cur; int2* wlist; int* slist; int* ucount; int* status;
+    float* cur; int2* wlist; int* slist; int* status;
     int ucap, H, W, r, max_rounds;
-    const float* clist; const int* ccount; int ccap, top_k;      // top-K pruning (see NmsArgs); clist null: none
+    const unsigned char* ubits; int wb;         // sweep 0's bitmap of undecided pixels (NmsArgs)
+    const unsigned* chist; int top_k;           // top-K pruning (NmsArgs); chist null: none
 };
 
 constexpr int TAIL_THREADS = 1024;
@@ -594,48 +564,108 @@ __global__ __launch_bounds__(TAIL_THREADS) void nms_tail(TailArgs a)
     float* cur = a.cur + (size_t)img * a.H * a.W;
     int2* wl[2] = {a.wlist + (size_t)img * 2 * a.ucap, a.wlist + (size_t)img * 2 * a.ucap + a.ucap};
     int* sl = a.slist + (size_t)img * a.ucap;
-    __shared__ int s_nw, s_ns;
-    __shared__ unsigned s_hist[256], s_prefix, s_krem;
-    const int total = a.ucount[img];
-    int nw = total <= a.ucap ? total : 0;       // an overflowed list is incomplete (and partly unwritten): leave the image to the tiled sweeps
-    const unsigned long long gmask = 0xFFFFull << (lane & 48);
-    // Top-K pruning.  The detection outputs the top_k best survivors.  If sweep 0 has already CONFIRMED more than top_k maxima
-    // that qualify for the output, let T be the (top_k+1)-th best of their scores: at least top_k+1 survivors score >= T, so
-    // (i) N > top_k holds whatever the undecided pixels turn out to be, and (ii) no pixel that scores below T can be among
-    // the top_k.  A pixel's fate depends only on pixels that outrank it, so the undecided pixels >= T can be resolved
-    // exactly while those below T are dropped unresolved (they stay positive in the map; select_topk takes confirmed maxima
-    // only).  Radix select of T over the listed scores (positive floats order like their bit patterns), 8 bits a pass.
-    float Tprune = 0.0f;
+    __shared__ int s_nw, s_ns, s_bin, s_wsum[TAIL_THREADS / 64];
+    // the four bins of sweep 0's score histogram this thread will scan: on their way while the watch list is built
+    uint4 hb = make_uint4(0, 0, 0, 0);
+    const bool prune = a.chist && a.top_k > 0;
+    if (prune) hb = reinterpret_cast<const uint4*>(a.chist + (size_t)img * NMS_HBINS)[tid];
+    static_assert(NMS_HBINS == 4 * TAIL_THREADS, "four bins per thread");
+    // r06: the watch list is built HERE from sweep 0's bitmap of undecided pixels, as (raster index, no blocker) entries: a 32-bit word (32 pixels of a
+    // row) per thread, CH words per trip with their loads in flight together, one scan and one LDS atomic per wave and trip (the order of the list is
+    // free).  A wave's set bits become raster indices in the wave's own LDS strip first, each lane writing at its scanned offset; the wave then reads the
+    // strip back LINEARLY -- lane i takes entry i -- so that the stores to the list are whole 512-byte runs.  (First form: the lanes stored their own bits
+    // straight to the list, every store instruction touching ~20 lines: +0.03 ms, profiles/r06_nms_knockouts.txt.)
+    if (tid == 0) { s_nw = 0; s_ns = 0; s_bin = -1; }
+    __syncthreads();
     {
-        const int nc = a.clist ? a.ccount[img] : 0;
-        if (a.top_k > 0 && nc > a.top_k && nc <= a.ccap) {
-            const float* cl = a.clist + (size_t)img * a.ccap;
-            if (tid == 0) { s_prefix = 0; s_krem = (unsigned)(a.top_k + 1); }
-            for (int shift = 24; shift >= 0; shift -= 8) {
-                if (tid < 256) s_hist[tid] = 0;
-                __syncthreads();
-                const unsigned prefix = s_prefix;
-                const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
-                for (int i = tid; i < nc; i += TAIL_THREADS) {
-                    const unsigned k = __float_as_uint(cl[i]);
-                    if ((k & himask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255u], 1u);
-                }
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned krem = s_krem, cum = 0;
-                    int d = 255;
-                    for (; d > 0; --d) {
-                        if (cum + s_hist[d] >= krem) break;
-                        cum += s_hist[d];
-                    }
-                    s_krem = krem - cum;
-                    s_prefix = prefix | ((unsigned)d << shift);
-                }
-                __syncthreads();
+        const int wq = a.wb / 4, nwords = a.H * wq, vb = (a.W + 7) / 8;     // wb is a multiple of 4 (nms_plan); bytes vb .. wb - 1 of a row are never written
+        const unsigned char* ub = a.ubits + (size_t)img * a.H * a.wb;
+        constexpr int CH = 4, WBUF = 640;
+        __shared__ int s_strip[TAIL_THREADS / 64][WBUF];
+        int* strip = s_strip[tid >> 6];
+        for (int w0 = 0; w0 < nwords; w0 += CH * TAIL_THREADS) {
+            unsigned um[CH];
+            int base_idx[CH], c = 0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int w = w0 + j * TAIL_THREADS + tid;
+                const bool live = w < nwords;
+                const int row = live ? w / wq : 0, q = live ? w - row * wq : 0;
+                unsigned word = live ? *reinterpret_cast<const unsigned*>(ub + (size_t)row * a.wb + 4 * q) : 0u;
+                const int nb = vb - 4 * q;
+                if (nb < 4) word &= (1u << (8 * nb)) - 1u;       // the bytes past the row's end
+                um[j] = word;
+                base_idx[j] = row * a.W + 32 * q;
             }
-            Tprune = __uint_as_float(s_prefix);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) c += __popc(um[j]);
+            const int incl = kpb_wave_incl_scan(c), tot = __builtin_amdgcn_readlane(incl, 63);
+            if (tot == 0) continue;
+            int b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&s_nw, tot);
+            b0 = __builtin_amdgcn_readfirstlane(b0);
+            const bool fits = tot <= WBUF;
+            int slot = incl - c;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                unsigned mm = um[j];
+                while (mm) {
+                    const int k = __ffs((int)mm) - 1;
+                    mm &= mm - 1;
+                    if (fits) strip[slot] = base_idx[j] + k;
+                    else if (b0 + slot < a.ucap) wl[0][b0 + slot] = make_int2(base_idx[j] + k, -1);       // a crowded wave: the slow way
+                    ++slot;
+                }
+            }
+            if (fits) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < tot; i += 64)
+                    if (b0 + i < a.ucap) wl[0][b0 + i] = make_int2(strip[i], -1);
+                __builtin_amdgcn_wave_barrier();        // the strip is free again
+            }
         }
     }
+    // Top-K pruning.  The detection outputs the top_k best survivors.  If sweep 0 has already CONFIRMED more than top_k maxima that qualify for the
+    // output, let T be at or below the (top_k+1)-th best of their scores: at least top_k+1 survivors score >= T, so (i) N > top_k holds whatever the
+    // undecided pixels turn out to be, and (ii) no pixel that scores below T can be among the top_k.  A pixel's fate depends only on pixels that
+    // outrank it, so the undecided pixels >= T can be resolved exactly while those below T are dropped unresolved (they stay positive in the map;
+    // select_topk takes confirmed maxima only).  T = the floor of the histogram bin that holds the (top_k+1)-th best: a block scan of the bin counts.
+    int above = 0;
+    if (prune) {
+        const int mine = (int)(hb.x + hb.y + hb.z + hb.w), incl = kpb_wave_incl_scan(mine);
+        if (lane == 63) s_wsum[tid >> 6] = incl;
+        above = incl;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int total = s_nw;
+    float Tprune = 0.0f;
+    if (prune) {
+        int before = 0, n = 0;
+#pragma unroll
+        for (int w = 0; w < TAIL_THREADS / 64; ++w) {
+            const int v = s_wsum[w];
+            before += w < (tid >> 6) ? v : 0;
+            n += v;
+        }
+        if (n > a.top_k) {
+            const int need = a.top_k + 1;
+            const unsigned h[4] = {hb.x, hb.y, hb.z, hb.w};
+            int ab = n - (before + above);      // confirmed maxima in the bins beyond this thread's four
+#pragma unroll
+            for (int j = 3; j >= 0; --j) {
+                if (ab < need && ab + (int)h[j] >= need) s_bin = 4 * tid + j;       // exactly one thread and bin
+                ab += (int)h[j];
+            }
+        }
+        __syncthreads();
+        const int b = s_bin;
+        if (b >= 0) Tprune = nms_bin_floor(b);
+    }
+    __syncthreads();
+    int nw = total <= a.ucap ? total : 0;       // an overflowed list is incomplete (and partly unwritten): leave the image to the tiled sweeps
+    const unsigned long long gmask = 0xFFFFull << (lane & 48);
     int round = 0;
     for (; round < a.max_rounds && nw > 0; ++round) {
         if (tid == 0) { s_nw = 0; s_ns = 0; }
@@ -1046,14 +1076,14 @@ struct NmsPlan {
     int* tchg[2];
     int* lastchg;
     int* negflag;
-    int* ucount;        // sparse tail (r <= 8): undecided pixels of sweep 0
-    int2* ulist;        // [B][2][ucap] watch lists (ping-pong)
+    int2* ulist;        // sparse tail (r <= 8): [B][2][ucap] watch lists (ping-pong)
     int* slist;         // [B][ucap] pixels due for a window scan
     int ucap;
-    float* clist;       // [B][ccap] scores of confirmed maxima (top-K pruning); null when off
-    int* ccount;
-    int ccap, prune_k, border;
+    unsigned* chist;    // [B][NMS_HBINS] score histogram of the confirmed maxima (top-K pruning); null when off
+    int prune_k, border;
     float cmin;
+    unsigned char* ubits; int wb;       // [B][H][wb] sweep 0's bitmap of undecided pixels (NmsArgs)
+    size_t nclear;      // ints at lastchg that nms_open clears: lastchg, negflag and the histograms
 };
 
 int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p, int prune_k = 0, int border = 0, float cmin = 0.0f)
@@ -1064,30 +1094,32 @@ int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p, int prune
     const int LH = TH + 4 * r, LW = TW + 4 * r;
     p.lds = (size_t)2 * LH * LW * sizeof(float) + (MAXLIST + 4) * sizeof(int);
     const size_t nflag = (size_t)batch * p.ntiles;
-    const size_t bytes = (2 * nflag + 4 * (size_t)batch) * sizeof(int);
-    if (int rc = kpb_reserve(ctx, ctx->ws_nms_state, bytes)) return rc;
-    int* base = static_cast<int*>(ctx->ws_nms_state.p);
-    p.lastchg = base;
-    p.negflag = base + batch;
-    p.ucount = base + 2 * batch;
-    p.ccount = base + 3 * batch;
-    p.tchg[0] = base + 4 * batch;
-    p.tchg[1] = p.tchg[0] + nflag;
-    p.ulist = nullptr;
-    p.ucap = 0;
-    p.clist = nullptr; p.ccap = 0; p.prune_k = 0; p.border = border; p.cmin = cmin;
     // The tail is one workgroup per image and latency-bound (about 1.4 ms whatever the batch); four more tiled sweeps
     // cost about 8 us per 480x640 image.  It pays once the batch fills the chip.  KPB_NMS_TILED=1 / =0 force a choice.
     const int tiled = env_int("KPB_NMS_TILED", -1);
     const bool big = (size_t)batch * H * W >= (size_t)192 * 480 * 640;
-    if (r >= 1 && r <= 8 && (tiled == 0 || (tiled < 0 && big))) {
+    const bool tail = r >= 1 && r <= 8 && (tiled == 0 || (tiled < 0 && big));
+    const bool prune = tail && prune_k > 0 && prune_k < H * W && env_int("KPB_NMS_PRUNE", 1);
+    const size_t head = (2 * (size_t)batch + 3) & ~(size_t)3;        // lastchg[B], negflag[B]; the histograms start on 16 bytes (nms_tail reads uint4s)
+    p.nclear = head + (prune ? (size_t)batch * NMS_HBINS : 0);
+    if (int rc = kpb_reserve(ctx, ctx->ws_nms_state, (p.nclear + 2 * nflag) * sizeof(int))) return rc;
+    int* base = static_cast<int*>(ctx->ws_nms_state.p);
+    p.lastchg = base;
+    p.negflag = base + batch;
+    p.chist = prune ? reinterpret_cast<unsigned*>(base + head) : nullptr;
+    p.tchg[0] = base + p.nclear;
+    p.tchg[1] = p.tchg[0] + nflag;
+    p.ulist = nullptr;
+    p.ucap = 0;
+    p.prune_k = prune ? prune_k : 0; p.border = border; p.cmin = cmin;
+    p.ubits = nullptr; p.wb = 0;
+    if (tail) {
         p.ucap = std::max(4096, H * W / 8);
-        const bool prune = prune_k > 0 && prune_k < H * W && env_int("KPB_NMS_PRUNE", 1);
-        p.ccap = prune ? std::min(H * W, 16384) : 0;
-        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * (5 * (size_t)p.ucap + p.ccap) * sizeof(int))) return rc;
+        p.wb = (cdiv(W, 8) + 3) & ~3;
+        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * 5 * (size_t)p.ucap * sizeof(int) + (size_t)batch * H * p.wb)) return rc;
         p.ulist = static_cast<int2*>(ctx->ws_nms_list.p);
         p.slist = reinterpret_cast<int*>(p.ulist + (size_t)batch * 2 * p.ucap);
-        if (prune) { p.clist = reinterpret_cast<float*>(p.slist + (size_t)batch * p.ucap); p.prune_k = prune_k; }
+        p.ubits = reinterpret_cast<unsigned char*>(p.slist + (size_t)batch * p.ucap);
     }
     if (!(ctx->lds_attr_done & KPB_ATTR_NMS)) {
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep),
@@ -1108,8 +1140,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.tchg_prev = p.tchg[(s + 1) & 1];
         a.tchg_cur = p.tchg[s & 1];
         a.lastchg = p.lastchg; a.negflag = p.negflag;
-        a.ucount = p.ucount; a.ulist = p.ulist; a.ucap = p.ucap;
-        a.clist = p.clist; a.ccount = p.ccount; a.ccap = p.ccap; a.border = p.border; a.cmin = p.cmin;
+        a.ubits = p.ubits; a.wb = p.wb; a.chist = p.chist; a.border = p.border; a.cmin = p.cmin;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s;
         a.xcd_map = 1;      // -1 % (profiles/r04_ab_knobs.txt)
@@ -1117,7 +1148,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         // then; measured: 3 rounds 2.26 + 1.49 ms, 5 rounds 2.75 + 1.39 ms, 2 rounds 1.87 + 2.52 ms per 512 images)
         // with top-K pruning the tail is cheap and two rounds are the optimum (r02: 2 rounds 2.19 + <0.2 ms, 3 rounds 2.57 + <0.2 ms;
         // one round confirms too few maxima for the bound and the tail overflows)
-        a.max_local = (p.ulist && s == 0) ? (p.clist ? 2 : 3) : 64;
+        a.max_local = (p.ulist && s == 0) ? (p.chist ? 2 : 3) : 64;
         const dim3 grid(p.ntiles, batch), block(NMS_THREADS);
         switch (r) {
         case 1: KPB_LAUNCH(ctx, "nms_sweep", nms_sweep_r<1>, grid, block, 0, ctx->stream, a); break;
@@ -1142,13 +1173,13 @@ int nms_open(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int b
 {
     if ((size_t)H * W >= ((size_t)1 << 30))       // nms_sweep_r addresses a pixel by a 32-bit BYTE offset from its image
         return kpb_fail(ctx, KPB_E_UNSUPPORTED, "NMS: a %d x %d map is too large (2^30 pixels per image at most)", H, W);
-    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, 4 * (size_t)batch * sizeof(int), ctx->stream));
+    KPB_HIP(ctx, hipMemsetAsync(p.lastchg, 0, p.nclear * sizeof(int), ctx->stream));
     if (!p.ulist) {
         sweeps_run = chunk;
         return nms_launch(ctx, p, src, cur, batch, H, W, r, 0, chunk);
     }
     if (int rc = nms_launch(ctx, p, src, cur, batch, H, W, r, 0, 1)) return rc;
-    TailArgs t{cur, p.ulist, p.slist, p.ucount, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256), p.clist, p.ccount, p.ccap, p.prune_k};
+    TailArgs t{cur, p.ulist, p.slist, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256), p.ubits, p.wb, p.chist, p.prune_k};
     switch (r) {
     case 1: KPB_LAUNCH(ctx, "nms_tail", nms_tail<1>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
     case 2: KPB_LAUNCH(ctx, "nms_tail", nms_tail<2>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;

@@ -219,3 +219,33 @@ def test_topk_pruned_tail_is_exact(prune, monkeypatch):
             got = detection(torch.from_numpy(m)[None, None].to(_dev()), p).cpu().numpy()
             want, _ = oracle.detection(m, p)
             np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg="%s %r" % (mname, p))
+
+
+def test_nms_tail_handoff_bitmap_and_histogram_edges(monkeypatch):
+    """r06: sweep 0 hands the tail a bitmap of undecided pixels (one byte per eight pixels, rows padded to four bytes) and a 4 096-bin histogram of
+    the confirmed scores.  The corners of that hand-off: an odd batch (the histograms must still start on 16 bytes), a width that fills neither the
+    last byte nor the last word of a bitmap row, a band of plateaus dense enough that a wave's bits overflow its LDS strip (the direct-store
+    fallback) while the image stays under the list capacity, and scores far outside [2^-62, 4) (the histogram's end bins: a bound of 0 or a floor
+    below every score -- still exact)."""
+    from keypoint_bench_amd.utils.extracter import detection_batch, fast_nms
+    monkeypatch.setenv("KPB_NMS_TILED", "0")            # small batches default to the tiled sweeps: force sweep 0 + tail
+    rng = np.random.default_rng(61)
+    H, W = 237, 301
+    band = synthetic.score_smooth(62, H, W).copy()
+    band[:20] = (np.floor(rng.random((20, W)) * 3) / 4 + 0.25).astype(np.float32)      # 20 of 237 rows: ~6 000 undecided pixels, capacity 8 917
+    maps = np.stack([synthetic.score_uniform(63, H, W), band, synthetic.score_smooth(64, H, W)])[:, None]
+    for r in (2, 6):
+        got = fast_nms(torch.from_numpy(maps).to(_dev()), r).cpu().numpy()
+        for b in range(3):
+            exp, _ = oracle.fast_nms(maps[b, 0], r)
+            np.testing.assert_array_equal(got[b, 0], exp, err_msg="r %d image %d" % (r, b))
+    for scale in (1.0, 2.0 ** -70, 37.5):
+        m = (maps * np.float32(scale)).astype(np.float32)
+        for nms, top_k, border in ((2, 300, 3), (6, 40, 0)):
+            p = dict(nms_dist=nms, threshold=0.0, border_dist=border, top_k=top_k, min_score=0.0)
+            kps, _, n = detection_batch(torch.from_numpy(m).to(_dev()), p)
+            kps, n = kps.cpu().numpy(), n.cpu().numpy()
+            for b in range(3):
+                want, _ = oracle.detection(m[b, 0], p)
+                assert int(n[b]) == len(want), (scale, b, p)
+                np.testing.assert_array_equal(kps[b, : n[b]].view(np.uint32), want.view(np.uint32), err_msg="scale %g image %d %r" % (scale, b, p))
