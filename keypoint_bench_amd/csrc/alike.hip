@@ -660,12 +660,11 @@ __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, b = tile.z;
     const int ty0 = tile.y * TH, tx0 = tile.x * TW;
     const size_t P = (size_t)a.H * a.W;
+    // r06: conv2's and agg2's fragments (48 registers) are requested AFTER conv1 -- while conv1 runs they would only keep the allocator from holding conv1's six
+    // operand pieces in flight together (below); their round trip hides behind the barrier between the two products.
     h8v w1h[3], w1l[3], w2h[5], w2l[5];
 #pragma unroll
     for (int kb = 0; kb < 3; ++kb) { w1h[kb] = __builtin_bit_cast(h8v, a.w1pk[(kb * 2) * 64 + lane]); w1l[kb] = __builtin_bit_cast(h8v, a.w1pk[(kb * 2 + 1) * 64 + lane]); }
-#pragma unroll
-    for (int kb = 0; kb < 5; ++kb) { w2h[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2) * 64 + lane]); w2l[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2 + 1) * 64 + lane]); }
-    const h8v wah = __builtin_bit_cast(h8v, a.wapk[lane]), wal = __builtin_bit_cast(h8v, a.wapk[64 + lane]);
     // the lane's biases and score weights are requested with the fragments (read where they are used, each was an exposed round trip)
     const float4 b1v = *reinterpret_cast<const float4*>(a.b1 + 4 * (lane >> 4));
     const float4 bsum = *reinterpret_cast<const float4*>(a.bsum + 4 * (lane >> 4)), wsg = *reinterpret_cast<const float4*>(a.wsg + 4 * (lane >> 4));
@@ -735,12 +734,17 @@ __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.
             const uint4* q2 = has2 ? &pin[(y0 + 2) * PW + xl + 2] : zp;
             const int st2 = has2 ? 2 * PW : 0, lo2 = has2 ? NP : 0;
             int h8 = (((g >> 1) * NM + y0 * MW + xl) << 1) + (g & 1);
+            // r06: a group's six operand pieces are requested while the PREVIOUS group's epilogue (ReLU, split, two LDS writes) runs, all six in flight
+            // together.  Left alone the scheduler re-used ONE register quad for them -- ds_read_b128, s_waitcnt lgkmcnt(0), MFMA, six times per group: six
+            // exposed LDS round trips (profiles/r06_block2_operand_prefetch_ab.txt).
+            constexpr int NIT = 2 * MH / 4;
+            h8v i0h = __builtin_bit_cast(h8v, q0[0]), i0l = __builtin_bit_cast(h8v, q0[NP]);
+            h8v i1h = __builtin_bit_cast(h8v, q1[0]), i1l = __builtin_bit_cast(h8v, q1[NP]);
+            h8v i2h = __builtin_bit_cast(h8v, q2[0]), i2l = __builtin_bit_cast(h8v, q2[lo2]);
 #pragma unroll 1      // (unrolled by two the allocator needs 142 registers, or 128 and 48 bytes of scratch: 2.02 -> 2.60 ms)
-            for (int it = 0; it < 2 * MH / 4; ++it, q0 += 2 * PW, q1 += 2 * PW, q2 += st2, h8 += 4 * MW) {
+            for (int it = 0; it < NIT; ++it, h8 += 4 * MW) {
                 f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-                const h8v i0h = __builtin_bit_cast(h8v, q0[0]), i0l = __builtin_bit_cast(h8v, q0[NP]);
-                const h8v i1h = __builtin_bit_cast(h8v, q1[0]), i1l = __builtin_bit_cast(h8v, q1[NP]);
-                const h8v i2h = __builtin_bit_cast(h8v, q2[0]), i2l = __builtin_bit_cast(h8v, q2[lo2]);
+                __builtin_amdgcn_sched_barrier(0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[0], i0l, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[0], i0h, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[0], i0h, acc, 0, 0, 0);
@@ -750,6 +754,14 @@ __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2], i2l, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1l[2], i2h, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1h[2], i2h, acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (it + 1 < NIT) {         // the next group's pieces (the tile ends two rows below the last group's)
+                    q0 += 2 * PW; q1 += 2 * PW; q2 += st2;
+                    i0h = __builtin_bit_cast(h8v, q0[0]); i0l = __builtin_bit_cast(h8v, q0[NP]);
+                    i1h = __builtin_bit_cast(h8v, q1[0]); i1l = __builtin_bit_cast(h8v, q1[NP]);
+                    i2h = __builtin_bit_cast(h8v, q2[0]); i2l = __builtin_bit_cast(h8v, q2[lo2]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 const bool yin = (unsigned)(ty0 - 1 + y0 + 2 * it) < (unsigned)a.H;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (yin) v = make_float4(relu(fmaf(acc[0], unm, bm.x)), relu(fmaf(acc[1], unm, bm.y)), relu(fmaf(acc[2], unm, bm.z)), relu(fmaf(acc[3], unm, bm.w)));
@@ -789,6 +801,10 @@ __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.
             }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);       // (not before conv1's last group: see the fragments' comment above)
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) { w2h[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2) * 64 + lane]); w2l[kb] = __builtin_bit_cast(h8v, a.w2pk[(kb * 2 + 1) * 64 + lane]); }
+    const h8v wah = __builtin_bit_cast(h8v, a.wapk[lane]), wal = __builtin_bit_cast(h8v, a.wapk[64 + lane]);
     __syncthreads();
     // conv2 + identity branch + ReLU -> x2; agg2 + ReLU -> a2, S2.  16 groups of 16 pixels per tile, four per wave: a wave owns
     // four rows of one 16-column half, so the 4 x 4 max-pool block 3 starts with is a running maximum over its four groups and
@@ -799,25 +815,38 @@ __global__ __launch_bounds__(256, 4) void alike_block2(Block2Args a)      // 39.
     uint2* xh = reinterpret_cast<uint2*>(&xs[wv][0][0][0]);
     float4 pm = make_float4(0.f, 0.f, 0.f, 0.f);        // x2 >= 0 (ReLU): zero is the neutral element of the pool
     float amx = 0.0f;                                    // this lane's largest a2 value
-#pragma unroll 2
+#pragma unroll 1      // (r06: unrolled by two the operand pieces below cannot be held in flight without scratch: 19 registers spilled, 3.7 ms)
     for (int k4 = 0; k4 < 4; ++k4) {
         const int row = 4 * (wv >> 1) + k4, col0 = (wv & 1) * 16;
         const int mbase = row * MW + col0 + px;
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 5; ++kb) {
+        h8v ihi[5], ilo[5];
+        auto fetch = [&](int kb) {
             const int kidx = 4 * kb + g;
             const uint4* ph;
             int lo_off;
             if (kidx < 18) { const int tap = kidx >> 1; ph = &mid[(kidx & 1) * NM + mbase + (tap / 3) * MW + tap % 3]; lo_off = 2 * NM; }
             else if (kidx == 18) { ph = &pin[(row + 2) * PW + col0 + px + 2]; lo_off = NP; }
             else { ph = zp; lo_off = 0; }
-            const h8v ihi = __builtin_bit_cast(h8v, ph[0]);
-            const h8v ilo = __builtin_bit_cast(h8v, ph[lo_off]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[kb], ilo, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[kb], ihi, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[kb], ihi, acc, 0, 0, 0);
-        }
+            ihi[kb] = __builtin_bit_cast(h8v, ph[0]);
+            ilo[kb] = __builtin_bit_cast(h8v, ph[lo_off]);
+        };
+        auto mm = [&](int kb) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[kb], ilo[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2l[kb], ihi[kb], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2h[kb], ihi[kb], acc, 0, 0, 0);
+        };
+        // r06: three k-blocks' pieces in flight together, the other two requested behind the first six MFMAs: 24 operand registers at most (all ten at once
+        // measure the same; the next group's first pieces requested under this group's epilogue cost two spilled registers and the gain)
+        fetch(0); fetch(1); fetch(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(0); mm(1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(3); fetch(4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(3); mm(4);
         const int gy = ty0 + row, gx = tx0 + col0 + px;
         const bool ok = gy < a.H && gx < a.W;
         const float4 v = make_float4(relu(fmaf(acc[0], un_c2, bsum.x)), relu(fmaf(acc[1], un_c2, bsum.y)), relu(fmaf(acc[2], un_c2, bsum.z)), relu(fmaf(acc[3], un_c2, bsum.w)));
