@@ -30,8 +30,15 @@ def main():
     f["B1"] = "%.2f" % k["alike_block1"]
     f["B2"] = "%.2f" % k["alike_block2"]
     f["NMS"] = "%.2f" % k["nms_sweep"]
+    f["TAIL"] = "%.2f" % k["nms_tail"]
+    f["SELTOPK"] = "%.2f" % k["select_topk"]
+    f["SAMPLE"] = "%.2f" % k["sample_bilinear"]
+    f["MATCH"] = "%.2f" % sum(v for n, v in k.items() if n.startswith("match_"))
     for a, b in (("B3C1", "conv3x3_b3c1"), ("B3C2", "conv3x3_b3c2"), ("B4C1", "conv3x3_b4c1"), ("B4C2", "conv3x3_b4c2")):
         f[a] = "%.2f" % k[b]
+    f["V2000"] = "{:,.0f}".format(line(P + "soak_bench_2000_steps.json")["value"]).replace(",", " ")
+    f["STEPMFMA"] = "%.2f" % d["roofline_step"]["frac_mfma"]
+    f["STEPHBM"] = "%.2f" % d["roofline_step"]["frac_hbm"]
     f["V500"] = "{:,.0f}".format(line(P + "bench_500_steps.json")["value"]).replace(",", " ")
     f["SPAWN"] = "{:,.0f}".format(line(P + "bench_spawn_w1.json")["value"]).replace(",", " ")
     sp = line(P + "bench_superpoint_brute_force.json")
