@@ -359,9 +359,14 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
     static_assert(PRE == GEN && (!GEN || KS == 3), "conv_mfma_h: the pre-split tile exists as the generated one (a 3 x 3 one-channel layer computed while staging); r05's DMA-landed form was measured, superseded and removed in r06");
     static_assert(!PRE || (CC == 32 && S == 1 && !POOL_IN && !XF && !XC && !WPRE), "conv_mfma_h: the pre-split input form exists for plain stride-1 32-channel slabs");
     constexpr int KC = CC / 2, NKB = CC / 16, T = KS * KS, PAD = KS / 2, TH = 8 * MT / WN;
-    // the tap loop of the one-tile 3 x 3 layers (ALIKE's b3c2: nine dependent weight-fragment round trips per workgroup) is unrolled so that the scheduler may
-    // request fragments ahead: 0.458 -> 0.442 ms at no register cost (r06); every larger form keeps its rolled loop (a tap ahead lost 12 % there, r02)
-    constexpr int TAPU = (MT * NTB == 1 && KS == 3 && !WPRE && !PRE) ? 9 : 1;
+    // r06: a tap's weight fragments (L2 round trips: NTB NKB 2 loads of 16 bytes per lane) are requested ONE TAP AHEAD and the order is pinned with a scheduling
+    // barrier -- left alone the scheduler puts every request next to its first use, the round trip exposed nine (25) times per slab.  The 3 x 3 forms unroll their
+    // tap loop (the two fragment sets are then plain registers: ALIKE's b3c2 0.444 -> 0.372 ms per 512 images, SuperPoint's conv2a .. conv4b -4 .. 5 %, no spills);
+    // the 5 x 5 forms unroll the kernel's columns only (ROW_AHEAD: a set per column, the row loop rolled); the generated-input form (conv1b: 46 registers spilled when
+    // unrolled, 1.90 -> 2.08 ms; rolled with the next set handed over by register copies 3.5 ms -- the copies' wait also covers the slab prefetch) keeps the scheduler's
+    // own order.  (r02 lost 12 % with "weights a tap ahead" written in the source alone: the scheduler undid it.  profiles/r06_weights_a_tap_ahead_ab.txt)
+    constexpr int TAPU = (KS == 3 && !WPRE && !PRE) ? 9 : 1;
+    constexpr bool ROW_AHEAD = TAPU == 1 && !WPRE && !PRE;
     constexpr int IH = (TH - 1) * S + KS, IW = 15 * S + KS, Q = CC / 4;
     constexpr int PITCH = 4 * CC + 16, LO = 2 * CC;                 // bytes per pixel, offset of its lo halves
     constexpr int ROWP = (IW * PITCH + 255) / 256 * 256;            // bytes per tile row
@@ -664,19 +669,35 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[m][kb], Wh[tap][n][kb], acc[m][n], 0, 0, 0);
                         }
             }
-        } else
-#pragma unroll (TAPU)
-        for (int tap = 0; tap < T; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
+        } else {
+        // fragment sets (two are live at a time): TAPU == 9: one per tap; ROW_AHEAD: one per kernel column (the row loop is rolled, the column loop unrolled: the
+        // indices are constants either way); otherwise one
+        constexpr int NSET = TAPU == 9 ? T : (ROW_AHEAD ? KS : 1);
+        cm_h8 BhA[NSET][NTB][NKB], BlA[NSET][NTB][NKB];
+        auto loadB = [&](int tap, int set) {
             const uint4* bp = wq + ((((size_t)nt0 * T + tap) * a.NCH + ch) * NKB * 4 + h) * 32 + p;
-            cm_h8 Bh[NTB][NKB], Bl[NTB][NKB], Ah[MT][NKB], Al[MT][NKB];
 #pragma unroll
             for (int n = 0; n < NTB; ++n)
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb) {
-                    Bh[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 0) * 32]);
-                    Bl[n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 2) * 32]);
+                    BhA[set][n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 0) * 32]);
+                    BlA[set][n][kb] = __builtin_bit_cast(cm_h8, bp[n * ntile_stride + (kb * 4 + 2) * 32]);
                 }
+        };
+        loadB(0, 0);
+#pragma unroll (TAPU == 9 ? KS : 1)
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll (PRE ? 1 : KS)      // (the generated-input form with its columns unrolled: conv1b 1.83 -> 3.3 ms)
+        for (int kx = 0; kx < KS; ++kx) {
+            const int tap = ky * KS + kx;
+            cm_h8 Ah[MT][NKB], Al[MT][NKB];
+            constexpr bool AHEAD = TAPU == 9 || ROW_AHEAD;
+            if constexpr (AHEAD) {
+                if (tap + 1 < T) loadB(tap + 1, TAPU == 9 ? tap + 1 : (kx + 1) % KS);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (tap > 0) loadB(tap, 0);          // requested where they are used: the scheduler's own order
+            auto& Bh = BhA[TAPU == 9 ? tap : (ROW_AHEAD ? kx : 0)];
+            auto& Bl = BlA[TAPU == 9 ? tap : (ROW_AHEAD ? kx : 0)];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const int orow = 2 * (wm * MT + m) + (p >> 4);
@@ -727,6 +748,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                     }
                 }
             }
+        }
         }
         if (XC && nb == 0) xacc = fmaf(xpart, cm_unscale_of(e_cur), xacc);
     }
