@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
             auto& Bh = BhA[TAPU == 9 ? tap : (ROW_AHEAD ? kx : 0)];
             auto& Bl = BlA[TAPU == 9 ? tap : (ROW_AHEAD ? kx : 0)];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
+            for (int m = 0; m < ((MT >= 2 && NTB == 1 && !PRE) ? 0 : MT); ++m) {
                 const int orow = 2 * (wm * MT + m) + (p >> 4);
                 if constexpr (PRE) {
                     const int t = (orow + ky) * IW + ocol + kx, key = ((ocol + kx) >> 1) & 7;
@@ -718,6 +718,35 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                 }
                 }
             }
+            if constexpr (MT >= 2 && NTB == 1 && !PRE) {
+                // r06: the A pieces of a k-block in a pinned order -- the MT lo pieces and the first hi piece in flight together, the next hi piece requested behind
+                // every lo piece's MFMA (whose registers it may take: the allocator decides, the order only makes it possible).  Left alone the scheduler sent the
+                // lo pieces through ONE register quad, a ds_read_b128 and an exposed wait each.  Same MFMAs per accumulator in the same order: bit-identical.
+                // DISK +1.1 %, SuperPoint +0.8 % (profiles/r06_weights_a_tap_ahead_ab.txt, 6.)
+                auto apiece = [&](int m, int kb, bool lo) {
+                    const int orow = 2 * (wm * MT + m) + (p >> 4);
+                    const unsigned char* ap = &tile[(orow * S + ky) * ROWP + (ocol * S + kx) * PITCH + h * KC * 2];
+                    return __builtin_bit_cast(cm_h8, *reinterpret_cast<const uint4*>(ap + (lo ? LO : 0) + 16 * kb));
+                };
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
+                    cm_h8 L[MT], H[MT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) L[m] = apiece(m, kb, true);
+                    H[0] = apiece(0, kb, false);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(L[m], Bh[0][kb], acc[m][0], 0, 0, 0);
+                        if (m + 1 < MT) { H[m + 1] = apiece(m + 1, kb, false); __builtin_amdgcn_sched_barrier(0); }
+                    }
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H[m], Bl[0][kb], acc[m][0], 0, 0, 0);
+                        acc[m][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(H[m], Bh[0][kb], acc[m][0], 0, 0, 0);
+                    }
+                }
+            } else
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll

@@ -613,17 +613,30 @@ __global__ __launch_bounds__(256) void lg_sim(const float* md, float* sim, const
     const float* A = md + ((size_t)(2 * b) * MP + i0 + p) * D + 32 * h;
     const float* Bm = md + ((size_t)(2 * b + 1) * MP + j0 + p) * D + 32 * h;
     f32x16 acc = {0};
-#pragma unroll 1
-    for (int kc = 0; kc < 4; ++kc) {
-        float ar[32], br[32];
+    // r06: the next half-chunk's rows (sixteen channels of A and of B per lane) are requested before this half-chunk's sixteen MFMAs, the order pinned: it was four
+    // chunks of 32 channels per lane, each one's sixteen loads waited for where they were issued (231 us per 16 pairs of 1 000 x 1 000 at 42 registers)
+    float4 xa[2][4], xb[2][4];
+    auto fetch = [&](int buf, int hc) {          // half-chunk hc = 0..7: channels 64 (hc / 2) + 32 h + 16 (hc & 1) .. + 15 of this lane's rows
+        const int off = (hc >> 1) * 64 + (hc & 1) * 16;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 x = *reinterpret_cast<const float4*>(A + kc * 64 + 4 * c), y = *reinterpret_cast<const float4*>(Bm + kc * 64 + 4 * c);
-            ar[4 * c] = x.x * 0.25f; ar[4 * c + 1] = x.y * 0.25f; ar[4 * c + 2] = x.z * 0.25f; ar[4 * c + 3] = x.w * 0.25f;
-            br[4 * c] = y.x * 0.25f; br[4 * c + 1] = y.y * 0.25f; br[4 * c + 2] = y.z * 0.25f; br[4 * c + 3] = y.w * 0.25f;
+        for (int q = 0; q < 4; ++q) { xa[buf][q] = *reinterpret_cast<const float4*>(A + off + 4 * q); xb[buf][q] = *reinterpret_cast<const float4*>(Bm + off + 4 * q); }
+    };
+    auto mm = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 x = xa[buf][q], y = xb[buf][q];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x * 0.25f, y.x * 0.25f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y * 0.25f, y.y * 0.25f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z * 0.25f, y.z * 0.25f, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w * 0.25f, y.w * 0.25f, acc, 0, 0, 0);
         }
+    };
+    fetch(0, 0);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[c], br[c], acc, 0, 0, 0);
+    for (int hc = 0; hc < 8; ++hc) {
+        if (hc + 1 < 8) fetch((hc + 1) & 1, hc + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(hc & 1);
     }
     float* o = sim + (size_t)b * MP * MP;
 #pragma unroll
@@ -633,62 +646,150 @@ __global__ __launch_bounds__(256) void lg_sim(const float* md, float* sim, const
     }
 }
 
-// max and log(sum(exp(x - max))) of every row (mode 0) or column (mode 1) of sim: the two halves of log_softmax
-__global__ __launch_bounds__(256) void lg_lse(const float* sim, float* mxo, float* lgo, const int* cnt, const int* fin_pair, int MP, int mode)
-{
-    const int b = blockIdx.y;
-    if (!fin_pair[b]) return;
-    const int lane = threadIdx.x & 63;
-    const int m = cnt[2 * b], n = cnt[2 * b + 1];
-    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nl = mode ? n : m, len = mode ? m : n;
-    if (line >= nl) return;
-    const float* base = sim + (size_t)b * MP * MP + (mode ? (size_t)line : (size_t)line * MP);
-    const size_t stride = mode ? MP : 1;
-    float mx = -INFINITY;
-    for (int k = lane; k < len; k += 64) mx = fmaxf(mx, base[k * stride]);
-    mx = kpb_wave_fmax(mx);
-    float sum = 0.0f;
-    for (int k = lane; k < len; k += 64) sum += expf(base[k * stride] - mx);
-    sum = kpb_wave_sum(sum);
-    if (lane == 0) { mxo[(size_t)(2 * b + mode) * MP + line] = mx; lgo[(size_t)(2 * b + mode) * MP + line] = logf(sum); }
-}
-
 __device__ __forceinline__ float logsigmoid(float z) { return fminf(z, 0.0f) - log1pf(expf(-fabsf(z))); }
 
-// scores = log_softmax(sim, rows) + log_softmax(sim, cols) + logsigmoid(z0) + logsigmoid(z1)^T (lightglue.py:278-290);
-// best column of every row (mode 0) / best row of every column (mode 1), first index on ties (filter_matches 317)
-__global__ __launch_bounds__(256) void lg_best(const float* sim, const float* mxo, const float* lgo, const float* zlog, float* bestv, int* besti,
-                                               const int* cnt, const int* fin_pair, int MP, int mode)
+// max and log(sum(exp(x - max))) of every ROW of sim (one half of log_softmax): a wave per row, lanes along the row.  Also logsigmoid(z) of the row's
+// token of image 0 and (lines < n) of the same-numbered token of image 1, once per token (r06: lg_best evaluated both per ELEMENT: an exp and a log1p
+// for each of the 16 M cells, most of its 138 us).
+constexpr int LG_CROWS = 32;       // rows per workgroup of the column kernels
+
+__device__ __forceinline__ void lg_lse_rows(const float* sim, float* mxo, float* lgo, const float* zlog, float* lso, const int* cnt, const int* fin_pair, int MP, int bx)
 {
     const int b = blockIdx.y;
     if (!fin_pair[b]) return;
     const int lane = threadIdx.x & 63;
     const int m = cnt[2 * b], n = cnt[2 * b + 1];
-    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nl = mode ? n : m, len = mode ? m : n;
-    if (line >= nl) return;
-    const float* S = sim + (size_t)b * MP * MP;
+    const int line = bx * 4 + (threadIdx.x >> 6);
+    if (lane == 0 && line < n) lso[(size_t)(2 * b + 1) * MP + line] = logsigmoid(zlog[(size_t)(2 * b + 1) * MP + line]);
+    if (line >= m) return;
+    const float* base = sim + (size_t)b * MP * MP + (size_t)line * MP;
+    float mx = -INFINITY;
+    for (int k = lane; k < n; k += 64) mx = fmaxf(mx, base[k]);
+    mx = kpb_wave_fmax(mx);
+    float sum = 0.0f;
+    for (int k = lane; k < n; k += 64) sum += expf(base[k] - mx);
+    sum = kpb_wave_sum(sum);
+    if (lane == 0) {
+        mxo[(size_t)(2 * b) * MP + line] = mx; lgo[(size_t)(2 * b) * MP + line] = logf(sum);
+        lso[(size_t)(2 * b) * MP + line] = logsigmoid(zlog[(size_t)(2 * b) * MP + line]);
+    }
+}
+
+// The same for every COLUMN, in two steps (r06; r03 .. r05 gave a column to a wave, its lanes a row pitch apart: 64 lines per load, 191 us per 16 pairs).
+// Step 1: a workgroup takes LG_CROWS rows x 256 columns, a thread one column: coalesced loads, all of a thread's rows in flight; it leaves the
+// column's (max, sum exp(x - max)) over those rows.  Step 2 folds a column's partials.
+__device__ __forceinline__ void lg_lse_cols(const float* sim, float* pmx, float* psum, const int* cnt, const int* fin_pair, int MP, int NCH, int bx, int chunk)
+{
+    const int b = blockIdx.y;
+    if (!fin_pair[b]) return;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1];
+    const int j = bx * 256 + threadIdx.x, i0 = chunk * LG_CROWS;
+    if (i0 >= m || j >= n) return;
+    const float* base = sim + (size_t)b * MP * MP + (size_t)i0 * MP + j;
+    float x[LG_CROWS];
+#pragma unroll
+    for (int r = 0; r < LG_CROWS; ++r) x[r] = i0 + r < m ? base[(size_t)r * MP] : -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < LG_CROWS; ++r) mx = fmaxf(mx, x[r]);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < LG_CROWS; ++r) sum += i0 + r < m ? expf(x[r] - mx) : 0.0f;
+    pmx[((size_t)b * NCH + chunk) * MP + j] = mx;
+    psum[((size_t)b * NCH + chunk) * MP + j] = sum;
+}
+
+// one launch for both: workgroups [0, nrow) take four rows each, the rest a (256-column group, row chunk) tile (grid: nrow + ncolgrp * NCH, pairs)
+__global__ __launch_bounds__(256) void lg_lse(const float* sim, float* mxo, float* lgo, const float* zlog, float* lso, float* pmx, float* psum, const int* cnt,
+                                              const int* fin_pair, int MP, int NCH, int nrow)
+{
+    const int bx = blockIdx.x;
+    if (bx < nrow) lg_lse_rows(sim, mxo, lgo, zlog, lso, cnt, fin_pair, MP, bx);
+    else lg_lse_cols(sim, pmx, psum, cnt, fin_pair, MP, NCH, (bx - nrow) / NCH, (bx - nrow) % NCH);
+}
+
+__global__ __launch_bounds__(256) void lg_lse_colfin(const float* pmx, const float* psum, float* mxo, float* lgo, const int* cnt, const int* fin_pair, int MP, int NCH)
+{
+    const int b = blockIdx.y;
+    if (!fin_pair[b]) return;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1], j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int nch = (m + LG_CROWS - 1) / LG_CROWS;
+    float mx = -INFINITY;
+    for (int c = 0; c < nch; ++c) mx = fmaxf(mx, pmx[((size_t)b * NCH + c) * MP + j]);
+    float sum = 0.0f;
+    for (int c = 0; c < nch; ++c) sum += psum[((size_t)b * NCH + c) * MP + j] * expf(pmx[((size_t)b * NCH + c) * MP + j] - mx);
+    mxo[(size_t)(2 * b + 1) * MP + j] = mx;
+    lgo[(size_t)(2 * b + 1) * MP + j] = logf(sum);
+}
+
+// scores = log_softmax(sim, rows) + log_softmax(sim, cols) + logsigmoid(z0) + logsigmoid(z1)^T (lightglue.py:278-290);
+// best column of every row, first index on ties (filter_matches 317): a wave per row
+__device__ __forceinline__ void lg_best_rows(const float* sim, const float* mxo, const float* lgo, const float* lso, float* bestv, int* besti,
+                                             const int* cnt, const int* fin_pair, int MP, int bx)
+{
+    const int b = blockIdx.y;
+    if (!fin_pair[b]) return;
+    const int lane = threadIdx.x & 63;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1];
+    const int i = bx * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const float* S = sim + (size_t)b * MP * MP + (size_t)i * MP;
     const size_t r0 = (size_t)(2 * b) * MP, r1 = (size_t)(2 * b + 1) * MP;
+    const float mi = mxo[r0 + i], li = lgo[r0 + i], si = lso[r0 + i];
     float bv = -INFINITY; int bi = 0x7FFFFFFF;
-    for (int k = lane; k < len; k += 64) {
-        const int i = mode ? k : line, j = mode ? line : k;
-        const float x = S[(size_t)i * MP + j];
-        const float s0 = (x - mxo[r0 + i]) - lgo[r0 + i], s1 = (x - mxo[r1 + j]) - lgo[r1 + j];
-        const float v = (s0 + s1) + (logsigmoid(zlog[r0 + i]) + logsigmoid(zlog[r1 + j]));
-        if (v > bv) { bv = v; bi = k; }
+    for (int j = lane; j < n; j += 64) {
+        const float x = S[j];
+        const float s0 = (x - mi) - li, s1 = (x - mxo[r1 + j]) - lgo[r1 + j];
+        const float v = (s0 + s1) + (si + lso[r1 + j]);
+        if (v > bv) { bv = v; bi = j; }
     }
     kpb_butterfly([&](auto o) {
         constexpr int O = decltype(o)::value;
         const float ov = kpb_shfl_xor<O>(bv); const int oi = kpb_shfl_xor<O>(bi);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     });
-    if (lane == 0) { bestv[(size_t)(2 * b + mode) * MP + line] = bv; besti[(size_t)(2 * b + mode) * MP + line] = bi; }
+    if (lane == 0) { bestv[r0 + i] = bv; besti[r0 + i] = bi; }
+}
+
+// best ROW of every column, first index on ties: the tiling of lg_lse_col; a column's partial (value, row) per row chunk, folded by lg_emit where it is needed
+__device__ __forceinline__ void lg_best_cols(const float* sim, const float* mxo, const float* lgo, const float* lso, float* pbv, int* pbi,
+                                             const int* cnt, const int* fin_pair, int MP, int NCH, int bx, int chunk)
+{
+    const int b = blockIdx.y;
+    if (!fin_pair[b]) return;
+    const int m = cnt[2 * b], n = cnt[2 * b + 1];
+    const int j = bx * 256 + threadIdx.x, i0 = chunk * LG_CROWS;
+    if (i0 >= m || j >= n) return;
+    const float* base = sim + (size_t)b * MP * MP + (size_t)i0 * MP + j;
+    const size_t r0 = (size_t)(2 * b) * MP, r1 = (size_t)(2 * b + 1) * MP;
+    float x[LG_CROWS];
+#pragma unroll
+    for (int r = 0; r < LG_CROWS; ++r) x[r] = i0 + r < m ? base[(size_t)r * MP] : 0.0f;
+    const float mj = mxo[r1 + j], lj = lgo[r1 + j], sj = lso[r1 + j];
+    float bv = -INFINITY; int bi = 0x7FFFFFFF;
+#pragma unroll
+    for (int r = 0; r < LG_CROWS; ++r) {
+        const int i = min(i0 + r, m - 1);               // (wave-uniform: scalar loads)
+        const float s0 = (x[r] - mxo[r0 + i]) - lgo[r0 + i], s1 = (x[r] - mj) - lj;
+        const float v = (s0 + s1) + (lso[r0 + i] + sj);
+        if (i0 + r < m && v > bv) { bv = v; bi = i0 + r; }
+    }
+    pbv[((size_t)b * NCH + chunk) * MP + j] = bv;
+    pbi[((size_t)b * NCH + chunk) * MP + j] = bi;
+}
+
+__global__ __launch_bounds__(256) void lg_best(const float* sim, const float* mxo, const float* lgo, const float* lso, float* bestv, int* besti, float* pbv, int* pbi,
+                                               const int* cnt, const int* fin_pair, int MP, int NCH, int nrow)
+{
+    const int bx = blockIdx.x;
+    if (bx < nrow) lg_best_rows(sim, mxo, lgo, lso, bestv, besti, cnt, fin_pair, MP, bx);
+    else lg_best_cols(sim, mxo, lgo, lso, pbv, pbi, cnt, fin_pair, MP, NCH, (bx - nrow) / NCH, (bx - nrow) % NCH);
 }
 
 // filter_matches (lightglue.py:315-331) + the index mapping of pruned points (616-623): ordered by the row index
-__global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* besti, const int* ind, const int* cnt, const int* fin_pair,
-                                               int* out_pairs, float* out_scores, int* out_k, int MP, int K, float th)
+__global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* besti, const float* pbv, const int* pbi, int NCH, const int* ind, const int* cnt,
+                                               const int* fin_pair, int* out_pairs, float* out_scores, int* out_k, int MP, int K, float th)
 {
     __shared__ int wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -702,7 +803,21 @@ __global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* be
         if (i < m) {
             j = besti[r0 + i];
             ms = expf(bestv[r0 + i]);
-            valid = (besti[r1 + j] == i) && (ms > th);
+            // the best row of column j: the best of its row chunks' partials, the first chunk on ties (each partial is its chunk's first row on ties)
+            const int nch = (m + LG_CROWS - 1) / LG_CROWS;
+            float cv = -INFINITY; int ci = 0x7FFFFFFF;
+            if (j < MP) {       // (no column won: bi = 0x7FFFFFFF, e.g. a row of NaNs)
+                int cc = -1;
+                for (int c0 = 0; c0 < nch; c0 += 16) {          // sixteen partials in flight, then the comparisons
+                    float pv[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) pv[c] = c0 + c < nch ? pbv[((size_t)b * NCH + c0 + c) * MP + j] : -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) if (pv[c] > cv) { cv = pv[c]; cc = c0 + c; }
+                }
+                if (cc >= 0) ci = pbi[((size_t)b * NCH + cc) * MP + j];
+            }
+            valid = (ci == i) && (ms > th);
         }
         const unsigned long long bal = __ballot(valid);
         const int within = __popcll(bal & ((1ull << lane) - 1ull));
@@ -932,7 +1047,9 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
                  o_din = take(T * C), o_cat0 = take(T * 512), o_cat1 = take(T * 512), o_qkv = take(T * 768), o_q = take(T * D), o_k = take(T * D),
                  o_v = take(T * D), o_ctx = take(T * D), o_h1 = take(T * 512), o_y = take(T * D), o_conf = take(T), o_msc = take(T), o_z = take(T),
                  o_md = take(T * D), o_sim = take((size_t)B * MP * MP), o_mx = take(T), o_lg = take(T), o_bv = take(T),
-                 o_ind0 = take(T), o_ind1 = take(T), o_dst = take(T), o_bi = take(T), o_ints = take((size_t)8 * S + 64),
+                 o_ind0 = take(T), o_ind1 = take(T), o_dst = take(T), o_bi = take(T), o_ints = take((size_t)8 * S + 64), o_ls = take(T),
+                 o_pmx = take((size_t)B * (MP / 32) * MP), o_psum = take((size_t)B * (MP / 32) * MP),      // column partials per chunk of LG_CROWS rows
+                 o_pbv = take((size_t)B * (MP / 32) * MP), o_pbi = take((size_t)B * (MP / 32) * MP),
                  o_kf = take(T * D), o_vf = take(T * D),      // K / V in MFMA operand order, (hi, lo) halves: 4 bytes per element
                  o_kve = take((size_t)S * NH * (MP / 32) * 2);  // per 32-key block: exponents of the K and V scales
     const bool fresh = need * sizeof(float) > lg->ws.cap;
@@ -943,7 +1060,10 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
     float *kpx = base + o_kpx, *cosb[2] = {base + o_cos0, base + o_cos1}, *sinb[2] = {base + o_sin0, base + o_sin1}, *din = base + o_din,
           *cat[2] = {base + o_cat0, base + o_cat1}, *qkv = base + o_qkv, *q = base + o_q, *k = base + o_k, *v = base + o_v, *cx = base + o_ctx,
           *h1 = base + o_h1, *y = base + o_y, *conf = base + o_conf, *msc = base + o_msc, *zlog = base + o_z, *md = base + o_md, *sim = base + o_sim,
-          *mxo = base + o_mx, *lgo = base + o_lg, *bestv = base + o_bv;
+          *mxo = base + o_mx, *lgo = base + o_lg, *bestv = base + o_bv, *lso = base + o_ls, *pmx = base + o_pmx, *psum = base + o_psum, *pbv = base + o_pbv;
+    int* pbi = reinterpret_cast<int*>(base + o_pbi);
+    const int NCHK = MP / LG_CROWS;
+    static_assert(LG_CROWS == 32, "the partial arrays are carved for 32-row chunks");
     int *ind[2] = {reinterpret_cast<int*>(base + o_ind0), reinterpret_cast<int*>(base + o_ind1)}, *dst = reinterpret_cast<int*>(base + o_dst),
         *besti = reinterpret_cast<int*>(base + o_bi), *ints = reinterpret_cast<int*>(base + o_ints);
     uint4 *kfrag = reinterpret_cast<uint4*>(base + o_kf), *vfrag = reinterpret_cast<uint4*>(base + o_vf);
@@ -1034,12 +1154,12 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
         // assignment for the pairs that finish at this layer (lightglue.py:606-614)
         if ((rc = lg_linear(ctx, lg, "lg_final_proj", L + ".fproj", 256, 256, c, 512, md, 256, 0, S, MP, fin_seq, cnt))) return rc;
         KPB_LAUNCH(ctx, "lg_sim", lg_sim, dim3(cdiv(max_k, 128), cdiv(max_k, 32), B), dim3(256), 0, st, md, sim, cnt, fin_pair, MP);
-        KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, cnt, fin_pair, MP, 0);
-        KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, cnt, fin_pair, MP, 1);
-        KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, zlog, bestv, besti, cnt, fin_pair, MP, 0);
-        KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(cdiv(max_k, 4), B), dim3(256), 0, st, sim, mxo, lgo, zlog, bestv, besti, cnt, fin_pair, MP, 1);
-        KPB_LAUNCH(ctx, "lg_emit", lg_emit, dim3(B), dim3(256), 0, st, bestv, besti, ind[i & 1], cnt, fin_pair, out_pairs_dev, out_scores_dev, out_k_dev,
-                   MP, max_k, prm->filter_threshold);
+        const int nrow = cdiv(max_k, 4), ntile = cdiv(max_k, 256) * NCHK;
+        KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(nrow + ntile, B), dim3(256), 0, st, sim, mxo, lgo, zlog, lso, pmx, psum, cnt, fin_pair, MP, NCHK, nrow);
+        KPB_LAUNCH(ctx, "lg_lse", lg_lse_colfin, dim3(cdiv(max_k, 256), B), dim3(256), 0, st, pmx, psum, mxo, lgo, cnt, fin_pair, MP, NCHK);
+        KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(nrow + ntile, B), dim3(256), 0, st, sim, mxo, lgo, lso, bestv, besti, pbv, pbi, cnt, fin_pair, MP, NCHK, nrow);
+        KPB_LAUNCH(ctx, "lg_emit", lg_emit, dim3(B), dim3(256), 0, st, bestv, besti, pbv, pbi, NCHK, ind[i & 1], cnt, fin_pair, out_pairs_dev, out_scores_dev,
+                   out_k_dev, MP, max_k, prm->filter_threshold);
         if (!last) {
             KPB_LAUNCH(ctx, "lg_gather", lg_gather, tokgrid64, dim3(256), 0, st, c, cat[(i + 1) & 1], cs, sn, cosb[(i + 1) & 1], sinb[(i + 1) & 1],
                        ind[i & 1], ind[(i + 1) & 1], dst, cnt, active_seq, MP);
