@@ -23,6 +23,7 @@ struct PrepArgs {
     float* cosb; float* sinb;               // [S][MP][32]
     int* ind; int* cnt; int* cnt_orig;      // [S][MP], [S], [S]
     int* active_seq; int* active_pair; int* stop;
+    int* done_pair;                         // [B] 1 once the pair has finished (lg_decide): the assignment stage runs once, after the last layer, for these
     int K, MP; float w1, h1;                // w - 1, h - 1
 };
 
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void lg_prepare(PrepArgs a)
         const int n_other = (side ? a.n0 : a.n1) ? min((side ? a.n0 : a.n1)[b], a.K) : a.K;
         const int act = (n > 0 && n_other > 0) ? 1 : 0;       // lightglue.py:553-554: nothing to do without keypoints
         a.active_seq[s] = act;
-        if (side == 0) { a.active_pair[b] = act; a.stop[b] = act ? 0 : 1; }
+        if (side == 0) { a.active_pair[b] = act; a.stop[b] = act ? 0 : 1; a.done_pair[b] = 0; }
     }
 }
 
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void lg_conf(const float* cat, const float* wc
 struct DecideArgs {
     const float* conf; const float* msc;
     int* cnt; const int* cnt_orig; int* newcnt; int* dst;   // dst [S][MP]: new row of a kept token, -1 if pruned
-    int* active_pair; int* active_seq; int* fin_pair; int* fin_seq; int* stop;
+    int* active_pair; int* active_seq; int* fin_pair; int* fin_seq; int* stop; int* done_pair;
     int MP, layer, prune_min; float thr, depth_conf, width_keep;   // width_keep = 1 - width_confidence
     int do_stop, do_prune;
 };
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(256) void lg_decide(DecideArgs a)
         if (tid == 0) {
             a.fin_pair[b] = 1; a.fin_seq[s0] = 1; a.fin_seq[s1] = 1;
             a.stop[b] = a.layer + 1;
+            a.done_pair[b] = 1;
             a.active_pair[b] = 0; a.active_seq[s0] = 0; a.active_seq[s1] = 0;
             a.newcnt[s0] = a.cnt[s0]; a.newcnt[s1] = a.cnt[s1];
         }
@@ -788,12 +790,13 @@ __global__ __launch_bounds__(256) void lg_best(const float* sim, const float* mx
 }
 
 // filter_matches (lightglue.py:315-331) + the index mapping of pruned points (616-623): ordered by the row index
-__global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* besti, const float* pbv, const int* pbi, int NCH, const int* ind, const int* cnt,
-                                               const int* fin_pair, int* out_pairs, float* out_scores, int* out_k, int MP, int K, float th)
+__global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* besti, const float* pbv, const int* pbi, int NCH, const int* ind0, const int* ind1,
+                                               const int* stop, const int* cnt, const int* fin_pair, int* out_pairs, float* out_scores, int* out_k, int MP, int K, float th)
 {
     __shared__ int wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (!fin_pair[b]) return;
+    const int* ind = ((stop[b] - 1) & 1) ? ind1 : ind0;      // the index map of the layer the pair finished at (layer stop - 1 used buffer (stop - 1) & 1)
     const int m = cnt[2 * b];
     const size_t r0 = (size_t)(2 * b) * MP, r1 = (size_t)(2 * b + 1) * MP;
     int base = 0;
@@ -1069,10 +1072,10 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
     uint4 *kfrag = reinterpret_cast<uint4*>(base + o_kf), *vfrag = reinterpret_cast<uint4*>(base + o_vf);
     int* kvexp = reinterpret_cast<int*>(base + o_kve);
     int *cnt = ints, *cnt_orig = ints + S, *newcnt = ints + 2 * S, *active_seq = ints + 3 * S, *fin_seq = ints + 4 * S, *active_pair = ints + 5 * S,
-        *fin_pair = ints + 5 * S + B, *stop = ints + 6 * S;
+        *fin_pair = ints + 5 * S + B, *stop = ints + 6 * S, *done_pair = ints + 6 * S + B;
 
     KPB_LAUNCH(ctx, "lg_init_out", lg_init_out, dim3(cdiv(B, 256)), dim3(256), 0, st, out_k_dev, out_stop_dev, stop, B, 0);
-    PrepArgs pa{pts0_dev, pts1_dev, n0_dev, n1_dev, lg->wp("posenc.Wr"), kpx, cosb[0], sinb[0], ind[0], cnt, cnt_orig, active_seq, active_pair, stop,
+    PrepArgs pa{pts0_dev, pts1_dev, n0_dev, n1_dev, lg->wp("posenc.Wr"), kpx, cosb[0], sinb[0], ind[0], cnt, cnt_orig, active_seq, active_pair, stop, done_pair,
                 max_k, MP, (float)(img_w - 1), (float)(img_h - 1)};
     KPB_LAUNCH(ctx, "lg_prepare", lg_prepare, dim3(S), dim3(256), 0, st, pa);
     SampleArgs sa{desc0_dev, desc1_dev, sb, sc, sh, sw, kpx, cnt, din, C, Hd, Wd, MP, lg->desc_scale};
@@ -1147,25 +1150,28 @@ KPB_API int kpb_lg_match(kpb_lg* lg, const float* pts0_dev, const float* pts1_de
         KPB_LAUNCH(ctx, "lg_conf", lg_conf, tokgrid4, dim3(256), 0, st, c, last ? lg->wp(L + ".mw") : lg->wp(L + ".cw"), last ? lg->wp(L + ".mb") : lg->wp(L + ".cb"),
                    lg->wp(L + ".mw"), lg->wp(L + ".mb"), conf, msc, zlog, cnt, active_seq, MP, last ? 0 : 1);
         const double thr = std::min(std::max(0.8 + 0.1 * std::exp(-4.0 * i / NL), 0.0), 1.0);
-        DecideArgs da{conf, msc, cnt, cnt_orig, newcnt, dst, active_pair, active_seq, fin_pair, fin_seq, stop, MP, i, prm->prune_min_kpts,
+        DecideArgs da{conf, msc, cnt, cnt_orig, newcnt, dst, active_pair, active_seq, fin_pair, fin_seq, stop, done_pair, MP, i, prm->prune_min_kpts,
                       (float)thr, prm->depth_confidence, (float)(1.0 - (double)prm->width_confidence), prm->depth_confidence > 0 ? 1 : 0,
                       prm->width_confidence > 0 ? 1 : 0};
         KPB_LAUNCH(ctx, "lg_decide", lg_decide, dim3(B), dim3(256), 0, st, da);
-        // assignment for the pairs that finish at this layer (lightglue.py:606-614)
+        // the projected descriptors of the pairs that finish at this layer (lightglue.py:606-614); their assignment runs after the loop
         if ((rc = lg_linear(ctx, lg, "lg_final_proj", L + ".fproj", 256, 256, c, 512, md, 256, 0, S, MP, fin_seq, cnt))) return rc;
-        KPB_LAUNCH(ctx, "lg_sim", lg_sim, dim3(cdiv(max_k, 128), cdiv(max_k, 32), B), dim3(256), 0, st, md, sim, cnt, fin_pair, MP);
-        const int nrow = cdiv(max_k, 4), ntile = cdiv(max_k, 256) * NCHK;
-        KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(nrow + ntile, B), dim3(256), 0, st, sim, mxo, lgo, zlog, lso, pmx, psum, cnt, fin_pair, MP, NCHK, nrow);
-        KPB_LAUNCH(ctx, "lg_lse", lg_lse_colfin, dim3(cdiv(max_k, 256), B), dim3(256), 0, st, pmx, psum, mxo, lgo, cnt, fin_pair, MP, NCHK);
-        KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(nrow + ntile, B), dim3(256), 0, st, sim, mxo, lgo, lso, bestv, besti, pbv, pbi, cnt, fin_pair, MP, NCHK, nrow);
-        KPB_LAUNCH(ctx, "lg_emit", lg_emit, dim3(B), dim3(256), 0, st, bestv, besti, pbv, pbi, NCHK, ind[i & 1], cnt, fin_pair, out_pairs_dev, out_scores_dev,
-                   out_k_dev, MP, max_k, prm->filter_threshold);
         if (!last) {
             KPB_LAUNCH(ctx, "lg_gather", lg_gather, tokgrid64, dim3(256), 0, st, c, cat[(i + 1) & 1], cs, sn, cosb[(i + 1) & 1], sinb[(i + 1) & 1],
                        ind[i & 1], ind[(i + 1) & 1], dst, cnt, active_seq, MP);
             KPB_LAUNCH(ctx, "lg_commit_counts", lg_commit_counts, dim3(cdiv(S, 256)), dim3(256), 0, st, cnt, newcnt, active_seq, S);
         }
     }
+    // the assignment of every finished pair (lightglue.py:606-614), ONCE: a pair's projected descriptors, matchability logits, counts and index map stay as its last
+    // layer left them (every later kernel skips inactive sequences).  (r03 .. r05 launched the stage after every layer for the pairs finishing there: 40 empty
+    // launches per call when all pairs run to the last layer.)
+    KPB_LAUNCH(ctx, "lg_sim", lg_sim, dim3(cdiv(max_k, 128), cdiv(max_k, 32), B), dim3(256), 0, st, md, sim, cnt, done_pair, MP);
+    const int nrow = cdiv(max_k, 4), ntile = cdiv(max_k, 256) * NCHK;
+    KPB_LAUNCH(ctx, "lg_lse", lg_lse, dim3(nrow + ntile, B), dim3(256), 0, st, sim, mxo, lgo, zlog, lso, pmx, psum, cnt, done_pair, MP, NCHK, nrow);
+    KPB_LAUNCH(ctx, "lg_lse", lg_lse_colfin, dim3(cdiv(max_k, 256), B), dim3(256), 0, st, pmx, psum, mxo, lgo, cnt, done_pair, MP, NCHK);
+    KPB_LAUNCH(ctx, "lg_best", lg_best, dim3(nrow + ntile, B), dim3(256), 0, st, sim, mxo, lgo, lso, bestv, besti, pbv, pbi, cnt, done_pair, MP, NCHK, nrow);
+    KPB_LAUNCH(ctx, "lg_emit", lg_emit, dim3(B), dim3(256), 0, st, bestv, besti, pbv, pbi, NCHK, ind[0], ind[1], stop, cnt, done_pair, out_pairs_dev, out_scores_dev,
+               out_k_dev, MP, max_k, prm->filter_threshold);
     if (out_stop_dev) KPB_LAUNCH(ctx, "lg_init_out", lg_init_out, dim3(cdiv(B, 256)), dim3(256), 0, st, out_k_dev, out_stop_dev, stop, B, 1);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
