@@ -699,7 +699,7 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
             auto& Bh = BhA[TAPU == 9 ? tap : (ROW_AHEAD ? kx : 0)];
             auto& Bl = BlA[TAPU == 9 ? tap : (ROW_AHEAD ? kx : 0)];
 #pragma unroll
-            for (int m = 0; m < ((MT >= 2 && NTB == 1 && !PRE) ? 0 : MT); ++m) {
+            for (int m = 0; m < ((MT >= 2 && NTB == 1 && !PRE && !(XC && !UP)) ? 0 : MT); ++m) {
                 const int orow = 2 * (wm * MT + m) + (p >> 4);
                 if constexpr (PRE) {
                     const int t = (orow + ky) * IW + ocol + kx, key = ((ocol + kx) >> 1) & 7;
@@ -718,11 +718,11 @@ __global__ __launch_bounds__(256, WPRE ? 1 : conv_mfma_h_waves(KS, CC, POOL_IN, 
                 }
                 }
             }
-            if constexpr (MT >= 2 && NTB == 1 && !PRE) {
+            if constexpr (MT >= 2 && NTB == 1 && !PRE && !(XC && !UP)) {
                 // r06: the A pieces of a k-block in a pinned order -- the MT lo pieces and the first hi piece in flight together, the next hi piece requested behind
                 // every lo piece's MFMA (whose registers it may take: the allocator decides, the order only makes it possible).  Left alone the scheduler sent the
                 // lo pieces through ONE register quad, a ds_read_b128 and an exposed wait each.  Same MFMAs per accumulator in the same order: bit-identical.
-                // DISK +1.1 %, SuperPoint +0.8 % (profiles/r06_weights_a_tap_ahead_ab.txt, 6.)
+                // DISK +1.1 %, SuperPoint +0.8 % (profiles/r06_weights_a_tap_ahead_ab.txt, 6.).  (Not the extra-channel form without the fused upsampling: 4 registers spilled.)
                 auto apiece = [&](int m, int kb, bool lo) {
                     const int orow = 2 * (wm * MT + m) + (p >> 4);
                     const unsigned char* ap = &tile[(orow * S + ky) * ROWP + (ocol * S + kx) * PITCH + h * KC * 2];
