@@ -54,6 +54,9 @@ def main():
     f["SPLGF16"] = "{:,.0f}".format(line(P + "bench_superpoint_lightglue_f16attn.json")["value"]).replace(",", " ")
     f["DISKLG"] = "{:,.0f}".format(line(P + "bench_disk_lightglue.json")["value"]).replace(",", " ")
     f["DISKLGF16"] = "{:,.0f}".format(line(P + "bench_disk_lightglue_f16attn.json")["value"]).replace(",", " ")
+    for key, name in (("LGMS", "bench_superpoint_lightglue.json"), ("LGMSF16", "bench_superpoint_lightglue_f16attn.json")):
+        kk = line(P + name)["roofline"]["kernels_ms_per_step"]
+        f[key] = "%.1f" % sum(v for n, v in kk.items() if n.startswith("lg_"))
     m = re.search(r"^dense ([0-9.]+) ms/pair", open(P + "single_pair_latency.txt").read(), re.M)
     f["SINGLE"] = m.group(1) if m else "?"
     num = lambda v: "{:,.0f}".format(v["pairs_per_s"] if isinstance(v, dict) else v).replace(",", " ")
