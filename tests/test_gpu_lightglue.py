@@ -106,3 +106,43 @@ def test_lightglue_cuda_pruning_threshold_and_empty():
     assert len(want ^ got) <= max(2, len(want) // 50) and stop == out["stop"]
     e0, e1 = m.match(torch.zeros(0, 3, device=DEV), T(p1), T(dm0), T(dm1), {"w": 320, "h": 240})
     assert e0.shape == (0, 3) and e1.shape == (0, 3)
+
+
+def test_lightglue_batch_with_pairs_that_stop_at_different_layers_equals_the_single_pair_runs():
+    """r06: the assignment stage runs once after the last layer for every finished pair, each with the index map of the layer IT stopped at.  Four pairs in
+    one kpb_lg_match call -- inputs chosen so that they stop at different layers, odd and even (the two index buffers alternate by layer), one of them an
+    empty pair -- must give exactly what four single-pair calls give (same kernels, same per-pair arithmetic: bit for bit)."""
+    import ctypes
+    from keypoint_bench_amd._lib import LgParams, ptr
+    g = load_golden("lightglue.npz")
+    dim, scale, seed, _, _ = (int(v) for v in g["sp_stop.cfg"])
+    m = _matcher(seed, dim, scale, str(g["sp_stop.variant"]))
+    T = lambda a: torch.from_numpy(a).to(DEV)
+    cases = []
+    for s2, n0g, n0, n1 in ((seed, int(g["sp_stop.cfg"][3]), int(g["sp_stop.cfg"][3]), int(g["sp_stop.cfg"][4])), (seed + 1, 300, 300, 280), (seed + 2, 300, 0, 120),
+                            (seed + 3, 512, 512, 400)):
+        dm0, dm1, p0, p1 = mk.inputs(s2, dim, scale, n0=n0g, n1=n1)
+        cases.append((dm0, dm1, p0[:n0], p1))
+    singles = [m.match_indices(T(p0), T(p1), T(d0), T(d1), {"w": 320, "h": 240}) for d0, d1, p0, p1 in cases]
+    stops = [s[2] for s in singles]
+    assert len(set(stops)) >= 2, stops                   # the point of the test: different stop layers in one batch
+    B, K = len(cases), max(max(len(c[2]), len(c[3])) for c in cases)
+    dev = torch.device(DEV)
+    P0 = torch.zeros((B, K, 3), device=dev); P1 = torch.zeros((B, K, 3), device=dev)
+    for b, (_, _, p0, p1) in enumerate(cases):
+        P0[b, : len(p0)] = T(p0); P1[b, : len(p1)] = T(p1)
+    D0 = torch.stack([T(c[0])[0] for c in cases]).contiguous(); D1 = torch.stack([T(c[1])[0] for c in cases]).contiguous()
+    n0 = torch.tensor([len(c[2]) for c in cases], dtype=torch.int32, device=dev); n1 = torch.tensor([len(c[3]) for c in cases], dtype=torch.int32, device=dev)
+    pairs = torch.empty((B, K, 2), dtype=torch.int32, device=dev); scores = torch.empty((B, K), dtype=torch.float32, device=dev)
+    k = torch.zeros((B,), dtype=torch.int32, device=dev); stop = torch.zeros((B,), dtype=torch.int32, device=dev)
+    _, C, Hd, Wd = D0.shape
+    sb, sc, sh, sw = D0.stride()
+    prm = LgParams(float(m.conf["depth_confidence"]), float(m.conf["width_confidence"]), float(m.conf["filter_threshold"]), m.prune_min_kpts)
+    ctx = m._ctx
+    ctx.check(ctx.lib.kpb_lg_match(m._handle, ptr(P0), ptr(P1), ptr(n0), ptr(n1), B, K, ptr(D0), ptr(D1), C, Hd, Wd, sb, sc, sh, sw, 320, 240,
+                                   ctypes.byref(prm), ptr(pairs), ptr(scores), ptr(k), ptr(stop)))
+    for b, (sp, ss, st) in enumerate(singles):
+        kb = int(k[b])
+        assert int(stop[b]) == st, (b, int(stop[b]), st)
+        np.testing.assert_array_equal(pairs[b, :kb].cpu().numpy(), sp.cpu().numpy().astype(np.int32), err_msg="pair %d" % b)
+        np.testing.assert_array_equal(scores[b, :kb].cpu().numpy().view(np.uint32), ss.cpu().numpy().view(np.uint32), err_msg="pair %d" % b)
