@@ -34,7 +34,10 @@ struct NmsArgs {
     //          CONFIRMED inside the border frame and above the output thresholds, one fire-and-forget atomic each.  If an image has more than top_k of
     //          them, nothing that scores below the (top_k+1)-th can reach the output, and nms_tail drops those undecided pixels unresolved; the lower
     //          edge of the bin that holds the (top_k+1)-th is such a bound (nms_score_bin).
+    //   cbits  the same layout: bit (y, x) = pixel CONFIRMED as a maximum (sweep 0 writes its tiles' bytes, nms_tail sets the bits of what it confirms):
+    //          select_topk reads these 38 KB per image instead of the 1.2 MB map when the tail has settled the image (r06).  Null: not kept.
     unsigned char* ubits; int wb;
+    unsigned char* cbits;
     unsigned* chist;
     int border;
     float cmin;         // a confirmed maximum counts when its score is > cmin (threshold / min_score of the detection)
@@ -525,6 +528,12 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_sweep_r(NmsArgs a)
                 atomicAdd(&hist[nms_score_bin(-t[(oy + 2 * R) * PITCH + ox + 2 * R + k])], 1u);
             }
             a.ubits[((size_t)img * a.H + gy) * a.wb + (gx >> 3)] = (unsigned char)umask;
+            if (a.cbits) {
+                unsigned conf = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if ((whole || gx + k < a.W) && v[k] < 0.0f) conf |= 1u << k;
+                a.cbits[((size_t)img * a.H + gy) * a.wb + (gx >> 3)] = (unsigned char)conf;
+            }
         }
     }
     if (changed) s_changed = 1;
@@ -551,6 +560,7 @@ struct TailArgs {
     int ucap, H, W, r, max_rounds;
     const unsigned char* ubits; int wb;         // sweep 0's bitmap of undecided pixels (NmsArgs)
     const unsigned* chist; int top_k;           // top-K pruning (NmsArgs); chist null: none
+    unsigned* cbits;                            // sweep 0's bitmap of confirmed maxima, as words (rows are wb bytes, a multiple of 4): the tail adds its own; null: not kept
 };
 
 constexpr int TAIL_THREADS = 1024;
@@ -728,7 +738,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void nms_tail(TailArgs a)
                 const int blocker = __shfl(blk[u], bb ? __ffsll((long long)bb) - 1 : 0, 64);
                 if (have[u] && l == 0) {
                     if (any_dead) cur[idx[u]] = 0.0f;
-                    else if (!bb) cur[idx[u]] = -v[u];
+                    else if (!bb) {
+                        cur[idx[u]] = -v[u];
+                        if (a.cbits) atomicOr(a.cbits + ((size_t)img * a.H + y[u]) * (a.wb / 4) + (x[u] >> 5), 1u << (x[u] & 31));
+                    }
                     else dst[atomicAdd(&s_nw, 1)] = make_int2(idx[u], blocker);
                 }
             }
@@ -792,6 +805,7 @@ struct SelArgs {
     int* chunk_cnt;              // [B][nchunks] two-phase form (small batches): select_scan has left chunk c's candidates at
     int nchunks;                 //   cand[c * SEL_CHUNK ...] and their number here; null: select_topk scans the map itself
     int lcap;                    // two-phase form: candidates that fit in LDS behind the kpad selection slots
+    const unsigned* cbits; int wb;      // r06: the NMS's bitmap of confirmed maxima ([B][H][wb bytes], NmsArgs): read instead of the map for an image the tail has settled
 };
 
 __device__ __forceinline__ void emit(const SelArgs& a, int img, const unsigned long long* src, int n,
@@ -892,6 +906,60 @@ __device__ __forceinline__ int scan_chunks(const SelArgs& a, const float* map, u
     return n;
 }
 
+// r06: the same list from the NMS's bitmap of confirmed maxima (signed map, threshold <= 0: every confirmed maximum is > 0 >= threshold): 38 KB of an image
+// instead of its 1.2 MB map -- the map scan is 19 rounds at the HBM rate of the whole launch (629 MB).  Four 32-pixel words per thread and round, the
+// border masked per word, raster order kept by the block scan; the scores are gathered afterwards, every load independent.
+__device__ __forceinline__ int scan_bits(const SelArgs& a, const float* map, const unsigned* bits, unsigned long long* cand, unsigned long long* wsum)
+{
+    const int tid = threadIdx.x, wq = a.wb / 4, nwords = a.H * wq, vb = (a.W + 7) / 8;
+    const int bx = min(max(a.border, 0), a.W), by = min(max(a.border, 0), a.H);
+    constexpr int G = 4;
+    int n = 0;
+    for (int c0 = 0; c0 < nwords; c0 += SEL_THREADS * G) {
+        unsigned m[G];
+        int base[G], cnt = 0;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const int w = c0 + tid * G + j;
+            const bool live = w < nwords;
+            const int row = live ? w / wq : 0, q = live ? w - row * wq : 0;
+            unsigned word = live ? bits[w] : 0u;
+            const int nb = vb - 4 * q;                          // bytes of this word inside the row (the rest was never written)
+            if (nb < 4) word = nb > 0 ? (word & ((1u << (8 * nb)) - 1u)) : 0u;
+            // columns [bx, W - bx) of rows [by, H - by)
+            const int lo = max(bx - 32 * q, 0), hi = min(a.W - bx - 32 * q, 32);
+            unsigned keep = (hi > lo && row >= by && row < a.H - by) ? ((hi >= 32 ? 0xFFFFFFFFu : ((1u << hi) - 1u)) & ~((lo >= 32) ? 0xFFFFFFFFu : ((1u << lo) - 1u))) : 0u;
+            m[j] = word & keep;
+            base[j] = row * a.W + 32 * q;
+            cnt += __popc(m[j]);
+        }
+        unsigned long long tot;
+        int pos = n + (int)block_scan((unsigned long long)cnt, wsum, tot);
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            unsigned mm = m[j];
+            while (mm) {
+                const int k = __ffs((int)mm) - 1;
+                mm &= mm - 1;
+                cand[pos++] = 0xFFFFFFFFu - (unsigned)(base[j] + k);          // the key follows
+            }
+        }
+        n += (int)tot;
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 4 * SEL_THREADS) {
+        unsigned low[4];
+        float sc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * SEL_THREADS + tid; low[j] = i < n ? (unsigned)cand[i] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sc[j] = -map[0xFFFFFFFFu - low[j]];       // a confirmed maximum is stored negated
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = i0 + j * SEL_THREADS + tid; if (i < n) cand[i] = ((unsigned long long)f2key(sc[j]) << 32) | low[j]; }
+    }
+    return n;
+}
+
 // Two-phase form, phase 1 (r04): one workgroup per SEL_CHUNK pixels and image.  select_topk is one workgroup per image -- right
 // when hundreds of images fill the chip, 129 us of one CU's latency (19 dependent rounds) for the single map `detection` hands
 // over on the drop-in path (profiles/r04_single_pair_latency.txt).
@@ -903,6 +971,9 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scan(SelArgs a)
     if (threadIdx.x == 0) a.chunk_cnt[(size_t)img * a.nchunks + c] = n;
 }
 
+// BITS (r06): the form for the launch right after sweep 0 + tail -- it reads the bitmap of confirmed maxima only; an image the tail did not settle gets no
+// candidates here (its status sends it through more sweeps and the map-reading form afterwards).  0.256 -> 0.114 ms per 512 images; at two workgroups per CU (64 registers, 17 spilled) 0.111: not taken.
+template <bool BITS>
 __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -919,7 +990,10 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk(SelArgs a)
     // A2 + A3: border mask and raster-order compaction of map > threshold
     int n = 0;
     const unsigned long long* cl = cand;        // the raster-ordered candidate list the selection below reads
-    if (a.chunk_cnt) {
+    if constexpr (BITS) {
+        if (a.lastchg[img] == 0) n = scan_bits(a, map, a.cbits + (size_t)img * a.H * (a.wb / 4), cand, wsum);
+        __syncthreads();
+    } else if (a.chunk_cnt) {
         // two-phase form: the scan ran as select_scan on (nchunks x batch) workgroups and left chunk c's list at cand[c * SEL_CHUNK].
         const int* cc = a.chunk_cnt + (size_t)img * a.nchunks;
         __shared__ int s_off[65];
@@ -1083,6 +1157,7 @@ struct NmsPlan {
     int prune_k, border;
     float cmin;
     unsigned char* ubits; int wb;       // [B][H][wb] sweep 0's bitmap of undecided pixels (NmsArgs)
+    unsigned char* cbits;               // [B][H][wb] confirmed maxima (NmsArgs)
     size_t nclear;      // ints at lastchg that nms_open clears: lastchg, negflag and the histograms
 };
 
@@ -1112,19 +1187,21 @@ int nms_plan(kpb_ctx* ctx, int batch, int H, int W, int r, NmsPlan& p, int prune
     p.ulist = nullptr;
     p.ucap = 0;
     p.prune_k = prune ? prune_k : 0; p.border = border; p.cmin = cmin;
-    p.ubits = nullptr; p.wb = 0;
+    p.ubits = nullptr; p.cbits = nullptr; p.wb = 0;
     if (tail) {
         p.ucap = std::max(4096, H * W / 8);
         p.wb = (cdiv(W, 8) + 3) & ~3;
-        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * 5 * (size_t)p.ucap * sizeof(int) + (size_t)batch * H * p.wb)) return rc;
+        const size_t nbits = (size_t)batch * H * p.wb;       // (a multiple of 4: wb is)
+        if (int rc = kpb_reserve(ctx, ctx->ws_nms_list, (size_t)batch * 5 * (size_t)p.ucap * sizeof(int) + 2 * nbits)) return rc;
         p.ulist = static_cast<int2*>(ctx->ws_nms_list.p);
         p.slist = reinterpret_cast<int*>(p.ulist + (size_t)batch * 2 * p.ucap);
         p.ubits = reinterpret_cast<unsigned char*>(p.slist + (size_t)batch * p.ucap);
+        p.cbits = p.ubits + nbits;
     }
     if (!(ctx->lds_attr_done & KPB_ATTR_NMS)) {
         KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(nms_sweep),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk),
+        KPB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(select_topk<false>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         ctx->lds_attr_done |= KPB_ATTR_NMS;
     }
@@ -1140,7 +1217,7 @@ int nms_launch(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int
         a.tchg_prev = p.tchg[(s + 1) & 1];
         a.tchg_cur = p.tchg[s & 1];
         a.lastchg = p.lastchg; a.negflag = p.negflag;
-        a.ubits = p.ubits; a.wb = p.wb; a.chist = p.chist; a.border = p.border; a.cmin = p.cmin;
+        a.ubits = p.ubits; a.cbits = p.cbits; a.wb = p.wb; a.chist = p.chist; a.border = p.border; a.cmin = p.cmin;
         a.H = H; a.W = W; a.r = r; a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
         a.sweep = s;
         a.xcd_map = 1;      // -1 % (profiles/r04_ab_knobs.txt)
@@ -1179,7 +1256,8 @@ int nms_open(kpb_ctx* ctx, const NmsPlan& p, const float* src, float* cur, int b
         return nms_launch(ctx, p, src, cur, batch, H, W, r, 0, chunk);
     }
     if (int rc = nms_launch(ctx, p, src, cur, batch, H, W, r, 0, 1)) return rc;
-    TailArgs t{cur, p.ulist, p.slist, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256), p.ubits, p.wb, p.chist, p.prune_k};
+    TailArgs t{cur, p.ulist, p.slist, p.lastchg, p.ucap, H, W, r, env_int("KPB_NMS_TAIL_ROUNDS", 256), p.ubits, p.wb, p.chist, p.prune_k,
+               reinterpret_cast<unsigned*>(p.cbits)};
     switch (r) {
     case 1: KPB_LAUNCH(ctx, "nms_tail", nms_tail<1>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
     case 2: KPB_LAUNCH(ctx, "nms_tail", nms_tail<2>, dim3(batch), dim3(TAIL_THREADS), 0, ctx->stream, t); break;
@@ -1296,6 +1374,9 @@ int det_select(kpb_ctx* ctx, const DetState& d)
     }
     s.host_status = ctx->host_det;
     s.chunk_cnt = nullptr; s.nchunks = cdiv(d.H * d.W, SEL_CHUNK); s.lcap = 0;
+    // the bitmap of confirmed maxima stands for the map right after sweep 0 + tail only (later sweeps do not keep it), and only for thresholds every maximum passes
+    const bool bits = d.plan.cbits && d.sweeps_run == 1 && !(d.prm.threshold > 0.0f) && s.signed_map;
+    s.cbits = bits ? reinterpret_cast<const unsigned*>(d.plan.cbits) : nullptr; s.wb = d.plan.wb;
     size_t lds = (size_t)s.kpad * sizeof(unsigned long long);
     if (d.batch < 64 && s.nchunks > 1) {       // too few images to fill the chip with one workgroup each: scan in (chunks x batch) workgroups first
         if (int rc = kpb_reserve(ctx, ctx->ws_sel, (size_t)d.batch * s.nchunks * sizeof(int))) return rc;
@@ -1304,7 +1385,8 @@ int det_select(kpb_ctx* ctx, const DetState& d)
         lds = 64 * 1024;
         KPB_LAUNCH(ctx, "select_scan", select_scan, dim3(s.nchunks, d.batch), dim3(SEL_THREADS), 0, ctx->stream, s);
     }
-    KPB_LAUNCH(ctx, "select_topk", select_topk, dim3(d.batch), dim3(SEL_THREADS), lds, ctx->stream, s);
+    if (bits && !s.chunk_cnt) KPB_LAUNCH(ctx, "select_topk", select_topk<true>, dim3(d.batch), dim3(SEL_THREADS), lds, ctx->stream, s);
+    else KPB_LAUNCH(ctx, "select_topk", select_topk<false>, dim3(d.batch), dim3(SEL_THREADS), lds, ctx->stream, s);
     KPB_HIP(ctx, hipGetLastError());
     return KPB_OK;
 }

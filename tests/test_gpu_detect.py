@@ -249,3 +249,28 @@ def test_nms_tail_handoff_bitmap_and_histogram_edges(monkeypatch):
                 want, _ = oracle.detection(m[b, 0], p)
                 assert int(n[b]) == len(want), (scale, b, p)
                 np.testing.assert_array_equal(kps[b, : n[b]].view(np.uint32), want.view(np.uint32), err_msg="scale %g image %d %r" % (scale, b, p))
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (237, 301), (96, 80)])
+def test_selection_from_the_bitmap_of_confirmed_maxima_equals_the_map_scan(shape, monkeypatch):
+    """r06: right after sweep 0 + tail, select_topk<BITS> reads the NMS's bitmap of confirmed maxima (a byte per eight pixels from sweep 0's owner threads, bits set
+    by the tail for what it confirms) instead of the map.  It runs for batches of 64 images and more (or one-chunk maps) when the threshold is <= 0; a threshold
+    of 1e-37 -- below every score -- sends the same detection through the map-reading form.  Both must give the same rows, bit for bit: 64 images, three
+    bitmap rounds per image at 480 x 640, a ragged width, a map smaller than one round; a few images also against the oracle."""
+    from keypoint_bench_amd.utils.extracter import detection_batch
+    monkeypatch.setenv("KPB_NMS_TILED", "0")            # (64 images are below the batch at which the tail is the default)
+    H, W = shape
+    maps = np.stack([(synthetic.score_smooth if b % 2 else synthetic.score_uniform)(700 + b, H, W) for b in range(64)])[:, None]
+    maps[5, 0, : H // 3] = (np.floor(maps[5, 0, : H // 3] * 4) / 4 + 0.25).astype(np.float32)         # plateaus: the tail has work to do, or gives up
+    x = torch.from_numpy(maps).to(_dev())
+    for nms, top_k, border in ((6, 1000, 8), (2, 300, 0)):
+        p = dict(nms_dist=nms, threshold=0.0, border_dist=border, top_k=min(top_k, H * W), min_score=0.0)
+        k0, i0, n0 = (t.cpu().numpy() for t in detection_batch(x, p))
+        k1, i1, n1 = (t.cpu().numpy() for t in detection_batch(x, dict(p, threshold=1e-37)))
+        np.testing.assert_array_equal(n0, n1)
+        for b in range(64):
+            np.testing.assert_array_equal(k0[b, : n0[b]].view(np.uint32), k1[b, : n1[b]].view(np.uint32), err_msg="image %d %r" % (b, p))
+            np.testing.assert_array_equal(i0[b, : n0[b]], i1[b, : n1[b]])
+        for b in (0, 5, 63):
+            want, _ = oracle.detection(maps[b, 0], p)
+            np.testing.assert_array_equal(k0[b, : n0[b]].view(np.uint32), want.view(np.uint32), err_msg="oracle, image %d %r" % (b, p))
