@@ -851,8 +851,12 @@ template <int NTB, int MT = 2, int EPI = GE_PLAIN, bool UNFOLD = false>
 // (at four waves per SIMD the one-tile GE_RESIDUAL / GE_ROTARY forms spill 2 / 11 registers to scratch -- their epilogue operands
 // xv sit beside the accumulators in the last slab.  r05 measured the alternative it named, three waves per SIMD for those two (132 / 144
 // registers, no scratch): ffn3 + residual 0.915 -> 1.09 ms per 18 launches, three interleaved runs -- the spill is the cheaper evil; loading
-// the second k-block's weight fragments behind the first one's products changed nothing, the scheduler hoists them back.)
-__global__ __launch_bounds__(256, MT == 1 ? 4 : 2) void gemm_h(ConvM a)
+// the second k-block's weight fragments behind the first one's products changed nothing, the scheduler hoists them back.
+//  r06: measured per form -- the ROTARY form alone at three waves per SIMD (144 registers, its 11 spilled registers gone): lg_Wqkv 0.091 -> 0.077 ms per launch, and it
+//  takes them; the RESIDUAL form stays at four.  The weight fragments through LDS, once per workgroup by LDS-DMA a slab ahead with one barrier per slab (53 KB: three
+//  workgroups per CU), help only that same form and by the same amount (it is the spills, not the bytes): ffn3 +18 %, to_out / out_proj +14 %, ffn0 +3 %.
+//  profiles/r06_gemm_forms_ab.txt)
+__global__ __launch_bounds__(256, MT == 1 ? (EPI == GE_ROTARY ? 3 : 4) : 2) void gemm_h(ConvM a)
 {
     // r03: a wave stages exactly the 32 MT rows it multiplies, so its slice of the LDS buffers is private to it (a wave's LDS
     // operations execute in order: no barrier anywhere in the kernel) and the activation scale is chosen PER WAVE from the

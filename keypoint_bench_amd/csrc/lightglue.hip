@@ -811,12 +811,12 @@ __global__ __launch_bounds__(256) void lg_emit(const float* bestv, const int* be
             float cv = -INFINITY; int ci = 0x7FFFFFFF;
             if (j < MP) {       // (no column won: bi = 0x7FFFFFFF, e.g. a row of NaNs)
                 int cc = -1;
-                for (int c0 = 0; c0 < nch; c0 += 16) {          // sixteen partials in flight, then the comparisons
+                for (int q0 = 0; q0 < nch; q0 += 16) {          // sixteen partials in flight, then the comparisons
                     float pv[16];
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) pv[c] = c0 + c < nch ? pbv[((size_t)b * NCH + c0 + c) * MP + j] : -INFINITY;
+                    for (int c = 0; c < 16; ++c) pv[c] = q0 + c < nch ? pbv[((size_t)b * NCH + q0 + c) * MP + j] : -INFINITY;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) if (pv[c] > cv) { cv = pv[c]; cc = c0 + c; }
+                    for (int c = 0; c < 16; ++c) if (pv[c] > cv) { cv = pv[c]; cc = q0 + c; }
                 }
                 if (cc >= 0) ci = pbi[((size_t)b * NCH + cc) * MP + j];
             }

@@ -53,9 +53,9 @@ NO_DEST = ("s_waitcnt", "s_nop", "s_barrier", "s_branch", "s_cbranch", "s_endpgm
            "flat_store", "scratch_store", "s_setprio", "s_sleep", "global_load_lds", "s_setreg", "s_sendmsg", "s_code_end", "s_setpc", "s_icache",
            "s_dcache", "buffer_wbl2", "buffer_inv", "s_trap", "s_waitcnt_", "ds_nop", "s_endpgm_saved", "s_set_gpr", "v_nop", "s_wakeup", "s_getpc_dummy")
 TWO_DEST = ("v_add_co", "v_sub_co", "v_subrev_co", "v_addc_co", "v_subb_co", "v_subbrev_co", "v_div_scale", "v_mad_u64", "v_mad_i64")
-# kernels known to spill, with the most dwords they may: gemm_h's one-tile epilogue forms at four waves per SIMD (three without spills measured
-# slower, conv_mfma.h), the rarely used radius-7 / 8 forms of the sparse NMS tail (1024 threads: 128 registers)
-KNOWN_SPILLS = {"gemm_hILi2ELi1ELi0ELb1E": 3, "gemm_hILi2ELi1ELi1ELb0E": 1, "gemm_hILi2ELi1ELi2ELb0E": 10, "nms_tailILi7E": 6, "nms_tailILi8E": 215}
+# kernels known to spill, with the most dwords they may: gemm_h's one-tile plain / residual forms at four waves per SIMD (three without spills measured
+# slower, conv_mfma.h; the rotary form runs at three since r06), the rarely used radius-7 / 8 forms of the sparse NMS tail (1024 threads: 128 registers)
+KNOWN_SPILLS = {"gemm_hILi2ELi1ELi0ELb1E": 3, "gemm_hILi2ELi1ELi1ELb0E": 1, "nms_tailILi7E": 6, "nms_tailILi8E": 215}
 ASM_ALLOWED = re.compile(r"^(s_waitcnt|s_nop|s_mov_b32|s_mov_b64|global_load_lds_dwordx4|global_load_lds_dword|s_memtime|s_sleep|s_setprio)\b")
 
 
